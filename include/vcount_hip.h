@@ -1,0 +1,179 @@
+/* libvcount_hip.so -- C ABI of the MI355X-native detect + track hot path of kaylode/vehicle-counting.
+ *
+ * The reference is pure Python and has no FFI layer; its seam is the duck-typed stage API that
+ * modules/__init__.py:54-84 (CountingPipeline.run) calls.  Each group of entry points below is what a
+ * ctypes binding of one of those Python operators would call (see INTEGRATION.md for the stubs):
+ *
+ *   vc_detect*            <- modules/detect.py:30-60 ImageDetect.run -> networks/detector.py:36-38
+ *                            -> networks/yolo.py:68-99 YoloBackbone.detect (AutoShape forward: letterbox, YOLOv5
+ *                            v6.0 conv stack, Detect decode, NMS, scale_coords)
+ *   vc_embed              <- networks/deepsort/deep/feature_extractor.py:42-47 Extractor.__call__ on the crops
+ *                            cut by networks/deepsort/deep_sort.py:119-129 DeepSort._get_features
+ *   vc_tracker_* / vc_deepsort_update
+ *                         <- networks/deepsort/deep_sort.py:25-59 DeepSort.update
+ *                            (sort/tracker.py:50-91 Tracker.predict/update and everything below it)
+ *   vc_videotracker_run   <- modules/track.py:30-70 VideoTracker.run (one DeepSORT per class)
+ *   vc_stream_*           <- the per-frame body of modules/__init__.py:54-84 for device-resident frames
+ *   vc_*_host             <- single-function entry points used by the parity tests (one reference function each)
+ *
+ * Conventions: every function returns an int status (VC_OK == 0); vc_last_error() gives the message for
+ * the calling thread.  Handles are opaque, thread-compatible (not thread-safe), own their device memory
+ * and HIP streams, and never call back into the caller.  All array arguments are caller-owned plain
+ * host pointers unless the name says `_dev`; outputs are caller-allocated.  No torch types anywhere.
+ */
+#ifndef VCOUNT_HIP_H
+#define VCOUNT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_ERR_ARG 1       /* bad argument / shape */
+#define VC_ERR_HIP 2       /* HIP runtime error (no device, OOM, launch failure) */
+#define VC_ERR_STATE 3     /* call order (e.g. run before finalize) */
+#define VC_ERR_CAPACITY 4  /* a configured capacity (tracks, candidates, crops) was exceeded */
+#define VC_ERR_NOTFOUND 5  /* unknown parameter name / handle id */
+
+#define VC_PREC_BF16 0     /* bf16 activations/weights, fp32 accumulate (throughput mode) */
+#define VC_PREC_F32 1      /* fp32 everywhere (tight-parity mode) */
+
+#define VC_FEAT_DIM 512    /* networks/deepsort/deep/model.py: embedding width */
+#define VC_REID_SIZE 50    /* feature_extractor.py:18 */
+
+int vc_version(void);
+const char* vc_last_error(void);
+int vc_device_count(int* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine: one per process / GPU.  Holds the detector, the ReID net, the tracker pool and the streams.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vc_engine vc_engine;
+
+typedef struct vc_engine_config {
+    int device;            /* HIP device ordinal */
+    int precision;         /* VC_PREC_* */
+    int yolo_variant;      /* 0 = yolov5s, 1 = yolov5m, 2 = yolov5l  (configs/configs.yaml: model_name) */
+    int num_classes;       /* detector classes == tracker fan-out (modules/__init__.py:33) */
+    int img_size;          /* AutoShape `size`, 640 in the reference (quirk Q8) */
+    int max_batch;         /* frames per detect launch */
+    int max_frame_h, max_frame_w; /* largest source frame */
+    float conf_thres;      /* configs/configs.yaml: min_conf 0.25 */
+    float iou_thres;       /* configs/configs.yaml: min_iou 0.45 */
+    int max_det;           /* configs/configs.yaml: max_det 300 */
+    int max_candidates;    /* per-frame cap on boxes entering NMS (upstream max_nms = 30000) */
+    int max_crops;         /* ReID crops per launch */
+    int max_tracks;        /* live tracks over all trackers */
+    int nn_budget_cap;     /* largest NN_BUDGET any tracker will ask for */
+    int with_detector;     /* 0: skip building the YOLO plan (track-only users) */
+    int with_reid;         /* 0: skip building the ReID plan */
+} vc_engine_config;
+
+int vc_engine_config_default(vc_engine_config* cfg);
+int vc_engine_create(const vc_engine_config* cfg, vc_engine** out);
+int vc_engine_destroy(vc_engine* e);
+
+/* Parameters: conv layers addressed by the checkpoint's own names ("model.0.conv", "layer2.0.conv1", ...);
+ * weights OIHW fp32 with BatchNorm already folded (vehicle-counting_amd/weights.py: fold_bn). */
+#define VC_NET_YOLO 0
+#define VC_NET_REID 1
+int vc_engine_param_count(const vc_engine* e, int net, int* n);
+int vc_engine_param_info(const vc_engine* e, int net, int index, char* name, int name_cap, int dims[4] /* O,I,kh,kw */);
+int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w_oihw, const float* bias);
+int vc_engine_finalize(vc_engine* e); /* packs + uploads weights; detector/ReID calls are valid afterwards */
+
+/* ---- detect: ImageDetect.run ------------------------------------------------------------------ */
+/* rgb[i]: H[i] x W[i] x 3 uint8 RGB.  out_det: n * max_det * 6 floats [x1,y1,x2,y2,conf,cls] in source pixels
+ * (what AutoShape returns in results.xyxy); out_count[i] = detections of image i.  All images of one call
+ * share the AutoShape inference shape (models/common.py v6.0). */
+int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* w, int n, float* out_det, int* out_count);
+/* Diagnostics for tensor-level parity: the network tensor the detector saw, raw head, candidates. */
+int vc_detect_debug_shape(const vc_engine* e, int* net_h, int* net_w, int* n_candidates);
+int vc_detect_debug_layer(vc_engine* e, int layer /* 0..23, or -1 = preprocessed input */, float* out_nhwc, size_t cap_floats,
+                          int dims[4] /* B,H,W,C */);
+int vc_detect_debug_pred(vc_engine* e, float* out /* B * n_candidates * (5+nc) */, size_t cap_floats);
+
+/* ---- embed: Extractor.__call__ over DeepSort._get_features crops -------------------------------- */
+/* bgr: H x W x 3 uint8 (the `ori_img` the reference crops from).  boxes_cxcywh: k x 4 float64 centre boxes
+ * (deep_sort.py:28 bbox_xywh).  out_feat: k x 512 float32, unit L2 norm. */
+int vc_embed(vc_engine* e, const uint8_t* bgr, int h, int w, const double* boxes_cxcywh, int k, float* out_feat);
+int vc_embed_tensor(vc_engine* e, const float* x_nchw /* k x 3 x 50 x 50 */, int k, float* out_feat);
+
+/* ---- tracker: sort/tracker.py + deep_sort.py ------------------------------------------------------ */
+typedef struct vc_tracker_params {
+    double max_dist;          /* MAX_DIST          (cosine matching threshold) */
+    double min_confidence;    /* MIN_CONFIDENCE */
+    double nms_max_overlap;   /* NMS_MAX_OVERLAP */
+    double max_iou_distance;  /* MAX_IOU_DISTANCE */
+    int max_age;              /* MAX_AGE */
+    int n_init;               /* N_INIT */
+    int nn_budget;            /* NN_BUDGET (<= engine nn_budget_cap) */
+} vc_tracker_params;
+
+int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* tracker_id);
+int vc_tracker_reset(vc_engine* e, int tracker_id);
+/* Tracker.predict() + Tracker.update(detections) for detections already filtered/NMS'ed by the caller.
+ * tlwh: k x 4 f64, conf: k f64, feat: k x 512 f32 (host). */
+int vc_tracker_step(vc_engine* e, int tracker_id, const double* tlwh, const double* conf, const float* feat, int k);
+/* Snapshot of the live tracks in list order (sort/tracker.py: self.tracks). Any pointer may be NULL. */
+int vc_tracker_count(vc_engine* e, int tracker_id, int* n);
+int vc_tracker_state(vc_engine* e, int tracker_id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu,
+                     double* mean8, double* cov64, int* gallery_count);
+/* DeepSort.update: boxes xyxy (k x 4 f64) + confidences on a BGR frame -> rows [x1,y1,x2,y2,track_id,-1,0]. */
+int vc_deepsort_update(vc_engine* e, int tracker_id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy,
+                       const double* conf, int k, int64_t* out_rows7, int cap_rows, int* out_m);
+/* VideoTracker.run: trackers[c] is the tracker id of class c.  boxes xywh (top-left), labels, scores as
+ * ImageDetect.run returns them.  Output rows [x1,y1,x2,y2,track_id,label]. */
+int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, const uint8_t* bgr, int h, int w,
+                        const double* boxes_xywh, const int64_t* labels, const double* scores, int n,
+                        int64_t* out_rows6, int cap_rows, int* out_m);
+
+/* ---- fused stream path: the per-frame body of CountingPipeline.run on device-resident frames -------- */
+/* frames_dev: device pointer to B x H x W x 3 uint8 *BGR* frames (cv2.VideoCapture order; the RGB view
+ * the detector needs is taken on the fly).  Results per frame: rows [x1,y1,x2,y2,track_id,label]. */
+int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);
+/* Detection injection for throughput studies: replaces the detector's NMS output of the next
+ * vc_stream_run frames with caller boxes after the conv stack has run. NULL clears. */
+int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+#define VC_PROF_CONV 0       /* all implicit-GEMM conv launches */
+#define VC_PROF_DETECT_AUX 1 /* letterbox, pools, upsample, decode, NMS */
+#define VC_PROF_REID_AUX 2   /* crop/resize, pools, L2 norm */
+#define VC_PROF_TRACK 3      /* Kalman, cost matrices */
+#define VC_PROF_NCAT 4
+int vc_profile_enable(vc_engine* e, int on);   /* brackets every launch with hipEvents on its own stream; disables graphs */
+int vc_profile_read(vc_engine* e, int category, double* total_ms, int64_t* launches, double* flops, double* bytes);
+int vc_profile_reset(vc_engine* e);
+int vc_engine_sync(vc_engine* e);
+
+/* ---- single-function entry points (parity tests; each runs the device kernel on host arrays) ------- */
+typedef struct vc_conv_desc {
+    int b, h, w, cin, cout, kh, kw, stride, pad;
+    int act;         /* 0 none, 1 SiLU, 2 ReLU */
+    int res_mode;    /* 0 none, 1 add after act, 2 add before act */
+    int precision;   /* VC_PREC_* */
+} vc_conv_desc;
+/* x NHWC f32, w OIHW f32, bias f32[cout], res NHWC f32 or NULL, y NHWC f32 (bf16 mode rounds x, w, res, y). */
+int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res, float* y);
+int vc_kalman_initiate_host(const double* xyah, int n, double* mean8, double* cov64);
+int vc_kalman_predict_host(double* mean8, double* cov64, int n);
+int vc_kalman_update_host(double* mean8, double* cov64, const double* z4, int n);
+int vc_kalman_gating_host(const double* mean8, const double* cov64, const double* z4, int n_meas, double* out);
+int vc_iou_cost_host(const double* track_tlwh, int t, const double* det_tlwh, int d, double* out_iou);
+int vc_cosine_cost_host(const float* gallery, const int* gal_count, int t, int s_cap, const float* feat, int d, double* out);
+int vc_dsort_nms_host(const double* tlwh, const double* scores, int n, double max_overlap, int* keep, int* n_keep);
+int vc_lap_host(const double* cost, int nr, int nc, int* row4col_rows, int* cols, int* n_assigned);
+int vc_letterbox_host(const uint8_t* rgb, int h, int w, int net_h, int net_w, int precision, float* out_nhwc3);
+/* candidates (already conf-filtered, in the reference's candidate order): boxes xyxy, conf, class -> kept rows */
+int vc_nms_host(const float* boxes4, const float* conf, const int* cls, int n, float iou, int max_det, int max_cand,
+                float* out6, int* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCOUNT_HIP_H */

@@ -1,0 +1,117 @@
+"""GPU: detector and ReID network parity (tensor level and end to end) through the C ABI against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from oracle import reid as orr  # noqa: E402
+from oracle import yolov5 as oy  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+
+NC = 8      # small head keeps the CPU oracle fast; the 80-class head is exercised by bench/smoke
+
+
+@pytest.fixture(scope="module")
+def yolo_sd():
+    return synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    return synth_frames(2, 360, 640, n_obj=6, seed=3)      # BGR uint8, (2, 360, 640, 3)
+
+
+def nchw(x_nhwc):
+    return np.ascontiguousarray(x_nhwc.transpose(0, 3, 1, 2))
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_detector_layers_and_pred(yolo_sd, frames, precision):
+    eng = E.Engine(yolo_sd, None, precision=precision, num_classes=NC, max_batch=2, max_frame_hw=(360, 640))
+    imgs = [f[:, :, ::-1] for f in frames]              # RGB views like VideoSet hands to the detector
+    eng.debug_pred(arm=True)
+    dets = eng.detect(imgs)
+    x, shape0, shape1 = oy.preprocess(imgs, 640)
+    assert shape1 == [384, 640]
+    pred, ys, raw = oy.forward(yolo_sd, x, "yolov5s", NC, return_layers=True)
+    inp = eng.debug_layer(-1, batch=2)
+    if precision == "f32":
+        np.testing.assert_array_equal(nchw(inp), x)      # letterbox + /255 is exact
+    # tolerances: SURVEY.md 8d ladder (1): f32 rel <= 1e-4 per tensor (observed margin recorded in DESIGN.md);
+    # bf16 <= 2e-2 of the tensor's max magnitude
+    tol = 1e-4 if precision == "f32" else 2e-2
+    for layer in (0, 1, 2, 4, 6, 8, 9, 10, 13, 17, 20, 23):
+        got = nchw(eng.debug_layer(layer, batch=2))
+        ref = ys[layer].numpy()
+        assert got.shape == ref.shape, (layer, got.shape, ref.shape)
+        assert rel_err(got, ref) <= tol, (layer, rel_err(got, ref))
+    got_pred = eng.debug_pred()[:2]
+    ref_pred = pred.numpy()
+    assert got_pred.shape == ref_pred.shape
+    if precision == "f32":
+        np.testing.assert_allclose(got_pred[..., :4], ref_pred[..., :4], rtol=1e-3, atol=2e-2)
+        np.testing.assert_allclose(got_pred[..., 4:], ref_pred[..., 4:], rtol=0, atol=2e-4)
+    ref_dets = oy.autoshape_detect(yolo_sd, imgs, "yolov5s", NC)
+    if precision == "f32":
+        for d, r in zip(dets, ref_dets):
+            assert len(d) == len(r) and len(r) > 0
+            np.testing.assert_array_equal(d[:, 5], r[:, 5])
+            np.testing.assert_allclose(d[:, :4], r[:, :4], rtol=0, atol=5e-2)      # pixels
+            np.testing.assert_allclose(d[:, 4], r[:, 4], rtol=0, atol=2e-4)
+    else:
+        # ladder (2): every reference box with conf >= 0.30 has a same-class partner with IoU >= 0.9 and |dconf| <= 3e-2
+        for d, r in zip(dets, ref_dets):
+            for rb in r[r[:, 4] >= 0.30]:
+                same = d[d[:, 5] == rb[5]]
+                assert len(same) > 0
+                ix = np.maximum(0, np.minimum(same[:, 2], rb[2]) - np.maximum(same[:, 0], rb[0]))
+                iy = np.maximum(0, np.minimum(same[:, 3], rb[3]) - np.maximum(same[:, 1], rb[1]))
+                inter = ix * iy
+                iou = inter / ((same[:, 2] - same[:, 0]) * (same[:, 3] - same[:, 1]) + (rb[2] - rb[0]) * (rb[3] - rb[1]) - inter)
+                j = int(iou.argmax())
+                assert iou[j] >= 0.9 and abs(same[j, 4] - rb[4]) <= 3e-2, (rb, iou[j], same[j])
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_reid_forward_golden(golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, "reid_forward.npz"))
+    eng = E.Engine(None, synth_reid(int(g["seed"])), precision=precision, max_crops=16)
+    y = eng.embed_tensor(g["x"])
+    np.testing.assert_allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
+    cos = (y * g["y"]).sum(1)
+    if precision == "f32":
+        np.testing.assert_allclose(y, g["y"], rtol=0, atol=2e-5)        # golden = the reference's own Net output
+    else:
+        assert cos.min() >= 0.999, cos                                   # cosine >= 0.999 on embeddings
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_embed_crops(frames, precision):
+    sd = synth_reid(1702)
+    eng = E.Engine(None, sd, precision=precision, max_crops=16, max_frame_hw=(360, 640))
+    img = frames[0]
+    boxes = np.array([[100.3, 80.7, 60.2, 90.9], [320.0, 200.0, 50.0, 50.0], [10.0, 12.0, 40.0, 60.0],
+                      [630.0, 350.0, 80.0, 70.0], [300.5, 180.5, 101.0, 33.0]])           # cx, cy, w, h (incl. clamped + exact 50x50)
+    y = eng.embed(img, boxes)
+    crops = []
+    from oracle.deepsort import crop_corners
+    for b in boxes:
+        x1, y1, x2, y2 = crop_corners(b, img.shape[1], img.shape[0])
+        crops.append(img[y1:y2, x1:x2])
+    ref = orr.make_embedder(sd)(crops)
+    if precision == "f32":
+        np.testing.assert_allclose(y, ref, rtol=0, atol=3e-5)
+    else:
+        assert (y * ref).sum(1).min() >= 0.999
+    eng.close()

@@ -1,0 +1,131 @@
+"""ctypes binding of libvcount_hip.so (C ABI in include/vcount_hip.h).  No fallback: if the library is absent or a
+call fails, a VcError is raised -- the product never computes the hot path on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcount_hip.so")
+
+VC_OK = 0
+PREC_BF16, PREC_F32 = 0, 1
+NET_YOLO, NET_REID = 0, 1
+FEAT_DIM = 512
+PROF_CONV, PROF_DETECT_AUX, PROF_REID_AUX, PROF_TRACK = 0, 1, 2, 3
+
+
+class VcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvcount_hip status {code}: {msg}")
+        self.code = code
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("precision", C.c_int), ("yolo_variant", C.c_int), ("num_classes", C.c_int),
+                ("img_size", C.c_int), ("max_batch", C.c_int), ("max_frame_h", C.c_int), ("max_frame_w", C.c_int),
+                ("conf_thres", C.c_float), ("iou_thres", C.c_float), ("max_det", C.c_int), ("max_candidates", C.c_int),
+                ("max_crops", C.c_int), ("max_tracks", C.c_int), ("nn_budget_cap", C.c_int),
+                ("with_detector", C.c_int), ("with_reid", C.c_int)]
+
+
+class TrackerParams(C.Structure):
+    _fields_ = [("max_dist", C.c_double), ("min_confidence", C.c_double), ("nms_max_overlap", C.c_double),
+                ("max_iou_distance", C.c_double), ("max_age", C.c_int), ("n_init", C.c_int), ("nn_budget", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("b", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("act", C.c_int), ("res_mode", C.c_int),
+                ("precision", C.c_int)]
+
+
+_P = C.POINTER
+_vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
+_pf, _pd, _pi, _pl, _pu8 = _P(C.c_float), _P(C.c_double), _P(C.c_int), _P(C.c_int64), _P(C.c_uint8)
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/vcount_hip.h one to one
+SIGNATURES = {
+    "vc_version": [],
+    "vc_last_error": [],
+    "vc_device_count": [_pi],
+    "vc_engine_config_default": [_P(EngineConfig)],
+    "vc_engine_create": [_P(EngineConfig), _P(_vp)],
+    "vc_engine_destroy": [_vp],
+    "vc_engine_param_count": [_vp, _i, _pi],
+    "vc_engine_param_info": [_vp, _i, _i, C.c_char_p, _i, _pi],
+    "vc_engine_set_param": [_vp, _i, C.c_char_p, _pf, _pf],
+    "vc_engine_finalize": [_vp],
+    "vc_engine_sync": [_vp],
+    "vc_detect": [_vp, _P(_vp), _pi, _pi, _i, _pf, _pi],
+    "vc_detect_debug_shape": [_vp, _pi, _pi, _pi],
+    "vc_detect_debug_layer": [_vp, _i, _pf, C.c_size_t, _pi],
+    "vc_detect_debug_pred": [_vp, _pf, C.c_size_t],
+    "vc_embed": [_vp, _pu8, _i, _i, _pd, _i, _pf],
+    "vc_embed_tensor": [_vp, _pf, _i, _pf],
+    "vc_tracker_create": [_vp, _P(TrackerParams), _pi],
+    "vc_tracker_reset": [_vp, _i],
+    "vc_tracker_step": [_vp, _i, _pd, _pd, _pf, _i],
+    "vc_tracker_count": [_vp, _i, _pi],
+    "vc_tracker_state": [_vp, _i, _i, _pl, _pi, _pi, _pi, _pi, _pd, _pd, _pi],
+    "vc_deepsort_update": [_vp, _i, _pu8, _i, _i, _pd, _pd, _i, _pl, _i, _pi],
+    "vc_videotracker_run": [_vp, _pi, _i, _pu8, _i, _i, _pd, _pl, _pd, _i, _pl, _i, _pi],
+    "vc_stream_run": [_vp, _pi, _i, _vp, _i, _i, _i, _pl, _i, _pi, _pi],
+    "vc_stream_inject": [_vp, _pf, _pi, _i, _i],
+    "vc_profile_enable": [_vp, _i],
+    "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
+    "vc_profile_reset": [_vp],
+    "vc_conv2d_host": [_P(ConvDesc), _pf, _pf, _pf, _pf, _pf],
+    "vc_kalman_initiate_host": [_pd, _i, _pd, _pd],
+    "vc_kalman_predict_host": [_pd, _pd, _i],
+    "vc_kalman_update_host": [_pd, _pd, _pd, _i],
+    "vc_kalman_gating_host": [_pd, _pd, _pd, _i, _pd],
+    "vc_iou_cost_host": [_pd, _i, _pd, _i, _pd],
+    "vc_cosine_cost_host": [_pf, _pi, _i, _i, _pf, _i, _pd],
+    "vc_dsort_nms_host": [_pd, _pd, _i, _d, _pi, _pi],
+    "vc_lap_host": [_pd, _i, _i, _pi, _pi, _pi],
+    "vc_letterbox_host": [_pu8, _i, _i, _i, _i, _i, _pf],
+    "vc_nms_host": [_pf, _pf, _pi, _i, _f, _i, _i, _pf, _pi],
+}
+_RESTYPE = {"vc_last_error": C.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library with all prototypes set."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VcError(-1, f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(code):
+    if code != VC_OK:
+        raise VcError(code, lib().vc_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a, ctype):
+    """Pointer to a C-contiguous numpy array of the matching dtype (or NULL for None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(_P(ctype))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

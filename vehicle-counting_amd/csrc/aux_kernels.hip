@@ -1,0 +1,366 @@
+// HBM-bound kernels around the convolutions: letterbox, SPPF pooling, nearest upsample, ReID crop/resize,
+// max/avg pooling and the L2 norm.  All are streaming kernels: 16-byte vector accesses along the NHWC
+// channel axis, one pass over the data, grid-stride over (pixel, channel-vector) items.
+//
+// Reference rows: A5 (AutoShape letterbox, ultralytics/yolov5 v6.0 utils/augmentations.py
+// restated in oracle/imageops.py), A6 (SPPF / Upsample / Concat), B3-B4
+// (/root/reference/networks/deepsort/deep_sort.py:89-95,119-129 and deep/feature_extractor.py:26-39), B5 pools
+// (/root/reference/networks/deepsort/deep/model.py:58,70,93).
+#include "kernels.h"
+
+#pragma clang fp contract(off)   // restated arithmetic must round like the reference's separate mul/add
+
+namespace vc {
+
+static inline int grid_for(long items, int block) {
+    long g = (items + block - 1) / block;
+    if (g > 256L * 8) g = 256L * 8;       // grid-stride beyond 8 blocks per CU
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------ vector helpers
+template <bool F32> struct Vec;
+template <> struct Vec<true> {            // 4 x f32
+    static constexpr int N = 4;
+    float v[4];
+    __device__ static Vec load(const void* p) { Vec r; const float4 t = *(const float4*)p; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+    __device__ void store(void* p) const { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<false> {           // 8 x bf16, held as f32
+    static constexpr int N = 8;
+    float v[8];
+    __device__ static Vec load(const void* p) {
+        Vec r; const uint4 t = *(const uint4*)p; const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r.v[2 * i] = bf16_to_f32((uint16_t)(w[i] & 0xffff)); r.v[2 * i + 1] = bf16_to_f32((uint16_t)(w[i] >> 16)); }
+        return r;
+    }
+    __device__ void store(void* p) const {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+        *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ letterbox (A5)
+// cv::resize INTER_LINEAR on 8-bit data: 11-bit fixed point coefficients, see oracle/imageops.py.
+__device__ __forceinline__ void lin_coef(int d, int src, double scale, int& s0, int& s1, int& c0, int& c1, bool horizontal) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (horizontal) {
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        s0 = s; s1 = min(s + 1, src - 1);
+    } else {
+        s0 = min(max(s, 0), src - 1); s1 = min(max(s + 1, 0), src - 1);
+    }
+    c0 = min(max(__float2int_rn((1.f - f) * 2048.f), -32768), 32767);
+    c1 = min(max(__float2int_rn(f * 2048.f), -32768), 32767);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, void* __restrict__ dst, int B, LetterboxGeom g) {
+    const long total = (long)B * g.net_h * g.net_w;
+    const bool resize = !(g.unpad_h == g.src_h && g.unpad_w == g.src_w);
+    const double sx = 1.0 / ((double)g.unpad_w / (double)g.src_w), sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % g.net_w);
+        const int y = (int)((i / g.net_w) % g.net_h);
+        const int b = (int)(i / ((long)g.net_w * g.net_h));
+        int px[3] = {114, 114, 114};
+        const int ux = x - g.left, uy = y - g.top;
+        if (ux >= 0 && ux < g.unpad_w && uy >= 0 && uy < g.unpad_h) {
+            const uint8_t* im = src + (size_t)b * g.src_h * g.src_w * 3;
+            if (!resize) {
+                const uint8_t* q = im + ((size_t)uy * g.src_w + ux) * 3;
+                px[0] = q[0]; px[1] = q[1]; px[2] = q[2];
+            } else {
+                int x0, x1, a0, a1, y0, y1, b0, b1;
+                lin_coef(ux, g.src_w, sx, x0, x1, a0, a1, true);
+                lin_coef(uy, g.src_h, sy, y0, y1, b0, b1, false);
+                const uint8_t* r0 = im + (size_t)y0 * g.src_w * 3;
+                const uint8_t* r1 = im + (size_t)y1 * g.src_w * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+                    const int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    px[c] = min(max(v, 0), 255);
+                }
+            }
+        }
+        if (g.swap_rb && ux >= 0 && ux < g.unpad_w && uy >= 0 && uy < g.unpad_h) { const int t = px[0]; px[0] = px[2]; px[2] = t; }
+        const float f0 = (float)px[0] / 255.f, f1 = (float)px[1] / 255.f, f2 = (float)px[2] / 255.f;
+        if (F32) {
+            ((float4*)dst)[i] = make_float4(f0, f1, f2, 0.f);
+        } else {
+            uint2 t;
+            t.x = (uint32_t)f32_to_bf16(f0) | ((uint32_t)f32_to_bf16(f1) << 16);
+            t.y = (uint32_t)f32_to_bf16(f2);
+            ((uint2*)dst)[i] = t;
+        }
+    }
+}
+
+int launch_letterbox(const uint8_t* src, void* dst, int B, const LetterboxGeom& g, int prec, hipStream_t s) {
+    const long total = (long)B * g.net_h * g.net_w;
+    if (prec == PREC_F32) hipLaunchKernelGGL(letterbox_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst, B, g);
+    else hipLaunchKernelGGL(letterbox_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst, B, g);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ SPPF pooling (A6)
+// Three chained MaxPool2d(5,1,2) == max over 5x5, 9x9, 13x13 windows of x (padding behaves as -inf).
+template <bool F32>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(View cat, int C) {
+    using V = Vec<F32>;
+    constexpr int ES = F32 ? 4 : 2;
+    const int cv = C / V::N;
+    const long total = (long)cat.B * cat.H * cat.W * cv;
+    char* base = (char*)cat.ptr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V::N;
+        long pix = i / cv;
+        const int x = (int)(pix % cat.W);
+        const int y = (int)((pix / cat.W) % cat.H);
+        const int b = (int)(pix / ((long)cat.W * cat.H));
+        V m1, m2, m3;
+#pragma unroll
+        for (int j = 0; j < V::N; ++j) m1.v[j] = m2.v[j] = m3.v[j] = -INFINITY;
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= cat.H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= cat.W) continue;
+                const V t = V::load(base + ((((size_t)b * cat.H + yy) * cat.W + xx) * cat.cs + cat.co + c) * ES);
+                const int r = max(abs(dx), abs(dy));
+#pragma unroll
+                for (int j = 0; j < V::N; ++j) {
+                    m3.v[j] = fmaxf(m3.v[j], t.v[j]);
+                    if (r <= 4) m2.v[j] = fmaxf(m2.v[j], t.v[j]);
+                    if (r <= 2) m1.v[j] = fmaxf(m1.v[j], t.v[j]);
+                }
+            }
+        }
+        char* o = base + ((((size_t)b * cat.H + y) * cat.W + x) * cat.cs + cat.co + c) * ES;
+        m1.store(o + (size_t)C * ES);
+        m2.store(o + (size_t)2 * C * ES);
+        m3.store(o + (size_t)3 * C * ES);
+    }
+}
+
+int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
+    const int n = prec == PREC_F32 ? 4 : 8;
+    VC_CHECK(C % n == 0 && cat.cs % n == 0 && cat.co % n == 0, VC_ERR_ARG, "sppf: channel alignment");
+    const long total = (long)cat.B * cat.H * cat.W * (C / n);
+    if (prec == PREC_F32) hipLaunchKernelGGL(sppf_pool_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, cat, C);
+    else hipLaunchKernelGGL(sppf_pool_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, cat, C);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ nearest 2x upsample
+template <int ES>
+__global__ __launch_bounds__(256) void upsample2x_kernel(View src, View dst) {
+    constexpr int N = 16 / ES;
+    const int cv = src.C / N;
+    const long total = (long)dst.B * dst.H * dst.W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * N;
+        long pix = i / cv;
+        const int x = (int)(pix % dst.W);
+        const int y = (int)((pix / dst.W) % dst.H);
+        const int b = (int)(pix / ((long)dst.W * dst.H));
+        const uint4 t = *(const uint4*)((const char*)src.ptr + ((((size_t)b * src.H + (y >> 1)) * src.W + (x >> 1)) * src.cs + src.co + c) * ES);
+        *(uint4*)((char*)dst.ptr + ((((size_t)b * dst.H + y) * dst.W + x) * dst.cs + dst.co + c) * ES) = t;
+    }
+}
+
+int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s) {
+    const int n = prec == PREC_F32 ? 4 : 8;
+    VC_CHECK(src.C % n == 0 && src.cs % n == 0 && src.co % n == 0 && dst.cs % n == 0 && dst.co % n == 0, VC_ERR_ARG, "upsample: alignment");
+    VC_CHECK(dst.H == 2 * src.H && dst.W == 2 * src.W && dst.B == src.B, VC_ERR_ARG, "upsample: shape");
+    const long total = (long)dst.B * dst.H * dst.W * (src.C / n);
+    if (prec == PREC_F32) hipLaunchKernelGGL(upsample2x_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst);
+    else hipLaunchKernelGGL(upsample2x_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ ReID crop + resize (B3/B4)
+// cv2.resize(im.astype(float32)/255., (50,50)) on float data: horizontal pass then vertical pass in f32,
+// then torchvision Normalize; restated in oracle/imageops.py::resize_linear_f32 + oracle/reid.py::preprocess_crops.
+__device__ __forceinline__ void lin_coef_f(int d, int src, double scale, int& s0, int& s1, float& c0, float& c1, bool horizontal) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (horizontal) {
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        s0 = s; s1 = min(s + 1, src - 1);
+    } else {
+        s0 = min(max(s, 0), src - 1); s1 = min(max(s + 1, 0), src - 1);
+    }
+    c0 = 1.f - f; c1 = f;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restrict__ frames, int H, int W, const int* __restrict__ crops5,
+                                                          int k, void* __restrict__ dst, int cpad) {
+    constexpr int S = VC_REID_SIZE;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const long total = (long)k * S * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S), y = (int)((i / S) % S), n = (int)(i / (S * S));
+        const int* cr = crops5 + n * 5;
+        const int x1 = cr[1], y1 = cr[2], cw = cr[3] - cr[1], chh = cr[4] - cr[2];
+        float out[3] = {0.f, 0.f, 0.f};
+        if (cw > 0 && chh > 0) {
+            const uint8_t* im = frames + (size_t)cr[0] * H * W * 3;
+            float v[3];
+            if (cw == S && chh == S) {
+                const uint8_t* q = im + ((size_t)(y1 + y) * W + x1 + x) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = (float)q[c] / 255.f;
+            } else {
+                int sx0, sx1, sy0, sy1; float a0, a1, b0, b1;
+                lin_coef_f(x, cw, 1.0 / ((double)S / (double)cw), sx0, sx1, a0, a1, true);
+                lin_coef_f(y, chh, 1.0 / ((double)S / (double)chh), sy0, sy1, b0, b1, false);
+                const uint8_t* r0 = im + ((size_t)(y1 + sy0) * W + x1) * 3;
+                const uint8_t* r1 = im + ((size_t)(y1 + sy1) * W + x1) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float p00 = (float)r0[sx0 * 3 + c] / 255.f, p01 = (float)r0[sx1 * 3 + c] / 255.f;
+                    const float p10 = (float)r1[sx0 * 3 + c] / 255.f, p11 = (float)r1[sx1 * 3 + c] / 255.f;
+                    const float h0 = __fadd_rn(__fmul_rn(p00, a0), __fmul_rn(p01, a1));
+                    const float h1 = __fadd_rn(__fmul_rn(p10, a0), __fmul_rn(p11, a1));
+                    v[c] = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = (v[c] - mean[c]) / stdv[c];
+        }
+        if (F32) {
+            float* o = (float*)dst + (size_t)i * cpad;
+            for (int c = 0; c < cpad; ++c) o[c] = c < 3 ? out[c] : 0.f;
+        } else {
+            uint16_t* o = (uint16_t*)dst + (size_t)i * cpad;
+            for (int c = 0; c < cpad; ++c) o[c] = c < 3 ? f32_to_bf16(out[c]) : (uint16_t)0;
+        }
+    }
+}
+
+int launch_crop_resize(const uint8_t* frames, int H, int W, const int* crops5, int k, void* dst, int cpad, int prec, hipStream_t s) {
+    if (k <= 0) return VC_OK;
+    const long total = (long)k * VC_REID_SIZE * VC_REID_SIZE;
+    if (prec == PREC_F32) hipLaunchKernelGGL(crop_resize_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, H, W, crops5, k, dst, cpad);
+    else hipLaunchKernelGGL(crop_resize_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, H, W, crops5, k, dst, cpad);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int k, int C, int H, int W, void* __restrict__ dst, int cpad) {
+    const long total = (long)k * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % ((long)H * W));
+        const int n = (int)(i / ((long)H * W));
+        for (int c = 0; c < cpad; ++c) {
+            const float v = c < C ? x[((size_t)n * C + c) * H * W + hw] : 0.f;
+            if (F32) ((float*)dst)[(size_t)i * cpad + c] = v;
+            else ((uint16_t*)dst)[(size_t)i * cpad + c] = f32_to_bf16(v);
+        }
+    }
+}
+
+int launch_nchw_to_nhwc_pad(const float* x, int k, int C, int H, int W, void* dst, int cpad, int prec, hipStream_t s) {
+    if (k <= 0) return VC_OK;
+    const long total = (long)k * H * W;
+    if (prec == PREC_F32) hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, x, k, C, H, W, dst, cpad);
+    else hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, x, k, C, H, W, dst, cpad);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ MaxPool2d(3, 2, padding=1)
+template <bool F32>
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(View src, View dst) {
+    using V = Vec<F32>;
+    constexpr int ES = F32 ? 4 : 2;
+    const int cv = src.C / V::N;
+    const long total = (long)dst.B * dst.H * dst.W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V::N;
+        long pix = i / cv;
+        const int x = (int)(pix % dst.W);
+        const int y = (int)((pix / dst.W) % dst.H);
+        const int b = (int)(pix / ((long)dst.W * dst.H));
+        V m;
+#pragma unroll
+        for (int j = 0; j < V::N; ++j) m.v[j] = -INFINITY;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * y + dy;
+            if (yy < 0 || yy >= src.H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * x + dx;
+                if (xx < 0 || xx >= src.W) continue;
+                const V t = V::load((const char*)src.ptr + ((((size_t)b * src.H + yy) * src.W + xx) * src.cs + src.co + c) * ES);
+#pragma unroll
+                for (int j = 0; j < V::N; ++j) m.v[j] = fmaxf(m.v[j], t.v[j]);
+            }
+        }
+        m.store((char*)dst.ptr + ((((size_t)b * dst.H + y) * dst.W + x) * dst.cs + dst.co + c) * ES);
+    }
+}
+
+int launch_maxpool3s2(const View& src, const View& dst, int prec, hipStream_t s) {
+    const int n = prec == PREC_F32 ? 4 : 8;
+    VC_CHECK(src.C % n == 0 && src.cs % n == 0 && dst.cs % n == 0, VC_ERR_ARG, "maxpool: alignment");
+    const long total = (long)dst.B * dst.H * dst.W * (src.C / n);
+    if (total <= 0) return VC_OK;
+    if (prec == PREC_F32) hipLaunchKernelGGL(maxpool3s2_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst);
+    else hipLaunchKernelGGL(maxpool3s2_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ AvgPool(4,4) + L2 normalise
+// One workgroup per crop: 256 threads x 2 channels; block-wide sum of squares through wave shuffles + LDS.
+template <bool F32>
+__global__ __launch_bounds__(256) void avgpool_l2norm_kernel(View src, float* __restrict__ out) {
+    constexpr int ES = F32 ? 4 : 2;
+    __shared__ float part[4];
+    const int n = blockIdx.x, t = threadIdx.x;
+    float a[2] = {0.f, 0.f};
+    const int npix = src.H * src.W;    // 16
+    for (int q = 0; q < npix; ++q) {
+        const char* ptr = (const char*)src.ptr + (((size_t)n * npix + q) * src.cs + src.co + 2 * t) * ES;
+        if (F32) { const float2 v = *(const float2*)ptr; a[0] += v.x; a[1] += v.y; }
+        else { const uint32_t v = *(const uint32_t*)ptr; a[0] += bf16_to_f32((uint16_t)(v & 0xffff)); a[1] += bf16_to_f32((uint16_t)(v >> 16)); }
+    }
+    a[0] /= (float)npix; a[1] /= (float)npix;
+    float ss = a[0] * a[0] + a[1] * a[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((t & 63) == 0) part[t >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    out[(size_t)n * VC_FEAT_DIM + 2 * t] = a[0] / nrm;
+    out[(size_t)n * VC_FEAT_DIM + 2 * t + 1] = a[1] / nrm;
+}
+
+int launch_avgpool_l2norm(const View& src, float* out, int prec, hipStream_t s) {
+    VC_CHECK(src.C == VC_FEAT_DIM, VC_ERR_ARG, "avgpool: expects 512 channels");
+    if (src.B <= 0) return VC_OK;
+    if (prec == PREC_F32) hipLaunchKernelGGL(avgpool_l2norm_kernel<true>, dim3(src.B), dim3(256), 0, s, src, out);
+    else hipLaunchKernelGGL(avgpool_l2norm_kernel<false>, dim3(src.B), dim3(256), 0, s, src, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace vc

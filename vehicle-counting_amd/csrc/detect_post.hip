@@ -1,0 +1,202 @@
+// Detect head decode, candidate filter, class-offset greedy NMS and scale_coords -- rows A7-A9 of SURVEY.md.
+//
+// Restates (ultralytics/yolov5 v6.0, reached from /root/reference/networks/yolo.py:70):
+//   models/yolo.py::Detect.forward (inference)      -> decode_kernel
+//   utils/general.py::non_max_suppression           -> decode_kernel filter + rank_sort + nms_mask + nms_scan
+//   torchvision.ops.nms (stable descending sort, greedy, IoU > thr suppressed, all in float32)
+//   utils/general.py::scale_coords / clip_coords    -> nms_scan_kernel tail
+// and the thresholds the reference sets at networks/yolo.py:62-66 (conf, iou, max_det, multi_label=False).
+// The float32 operation order follows oracle/yolov5.py so that kept/suppressed decisions are bit-identical
+// for identical logits; contraction is disabled for the same reason.
+#include <algorithm>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace vc {
+
+#define VC_MAX_WH 4096.0f
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeLevel l0, const DecodeLevel l1, const DecodeLevel l2, int B, int nc,
+                                                     float conf_thres, int max_cand, DetectPostBuffers pb, float* pred_debug,
+                                                     int n_total) {
+    const int no = nc + 5;
+    const long total = (long)B * n_total;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(g / n_total);
+        const int i = (int)(g % n_total);
+        const DecodeLevel& lv = i >= l2.base ? l2 : (i >= l1.base ? l1 : l0);
+        const int li = i - lv.base;
+        const int x = li % lv.nx;
+        const int y = (li / lv.nx) % lv.ny;
+        const int a = li / (lv.nx * lv.ny);
+        const float* q = lv.logits + (((size_t)b * lv.ny + y) * lv.nx + x) * lv.cs + a * no;
+        const float obj = sigmoidf_(q[4]);
+        if (pred_debug == nullptr && !(obj > conf_thres)) continue;
+        const float sx = sigmoidf_(q[0]), sy = sigmoidf_(q[1]), sw = sigmoidf_(q[2]), sh = sigmoidf_(q[3]);
+        const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
+        const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
+        const float tw = sw * 2.0f, th = sh * 2.0f;
+        const float w = tw * tw * lv.anchor_w[a];
+        const float h = th * th * lv.anchor_h[a];
+        float best = -1.0f;
+        int bj = 0;
+        float* dbg = pred_debug ? pred_debug + (size_t)g * no : nullptr;
+        if (dbg) { dbg[0] = cx; dbg[1] = cy; dbg[2] = w; dbg[3] = h; dbg[4] = obj; }
+        for (int c = 0; c < nc; ++c) {
+            const float sc = sigmoidf_(q[5 + c]);
+            if (dbg) dbg[5 + c] = sc;
+            const float v = sc * obj;
+            if (v > best) { best = v; bj = c; }
+        }
+        if (!(obj > conf_thres) || !(best > conf_thres)) continue;
+        const int pos = atomicAdd(pb.cand_count + b, 1);
+        if (pos >= max_cand) { pb.overflow[b] = 1; continue; }
+        const size_t o = (size_t)b * max_cand + pos;
+        const float hw = w / 2.0f, hh = h / 2.0f;
+        pb.cand_box[o * 4 + 0] = cx - hw;
+        pb.cand_box[o * 4 + 1] = cy - hh;
+        pb.cand_box[o * 4 + 2] = cx + hw;
+        pb.cand_box[o * 4 + 3] = cy + hh;
+        pb.cand_conf[o] = best;
+        pb.cand_cls[o] = bj;
+        pb.cand_idx[o] = i;
+    }
+}
+
+// Order candidates like `scores.sort(stable=True, descending=True)` over the reference's candidate order:
+// rank = #{j : conf_j > conf_i or (conf_j == conf_i and idx_j < idx_i)}.
+__global__ __launch_bounds__(256) void rank_sort_kernel(int max_cand, DetectPostBuffers pb) {
+    __shared__ float s_conf[1024];
+    __shared__ int s_idx[1024];
+    const int b = blockIdx.y;
+    const int n = min(pb.cand_count[b], max_cand);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const size_t base = (size_t)b * max_cand;
+    const float ci = i < n ? pb.cand_conf[base + i] : 0.f;
+    const int ii = i < n ? pb.cand_idx[base + i] : 0;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 1024 && j0 + t < n; t += blockDim.x) {
+            s_conf[t] = pb.cand_conf[base + j0 + t];
+            s_idx[t] = pb.cand_idx[base + j0 + t];
+        }
+        __syncthreads();
+        const int m = min(1024, n - j0);
+        for (int t = 0; t < m; ++t) {
+            const float cj = s_conf[t];
+            rank += (cj > ci || (cj == ci && s_idx[t] < ii)) ? 1 : 0;
+        }
+    }
+    if (i < n) {
+        const size_t o = base + rank;
+        const float4 bx = *(const float4*)(pb.cand_box + (base + i) * 4);
+        *(float4*)(pb.sort_box + o * 4) = bx;
+        pb.sort_conf[o] = ci;
+        pb.sort_cls[o] = pb.cand_cls[base + i];
+    }
+}
+
+// mask[i][w] bit j: box (w*64+j) > i in sorted order and IoU(i, j) > thr, boxes offset by cls * 4096 (float32 add).
+__global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, float iou_thres, DetectPostBuffers pb) {
+    __shared__ float4 cb[64];
+    const int b = blockIdx.z;
+    const int n = min(pb.cand_count[b], max_cand);
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    if (row0 >= n || col0 >= n || col0 + 63 < row0) return;     // block strictly below the diagonal: nothing to do
+    const size_t base = (size_t)b * max_cand;
+    const int t = threadIdx.x;
+    if (col0 + t < n) {
+        const float4 v = *(const float4*)(pb.sort_box + (base + col0 + t) * 4);
+        const float off = (float)pb.sort_cls[base + col0 + t] * VC_MAX_WH;
+        cb[t] = make_float4(v.x + off, v.y + off, v.z + off, v.w + off);
+    }
+    __syncthreads();
+    const int i = row0 + t;
+    if (i >= n) return;
+    const float4 v = *(const float4*)(pb.sort_box + (base + i) * 4);
+    const float off = (float)pb.sort_cls[base + i] * VC_MAX_WH;
+    const float ix1 = v.x + off, iy1 = v.y + off, ix2 = v.z + off, iy2 = v.w + off;
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    unsigned long long bits = 0;
+    const int m = min(64, n - col0);
+    for (int j = 0; j < m; ++j) {
+        if (col0 + j <= i) continue;
+        const float4 c = cb[j];
+        const float xx1 = fmaxf(ix1, c.x), yy1 = fmaxf(iy1, c.y), xx2 = fminf(ix2, c.z), yy2 = fminf(iy2, c.w);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        const float carea = (c.z - c.x) * (c.w - c.y);
+        const float ovr = inter / (iarea + carea - inter);
+        if (ovr > iou_thres) bits |= 1ull << j;
+    }
+    pb.mask[(base + i) * (size_t)(max_cand / 64) + blockIdx.x] = bits;
+}
+
+// One wave per frame walks the sorted candidates, keeps the un-suppressed ones (at most max_det), and writes
+// the surviving boxes mapped back to source pixels (scale_coords + clip_coords).
+__global__ __launch_bounds__(64) void nms_scan_kernel(int max_cand, int max_det, const float* __restrict__ geom, DetectPostBuffers pb) {
+    extern __shared__ unsigned long long removed[];     // max_cand / 64 words
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float gain = geom[b * 5 + 0], padw = geom[b * 5 + 1], padh = geom[b * 5 + 2], src_w = geom[b * 5 + 3], src_h = geom[b * 5 + 4];
+    const int n = min(pb.cand_count[b], max_cand);
+    const int words = max_cand / 64;
+    const int nw = (n + 63) / 64;
+    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    __syncthreads();
+    const size_t base = (size_t)b * max_cand;
+    int kept = 0;
+    for (int i = 0; i < n && kept < max_det; ++i) {
+        const unsigned long long r = removed[i >> 6];
+        if ((r >> (i & 63)) & 1ull) continue;        // wave-uniform
+        if (lane == 0) {
+            const float4 v = *(const float4*)(pb.sort_box + (base + i) * 4);
+            float x1 = (v.x - padw) / gain, y1 = (v.y - padh) / gain, x2 = (v.z - padw) / gain, y2 = (v.w - padh) / gain;
+            x1 = fminf(fmaxf(x1, 0.f), src_w); x2 = fminf(fmaxf(x2, 0.f), src_w);
+            y1 = fminf(fmaxf(y1, 0.f), src_h); y2 = fminf(fmaxf(y2, 0.f), src_h);
+            float* o = pb.det + ((size_t)b * max_det + kept) * 6;
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = pb.sort_conf[base + i]; o[5] = (float)pb.sort_cls[base + i];
+        }
+        ++kept;
+        const unsigned long long* mrow = pb.mask + (base + i) * (size_t)words;
+        for (int w = (i >> 6) + lane; w < nw; w += 64) removed[w] |= mrow[w];
+        __syncthreads();
+    }
+    if (lane == 0) pb.det_count[b] = kept;
+}
+
+int launch_decode(const DecodeLevel* lv, int nlv, int B, int nc, float conf, int max_cand, DetectPostBuffers& pb, float* pred_debug,
+                  int n_total, hipStream_t s) {
+    VC_CHECK(nlv == 3, VC_ERR_ARG, "decode: expects the 3 detection levels of YOLOv5");
+    VC_HIP(hipMemsetAsync(pb.cand_count, 0, sizeof(int) * B, s));
+    VC_HIP(hipMemsetAsync(pb.overflow, 0, sizeof(int) * B, s));
+    const long total = (long)B * n_total;
+    long grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(decode_kernel, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+void scale_geom_host(const ScaleGeom& g, float out5[5]) {
+    // scale_coords scalars exactly as python computes them (double), rounded to f32 when applied to the f32 tensor
+    const double gain = std::min((double)g.net_h / g.src_h, (double)g.net_w / g.src_w);
+    const double padw = (g.net_w - g.src_w * gain) / 2, padh = (g.net_h - g.src_h * gain) / 2;
+    out5[0] = (float)gain; out5[1] = (float)padw; out5[2] = (float)padh; out5[3] = (float)g.src_w; out5[4] = (float)g.src_h;
+}
+
+int launch_nms(int B, int max_cand, int max_det, float iou, const float* geom_dev, DetectPostBuffers& pb, hipStream_t s) {
+    VC_CHECK(max_cand % 64 == 0 && max_cand <= 8192, VC_ERR_ARG, "nms: max_candidates must be a multiple of 64 and <= 8192");
+    hipLaunchKernelGGL(rank_sort_kernel, dim3(max_cand / 256, B), dim3(256), 0, s, max_cand, pb);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(max_cand / 64, max_cand / 64, B), dim3(64), 0, s, max_cand, iou, pb);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), sizeof(unsigned long long) * (max_cand / 64), s, max_cand, max_det, geom_dev, pb);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace vc

@@ -1,0 +1,147 @@
+// Engine internals shared between engine.hip (networks), tracker.hip (DeepSORT) and stream.hip (fused path).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace vc {
+
+struct ConvParam {
+    std::string name;
+    int O = 0, I = 0, kh = 0, kw = 0;
+    bool set = false;
+    bool pair_stem = false;          // YOLO stem in bf16: two 4-channel pixels form one 16-byte chunk
+    std::vector<float> w, b;         // host copies (OIHW, BN folded) until finalize()
+    void* d_w = nullptr;             // packed [Cout_pad][Kp]
+    float* d_b = nullptr;            // [Cout_pad]
+    int cin_eff = 0, K = 0, Kp = 0, cout_pad = 0;
+};
+
+struct Op {
+    enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL } kind;
+    ConvP conv{};
+    View a{}, b{};
+    int C = 0;
+    int param = -1;                  // index into Net::params for CONV
+};
+
+struct Net {
+    std::vector<ConvParam> params;
+    std::map<std::string, int> index;
+    int add(const std::string& name, int O, int I, int kh, int kw) {
+        ConvParam p;
+        p.name = name; p.O = O; p.I = I; p.kh = kh; p.kw = kw;
+        index[name] = (int)params.size();
+        params.push_back(p);
+        return (int)params.size() - 1;
+    }
+};
+
+struct ProfCat {
+    double ms = 0, flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+// host-side tracker record (tracker.hip)
+struct TrackRec {
+    int64_t id;
+    int state, hits, age, tsu;
+    int slot;                        // index into the device TrackPool
+    int gal_count, gal_head;         // ring of the last `budget` features
+    double last_conf;
+};
+
+struct Tracker {
+    vc_tracker_params p;
+    std::vector<TrackRec> tracks;
+    int64_t next_id = 1;
+};
+
+}  // namespace vc
+
+struct vc_engine {
+    vc_engine_config cfg{};
+    int prec = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
+    std::vector<void*> host_allocs;  // hipHostMalloc'ed
+
+    // ---- detector --------------------------------------------------------------------------------
+    vc::Net yolo;
+    int ch[5] = {0, 0, 0, 0, 0}, rep[4] = {0, 0, 0, 0};
+    std::map<std::string, vc::View> ybuf;        // named activation buffers (max shape)
+    vc::View layer_view[24];
+    uint8_t* d_frames = nullptr;                 // staging for host images / stream frames
+    size_t d_frames_bytes = 0;
+    float* d_logits[3] = {nullptr, nullptr, nullptr};
+    vc::DetectPostBuffers post{};
+    float* d_geom = nullptr;                     // [max_batch][5] gain, padw, padh, src_w, src_h
+    float* d_pred_debug = nullptr;
+    bool want_pred_debug = false;
+    int last_B = 0, last_nh = 0, last_nw = 0, last_ntotal = 0;
+    float* h_det = nullptr;                      // pinned [max_batch][max_det][6]
+    int* h_det_count = nullptr;                  // pinned [max_batch]
+
+    // ---- ReID ---------------------------------------------------------------------------------------
+    vc::Net reid;
+    std::map<std::string, vc::View> rbuf;
+    int* d_crops = nullptr;                      // [max_crops][5]
+    int* h_crops = nullptr;
+    float* d_feat = nullptr;                     // [max_crops][512]
+    float* h_feat = nullptr;
+    float* d_reid_in_nchw = nullptr;
+
+    // ---- tracker pool ---------------------------------------------------------------------------------
+    vc::TrackPool pool{};
+    std::vector<int> free_slots;
+    std::vector<std::unique_ptr<vc::Tracker>> trackers;
+    // per-step scratch (pinned host + device mirrors)
+    int* h_slots = nullptr; int* d_slots = nullptr;
+    double* h_xyah = nullptr; double* d_xyah = nullptr;
+    double* h_tlwh = nullptr; double* d_tlwh = nullptr;
+    vc::CostJob* h_jobs = nullptr; vc::CostJob* d_jobs = nullptr;
+    double* h_cost = nullptr; double* d_cost = nullptr;
+    int* h_sps = nullptr; int* d_sps = nullptr;
+    double* h_mean = nullptr;
+    float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
+    size_t cost_cap = 0;
+    int det_cap = 0;
+
+    // ---- measurement ----------------------------------------------------------------------------------
+    bool profiling = false;
+    vc::ProfCat prof[VC_PROF_NCAT];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // ---- stream injection -----------------------------------------------------------------------------
+    std::vector<float> inject_det;
+    std::vector<int> inject_count;
+    int inject_b = 0, inject_n = 0;
+};
+
+namespace vc {
+// engine.hip
+int dev_alloc(vc_engine* e, void** p, size_t bytes);
+int host_alloc(vc_engine* e, void** p, size_t bytes);
+int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w, bool swap_rb);   // frames same size, on device
+int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k);                      // crops in e->d_crops -> e->d_feat
+int prof_launch(vc_engine* e, int cat, double flops, double bytes, int status);
+struct ProfScope {
+    vc_engine* e; int cat; double flops, bytes;
+    ProfScope(vc_engine* e_, int cat_, double flops_ = 0, double bytes_ = 0);
+    ~ProfScope();
+};
+// tracker.hip
+int tracker_init_pool(vc_engine* e);
+// detections of one tracker for one step; feature of det i = d_feat row (feat_rows ? feat_rows[i] : feat_off + i)
+struct DetIn { const double* tlwh; const double* conf; int k; const int* feat_rows; int feat_off; };
+int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat);
+int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
+                const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
+                int n, const float* d_feat_ready, int feat_row0, std::vector<int64_t>& rows6);
+int lap_solve(const double* cost, int nr, int nc, std::vector<int>& row_of_col_rows, std::vector<int>& cols);
+void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep);
+}  // namespace vc

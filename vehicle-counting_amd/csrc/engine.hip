@@ -1,0 +1,821 @@
+// Engine: owns the device, the stream, the detector (YOLOv5 v6.0 graph) and the ReID net, builds their
+// execution plans natively and exposes them through the C ABI in include/vcount_hip.h.
+//
+// Graph sources restated here (independently of oracle/yolov5.py, they only meet at the parameter names):
+//   ultralytics/yolov5 v6.0 models/yolov5{s,m,l}.yaml + models/common.py (Conv, Bottleneck, C3, SPPF, Concat) +
+//   models/yolo.py (Detect), loaded by /root/reference/networks/yolo.py:58;
+//   /root/reference/networks/deepsort/deep/model.py:5-98 (BasicBlock, make_layers, Net(reid=True)).
+// Concat never copies: producers write straight into channel slices of the consumer's buffer.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+
+#include "engine.h"
+
+namespace vc {
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+int dev_alloc(vc_engine* e, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    VC_HIP(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return VC_OK;
+}
+int host_alloc(vc_engine* e, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    VC_HIP(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    e->host_allocs.push_back(*p);
+    return VC_OK;
+}
+
+ProfScope::ProfScope(vc_engine* e_, int cat_, double flops_, double bytes_) : e(e_), cat(cat_), flops(flops_), bytes(bytes_) {
+    if (e->profiling) hipEventRecord(e->ev0, e->stream);
+}
+ProfScope::~ProfScope() {
+    if (!e->profiling) return;
+    hipEventRecord(e->ev1, e->stream);
+    hipEventSynchronize(e->ev1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    ProfCat& c = e->prof[cat];
+    c.ms += ms; c.flops += flops; c.bytes += bytes; c.launches += 1;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static int pack_and_upload(vc_engine* e, ConvParam& p, int prec) {
+    VC_CHECK(p.set, VC_ERR_STATE, "parameter '%s' was never set", p.name.c_str());
+    const int ch = prec == PREC_F32 ? 4 : 8;
+    const int kt = conv_k_tile(prec);
+    int kw_eff = p.kw;
+    if (p.pair_stem) {                       // two 4-channel pixels per chunk: kernel becomes kh x kw/2 over 8 channels
+        p.cin_eff = 8;
+        kw_eff = p.kw / 2;
+    } else {
+        p.cin_eff = round_up(p.I, ch);
+    }
+    p.K = p.kh * kw_eff * p.cin_eff;
+    p.Kp = round_up(p.K, kt);
+    p.cout_pad = round_up(p.O, 128);
+    std::vector<float> packed((size_t)p.cout_pad * p.Kp, 0.f);
+    for (int n = 0; n < p.O; ++n)
+        for (int c = 0; c < p.I; ++c)
+            for (int r = 0; r < p.kh; ++r)
+                for (int s = 0; s < p.kw; ++s) {
+                    const float v = p.w[(((size_t)n * p.I + c) * p.kh + r) * p.kw + s];
+                    size_t k;
+                    if (p.pair_stem) k = ((size_t)r * kw_eff + s / 2) * 8 + (s % 2) * 4 + c;
+                    else k = ((size_t)r * p.kw + s) * p.cin_eff + c;
+                    packed[(size_t)n * p.Kp + k] = v;
+                }
+    std::vector<float> bias(p.cout_pad, 0.f);
+    for (int n = 0; n < p.O; ++n) bias[n] = p.b[n];
+    const size_t nel = packed.size();
+    VC_TRY(dev_alloc(e, &p.d_w, nel * elem_size(prec)));
+    VC_TRY(dev_alloc(e, (void**)&p.d_b, bias.size() * sizeof(float)));
+    if (prec == PREC_F32) {
+        VC_HIP(hipMemcpy(p.d_w, packed.data(), nel * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint16_t> h(nel);
+        for (size_t i = 0; i < nel; ++i) h[i] = f32_to_bf16(packed[i]);
+        VC_HIP(hipMemcpy(p.d_w, h.data(), nel * 2, hipMemcpyHostToDevice));
+    }
+    VC_HIP(hipMemcpy(p.d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ plan helpers
+static View mkview(const View& buf, int B, int H, int W, int C, int co) {
+    View v = buf;
+    v.B = B; v.H = H; v.W = W; v.C = C; v.co = buf.co + co;
+    return v;
+}
+
+static int alloc_buf(vc_engine* e, std::map<std::string, View>& m, const std::string& name, size_t pixels, int C, int es) {
+    View v{};
+    v.cs = C; v.co = 0; v.C = C;
+    VC_TRY(dev_alloc(e, &v.ptr, pixels * C * es));
+    m[name] = v;
+    return VC_OK;
+}
+
+struct PlanBuilder {
+    vc_engine* e;
+    Net* net;
+    std::vector<Op>* ops;
+    int prec;
+    int status = VC_OK;
+
+    // out.H/W are filled from the conv arithmetic; returns the output view with its dims set
+    View conv(const std::string& pname, View in, View out, int k, int s, int p, int act, const View* res = nullptr,
+              int res_mode = RES_NONE, bool out_f32 = false) {
+        auto it = net->index.find(pname);
+        if (it == net->index.end()) { set_error("plan: unknown parameter %s", pname.c_str()); status = VC_ERR_NOTFOUND; return out; }
+        const ConvParam& cp = net->params[it->second];
+        Op op{};
+        op.kind = Op::CONV;
+        op.param = it->second;
+        ConvP& c = op.conv;
+        c.in = in.ptr; c.w = cp.d_w; c.bias = cp.d_b; c.out = out.ptr;
+        c.B = in.B;
+        if (cp.pair_stem) {
+            c.H = in.H; c.W = in.W / 2; c.Cin = 8; c.in_cs = 8; c.in_co = 0;
+            c.kh = cp.kh; c.kw = cp.kw / 2; c.sh = s; c.sw = 1; c.ph = p; c.pw = 1;
+            c.Ho = (in.H + 2 * p - k) / s + 1; c.Wo = (in.W + 2 * p - k) / s + 1;
+        } else {
+            c.H = in.H; c.W = in.W; c.Cin = cp.cin_eff; c.in_cs = in.cs; c.in_co = in.co;
+            c.kh = k; c.kw = k; c.sh = s; c.sw = s; c.ph = p; c.pw = p;
+            c.Ho = (in.H + 2 * p - k) / s + 1; c.Wo = (in.W + 2 * p - k) / s + 1;
+        }
+        c.Cout = cp.O; c.out_cs = out.cs; c.out_co = out.co;
+        c.K = cp.K; c.Kp = cp.Kp;
+        c.act = act; c.res_mode = res_mode; c.out_f32 = out_f32 ? 1 : 0; c.prec = prec;
+        if (res) { c.res = res->ptr; c.res_cs = res->cs; c.res_co = res->co; }
+        c.M = c.B * c.Ho * c.Wo;
+        op.C = cp.I * cp.kh * cp.kw;          // logical K for algorithmic FLOPs
+        ops->push_back(op);
+        out.B = in.B; out.H = c.Ho; out.W = c.Wo; out.C = cp.O;
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ YOLOv5 v6.0
+static const double kYoloMult[3][2] = {{0.33, 0.50}, {0.67, 0.75}, {1.0, 1.0}};   // depth, width (s, m, l)
+static const float kAnchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
+
+static void yolo_c3_params(Net& n, int idx, int cin, int cout, int reps) {
+    const std::string p = "model." + std::to_string(idx);
+    const int h = cout / 2;
+    n.add(p + ".cv1.conv", h, cin, 1, 1);
+    n.add(p + ".cv2.conv", h, cin, 1, 1);
+    n.add(p + ".cv3.conv", cout, 2 * h, 1, 1);
+    for (int j = 0; j < reps; ++j) {
+        n.add(p + ".m." + std::to_string(j) + ".cv1.conv", h, h, 1, 1);
+        n.add(p + ".m." + std::to_string(j) + ".cv2.conv", h, h, 3, 3);
+    }
+}
+
+static void yolo_define(vc_engine* e) {
+    const double gd = kYoloMult[e->cfg.yolo_variant][0], gw = kYoloMult[e->cfg.yolo_variant][1];
+    const int base[5] = {64, 128, 256, 512, 1024};
+    for (int i = 0; i < 5; ++i) e->ch[i] = (int)std::ceil(base[i] * gw / 8.0) * 8;
+    const int r[4] = {3, 6, 9, 3};
+    for (int i = 0; i < 4; ++i) e->rep[i] = std::max((int)std::nearbyint(r[i] * gd), 1);
+    Net& n = e->yolo;
+    const int* c = e->ch;
+    n.add("model.0.conv", c[0], 3, 6, 6);
+    n.params.back().pair_stem = (e->prec == PREC_BF16);
+    n.add("model.1.conv", c[1], c[0], 3, 3); yolo_c3_params(n, 2, c[1], c[1], e->rep[0]);
+    n.add("model.3.conv", c[2], c[1], 3, 3); yolo_c3_params(n, 4, c[2], c[2], e->rep[1]);
+    n.add("model.5.conv", c[3], c[2], 3, 3); yolo_c3_params(n, 6, c[3], c[3], e->rep[2]);
+    n.add("model.7.conv", c[4], c[3], 3, 3); yolo_c3_params(n, 8, c[4], c[4], e->rep[3]);
+    n.add("model.9.cv1.conv", c[4] / 2, c[4], 1, 1);
+    n.add("model.9.cv2.conv", c[4], c[4] * 2, 1, 1);
+    n.add("model.10.conv", c[3], c[4], 1, 1); yolo_c3_params(n, 13, 2 * c[3], c[3], e->rep[0]);
+    n.add("model.14.conv", c[2], c[3], 1, 1); yolo_c3_params(n, 17, 2 * c[2], c[2], e->rep[0]);
+    n.add("model.18.conv", c[2], c[2], 3, 3); yolo_c3_params(n, 20, 2 * c[2], c[3], e->rep[0]);
+    n.add("model.21.conv", c[3], c[3], 3, 3); yolo_c3_params(n, 23, 2 * c[3], c[4], e->rep[0]);
+    const int no = 3 * (e->cfg.num_classes + 5);
+    n.add("model.24.m.0", no, c[2], 1, 1);
+    n.add("model.24.m.1", no, c[3], 1, 1);
+    n.add("model.24.m.2", no, c[4], 1, 1);
+}
+
+static int yolo_alloc(vc_engine* e) {
+    const int es = elem_size(e->prec);
+    const int S = round_up(e->cfg.img_size, 32);
+    const size_t B = e->cfg.max_batch;
+    auto px = [&](int stride) { return B * (size_t)(S / stride) * (S / stride); };
+    const int* c = e->ch;
+    auto& m = e->ybuf;
+    auto c3 = [&](int idx, int stride, int cout) -> int {
+        const std::string p = "c3_" + std::to_string(idx);
+        const int h = cout / 2;
+        VC_TRY(alloc_buf(e, m, p + ".a", px(stride), h, es));
+        VC_TRY(alloc_buf(e, m, p + ".b", px(stride), h, es));
+        VC_TRY(alloc_buf(e, m, p + ".t", px(stride), h, es));
+        VC_TRY(alloc_buf(e, m, p + ".cat", px(stride), 2 * h, es));
+        return VC_OK;
+    };
+    VC_TRY(alloc_buf(e, m, "in", px(1), 4, es));
+    VC_TRY(alloc_buf(e, m, "l0", px(2), c[0], es));
+    VC_TRY(alloc_buf(e, m, "l1", px(4), c[1], es)); VC_TRY(c3(2, 4, c[1])); VC_TRY(alloc_buf(e, m, "l2", px(4), c[1], es));
+    VC_TRY(alloc_buf(e, m, "l3", px(8), c[2], es)); VC_TRY(c3(4, 8, c[2])); VC_TRY(alloc_buf(e, m, "cat16", px(8), 2 * c[2], es));
+    VC_TRY(alloc_buf(e, m, "l5", px(16), c[3], es)); VC_TRY(c3(6, 16, c[3])); VC_TRY(alloc_buf(e, m, "cat12", px(16), 2 * c[3], es));
+    VC_TRY(alloc_buf(e, m, "l7", px(32), c[4], es)); VC_TRY(c3(8, 32, c[4])); VC_TRY(alloc_buf(e, m, "l8", px(32), c[4], es));
+    VC_TRY(alloc_buf(e, m, "sppcat", px(32), 2 * c[4], es));
+    VC_TRY(alloc_buf(e, m, "l9", px(32), c[4], es));
+    VC_TRY(alloc_buf(e, m, "cat22", px(32), 2 * c[3], es));
+    VC_TRY(c3(13, 16, c[3])); VC_TRY(alloc_buf(e, m, "l13", px(16), c[3], es));
+    VC_TRY(alloc_buf(e, m, "cat19", px(16), 2 * c[2], es));
+    VC_TRY(c3(17, 8, c[2])); VC_TRY(alloc_buf(e, m, "l17", px(8), c[2], es));
+    VC_TRY(c3(20, 16, c[3])); VC_TRY(alloc_buf(e, m, "l20", px(16), c[3], es));
+    VC_TRY(c3(23, 32, c[4])); VC_TRY(alloc_buf(e, m, "l23", px(32), c[4], es));
+    const int no = 3 * (e->cfg.num_classes + 5);
+    const int lcs = round_up(no, 4);
+    const int strides[3] = {8, 16, 32};
+    for (int i = 0; i < 3; ++i) VC_TRY(dev_alloc(e, (void**)&e->d_logits[i], px(strides[i]) * lcs * sizeof(float)));
+    // post-processing
+    const size_t mc = e->cfg.max_candidates, md = e->cfg.max_det;
+    auto& pb = e->post;
+    VC_TRY(dev_alloc(e, (void**)&pb.cand_box, B * mc * 4 * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&pb.cand_conf, B * mc * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&pb.cand_cls, B * mc * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&pb.cand_idx, B * mc * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&pb.cand_count, B * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&pb.sort_box, B * mc * 4 * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&pb.sort_conf, B * mc * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&pb.sort_cls, B * mc * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&pb.mask, B * mc * (mc / 64) * sizeof(unsigned long long)));
+    VC_TRY(dev_alloc(e, (void**)&pb.det, B * md * 6 * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&pb.det_count, B * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&pb.overflow, B * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_geom, B * 5 * sizeof(float)));
+    VC_TRY(host_alloc(e, (void**)&e->h_det, B * md * 6 * sizeof(float)));
+    VC_TRY(host_alloc(e, (void**)&e->h_det_count, B * sizeof(int)));
+    e->d_frames_bytes = B * (size_t)e->cfg.max_frame_h * e->cfg.max_frame_w * 3;
+    VC_TRY(dev_alloc(e, (void**)&e->d_frames, e->d_frames_bytes));
+    return VC_OK;
+}
+
+// C3(c1 -> c2, n x Bottleneck(e=1.0, shortcut), cv3 over concat(m(cv1 x), cv2 x)); models/common.py::C3
+static View yolo_c3(PlanBuilder& pb, vc_engine* e, int idx, View x, View out, int cout, int reps, bool shortcut) {
+    const std::string p = "model." + std::to_string(idx), bn = "c3_" + std::to_string(idx);
+    const int h = cout / 2;
+    auto& m = e->ybuf;
+    View cat = mkview(m[bn + ".cat"], x.B, x.H, x.W, 2 * h, 0);
+    View y = pb.conv(p + ".cv1.conv", x, mkview(m[bn + ".a"], x.B, x.H, x.W, h, 0), 1, 1, 0, ACT_SILU);
+    for (int j = 0; j < reps; ++j) {
+        View t = pb.conv(p + ".m." + std::to_string(j) + ".cv1.conv", y, mkview(m[bn + ".t"], x.B, x.H, x.W, h, 0), 1, 1, 0, ACT_SILU);
+        View dst = j == reps - 1 ? mkview(cat, x.B, x.H, x.W, h, 0) : mkview(m[bn + ((j % 2 == 0) ? ".b" : ".a")], x.B, x.H, x.W, h, 0);
+        y = pb.conv(p + ".m." + std::to_string(j) + ".cv2.conv", t, dst, 3, 1, 1, ACT_SILU, shortcut ? &y : nullptr,
+                    shortcut ? RES_AFTER_ACT : RES_NONE);
+    }
+    pb.conv(p + ".cv2.conv", x, mkview(cat, x.B, x.H, x.W, h, h), 1, 1, 0, ACT_SILU);
+    return pb.conv(p + ".cv3.conv", cat, out, 1, 1, 0, ACT_SILU);
+}
+
+static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& ops) {
+    PlanBuilder pb{e, &e->yolo, &ops, e->prec};
+    auto& m = e->ybuf;
+    const int* c = e->ch;
+    auto full = [&](const char* name, int stride, int C) { return mkview(m[name], B, Hn / stride, Wn / stride, C, 0); };
+    View* lv = e->layer_view;
+    View x = full("in", 1, 4);
+    lv[0] = x = pb.conv("model.0.conv", x, full("l0", 2, c[0]), 6, 2, 2, ACT_SILU);
+    lv[1] = x = pb.conv("model.1.conv", x, full("l1", 4, c[1]), 3, 2, 1, ACT_SILU);
+    lv[2] = x = yolo_c3(pb, e, 2, x, full("l2", 4, c[1]), c[1], e->rep[0], true);
+    lv[3] = x = pb.conv("model.3.conv", x, full("l3", 8, c[2]), 3, 2, 1, ACT_SILU);
+    View cat16 = full("cat16", 8, 2 * c[2]);
+    lv[4] = x = yolo_c3(pb, e, 4, x, mkview(cat16, B, Hn / 8, Wn / 8, c[2], c[2]), c[2], e->rep[1], true);
+    lv[5] = x = pb.conv("model.5.conv", x, full("l5", 16, c[3]), 3, 2, 1, ACT_SILU);
+    View cat12 = full("cat12", 16, 2 * c[3]);
+    lv[6] = x = yolo_c3(pb, e, 6, x, mkview(cat12, B, Hn / 16, Wn / 16, c[3], c[3]), c[3], e->rep[2], true);
+    lv[7] = x = pb.conv("model.7.conv", x, full("l7", 32, c[4]), 3, 2, 1, ACT_SILU);
+    lv[8] = x = yolo_c3(pb, e, 8, x, full("l8", 32, c[4]), c[4], e->rep[3], true);
+    {   // SPPF (models/common.py::SPPF, k=5)
+        View sc = full("sppcat", 32, 2 * c[4]);
+        pb.conv("model.9.cv1.conv", x, mkview(sc, B, Hn / 32, Wn / 32, c[4] / 2, 0), 1, 1, 0, ACT_SILU);
+        Op op{}; op.kind = Op::SPPF; op.a = sc; op.C = c[4] / 2; ops.push_back(op);
+        lv[9] = x = pb.conv("model.9.cv2.conv", sc, full("l9", 32, c[4]), 1, 1, 0, ACT_SILU);
+    }
+    View cat22 = full("cat22", 32, 2 * c[3]);
+    lv[10] = x = pb.conv("model.10.conv", x, mkview(cat22, B, Hn / 32, Wn / 32, c[3], c[3]), 1, 1, 0, ACT_SILU);
+    { Op op{}; op.kind = Op::UPSAMPLE; op.a = x; op.b = mkview(cat12, B, Hn / 16, Wn / 16, c[3], 0); ops.push_back(op); lv[11] = op.b; }
+    lv[12] = cat12;
+    lv[13] = x = yolo_c3(pb, e, 13, cat12, full("l13", 16, c[3]), c[3], e->rep[0], false);
+    View cat19 = full("cat19", 16, 2 * c[2]);
+    lv[14] = x = pb.conv("model.14.conv", x, mkview(cat19, B, Hn / 16, Wn / 16, c[2], c[2]), 1, 1, 0, ACT_SILU);
+    { Op op{}; op.kind = Op::UPSAMPLE; op.a = x; op.b = mkview(cat16, B, Hn / 8, Wn / 8, c[2], 0); ops.push_back(op); lv[15] = op.b; }
+    lv[16] = cat16;
+    View p3 = lv[17] = yolo_c3(pb, e, 17, cat16, full("l17", 8, c[2]), c[2], e->rep[0], false);
+    lv[18] = pb.conv("model.18.conv", p3, mkview(cat19, B, Hn / 16, Wn / 16, c[2], 0), 3, 2, 1, ACT_SILU);
+    lv[19] = cat19;
+    View p4 = lv[20] = yolo_c3(pb, e, 20, cat19, full("l20", 16, c[3]), c[3], e->rep[0], false);
+    lv[21] = pb.conv("model.21.conv", p4, mkview(cat22, B, Hn / 32, Wn / 32, c[3], 0), 3, 2, 1, ACT_SILU);
+    lv[22] = cat22;
+    View p5 = lv[23] = yolo_c3(pb, e, 23, cat22, full("l23", 32, c[4]), c[4], e->rep[0], false);
+    // Detect.m[i]: 1x1 conv + bias, fp32 logits (models/yolo.py::Detect)
+    const int no = 3 * (e->cfg.num_classes + 5), lcs = round_up(no, 4);
+    const View heads[3] = {p3, p4, p5};
+    for (int i = 0; i < 3; ++i) {
+        View o{}; o.ptr = e->d_logits[i]; o.cs = lcs; o.co = 0;
+        pb.conv("model.24.m." + std::to_string(i), heads[i], o, 1, 1, 0, ACT_NONE, nullptr, RES_NONE, true);
+    }
+    return pb.status;
+}
+
+static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat) {
+    for (const Op& op : ops) {
+        switch (op.kind) {
+            case Op::CONV: {
+                const double fl = 2.0 * op.conv.M * (double)op.conv.Cout * op.C;
+                const double es = elem_size(op.conv.prec);
+                const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
+                                  (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
+                ProfScope ps(e, VC_PROF_CONV, fl, by);
+                VC_TRY(launch_conv(op.conv, e->stream));
+                break;
+            }
+            case Op::SPPF: { ProfScope ps(e, aux_cat); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, e->stream)); break; }
+            case Op::UPSAMPLE: { ProfScope ps(e, aux_cat); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, e->stream)); break; }
+            case Op::MAXPOOL: { ProfScope ps(e, aux_cat); VC_TRY(launch_maxpool3s2(op.a, op.b, e->prec, e->stream)); break; }
+        }
+    }
+    return VC_OK;
+}
+
+// AutoShape geometry: models/common.py::AutoShape.forward + utils/augmentations.py::letterbox (auto=False)
+static int py_round(double x) { return (int)std::nearbyint(x); }     // banker's rounding like Python 3 round()
+
+static void autoshape_net_size(const int* h, const int* w, int n, int size, int& nh, int& nw) {
+    double mh = 0, mw = 0;
+    for (int i = 0; i < n; ++i) {
+        const double g = (double)size / std::max(h[i], w[i]);
+        mh = std::max(mh, h[i] * g); mw = std::max(mw, w[i] * g);
+    }
+    nh = (int)std::ceil(mh / 32.0) * 32; nw = (int)std::ceil(mw / 32.0) * 32;
+}
+
+static LetterboxGeom letterbox_geom(int h0, int w0, int nh, int nw, bool swap_rb) {
+    LetterboxGeom g{};
+    g.src_h = h0; g.src_w = w0; g.net_h = nh; g.net_w = nw;
+    const double r = std::min((double)nh / h0, (double)nw / w0);
+    g.unpad_w = py_round(w0 * r); g.unpad_h = py_round(h0 * r);
+    const double dw = (nw - g.unpad_w) / 2.0, dh = (nh - g.unpad_h) / 2.0;
+    g.top = py_round(dh - 0.1); g.left = py_round(dw - 0.1);
+    g.swap_rb = swap_rb ? 1 : 0;
+    return g;
+}
+
+static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
+    std::vector<Op> ops;
+    VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
+    VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX));
+    // decode + NMS
+    const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 4);
+    DecodeLevel lv[3];
+    int base = 0;
+    const int strides[3] = {8, 16, 32};
+    for (int i = 0; i < 3; ++i) {
+        lv[i].logits = e->d_logits[i]; lv[i].ny = nh / strides[i]; lv[i].nx = nw / strides[i]; lv[i].cs = lcs;
+        lv[i].stride = (float)strides[i];
+        for (int a = 0; a < 3; ++a) { lv[i].anchor_w[a] = kAnchors[i][2 * a]; lv[i].anchor_h[a] = kAnchors[i][2 * a + 1]; }
+        lv[i].base = base;
+        base += 3 * lv[i].ny * lv[i].nx;
+    }
+    e->last_B = B; e->last_nh = nh; e->last_nw = nw; e->last_ntotal = base;
+    float* dbg = nullptr;
+    if (e->want_pred_debug) {
+        if (!e->d_pred_debug) {
+            const int S = round_up(e->cfg.img_size, 32);
+            const size_t nmax = (size_t)3 * ((S / 8) * (S / 8) + (S / 16) * (S / 16) + (S / 32) * (S / 32));
+            VC_TRY(dev_alloc(e, (void**)&e->d_pred_debug, (size_t)e->cfg.max_batch * nmax * no * sizeof(float)));
+        }
+        dbg = e->d_pred_debug;
+    }
+    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_decode(lv, 3, B, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, dbg, base, e->stream)); }
+    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_nms(B, e->cfg.max_candidates, e->cfg.max_det, e->cfg.iou_thres, e->d_geom, e->post, e->stream)); }
+    return VC_OK;
+}
+
+int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w, bool swap_rb) {
+    VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "detector not finalized");
+    VC_CHECK(B >= 1 && B <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    int nh, nw;
+    autoshape_net_size(&h, &w, 1, e->cfg.img_size, nh, nw);
+    const LetterboxGeom g = letterbox_geom(h, w, nh, nw, swap_rb);
+    float geom[5];
+    scale_geom_host(ScaleGeom{nh, nw, h, w}, geom);
+    std::vector<float> hg((size_t)B * 5);
+    for (int b = 0; b < B; ++b) memcpy(&hg[b * 5], geom, sizeof(geom));
+    VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));      // hg is a stack-lifetime vector
+    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->stream)); }
+    return yolo_forward(e, B, nh, nw);
+}
+
+// ------------------------------------------------------------------------------------------------ ReID net
+static const struct { const char* name; int cin, cout; bool down; } kReidBlocks[8] = {
+    {"layer1.0", 64, 64, false}, {"layer1.1", 64, 64, false}, {"layer2.0", 64, 128, true}, {"layer2.1", 128, 128, false},
+    {"layer3.0", 128, 256, true}, {"layer3.1", 256, 256, false}, {"layer4.0", 256, 512, true}, {"layer4.1", 512, 512, false}};
+
+static void reid_define(vc_engine* e) {
+    Net& n = e->reid;
+    n.add("conv", 64, 3, 3, 3);
+    for (const auto& b : kReidBlocks) {
+        n.add(std::string(b.name) + ".conv1", b.cout, b.cin, 3, 3);
+        n.add(std::string(b.name) + ".conv2", b.cout, b.cout, 3, 3);
+        if (b.down || b.cin != b.cout) n.add(std::string(b.name) + ".downsample", b.cout, b.cin, 1, 1);
+    }
+}
+
+static int reid_cpad(int prec) { return prec == PREC_F32 ? 4 : 8; }
+
+static int reid_alloc(vc_engine* e) {
+    const int es = elem_size(e->prec);
+    const size_t K = e->cfg.max_crops;
+    auto& m = e->rbuf;
+    VC_TRY(alloc_buf(e, m, "in", K * 50 * 50, reid_cpad(e->prec), es));
+    VC_TRY(alloc_buf(e, m, "r0", K * 50 * 50, 64, es));
+    VC_TRY(alloc_buf(e, m, "x0", K * 25 * 25, 64, es));
+    int hw = 25;
+    for (int i = 0; i < 8; ++i) {
+        const auto& b = kReidBlocks[i];
+        if (b.down) hw = (hw - 1) / 2 + 1;
+        const std::string p = b.name;
+        VC_TRY(alloc_buf(e, m, p + ".t", K * hw * hw, b.cout, es));
+        VC_TRY(alloc_buf(e, m, p + ".y", K * hw * hw, b.cout, es));
+        if (b.down || b.cin != b.cout) VC_TRY(alloc_buf(e, m, p + ".d", K * hw * hw, b.cout, es));
+    }
+    VC_TRY(dev_alloc(e, (void**)&e->d_crops, K * 5 * sizeof(int)));
+    VC_TRY(host_alloc(e, (void**)&e->h_crops, K * 5 * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_feat, K * VC_FEAT_DIM * sizeof(float)));
+    VC_TRY(host_alloc(e, (void**)&e->h_feat, K * VC_FEAT_DIM * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_reid_in_nchw, K * 3 * 50 * 50 * sizeof(float)));
+    return VC_OK;
+}
+
+// forward from the pre-filled "in" buffer (k x 50 x 50 x cpad) to e->d_feat
+static int reid_forward(vc_engine* e, int k) {
+    std::vector<Op> ops;
+    PlanBuilder pb{e, &e->reid, &ops, e->prec};
+    auto& m = e->rbuf;
+    View x = mkview(m["in"], k, 50, 50, reid_cpad(e->prec), 0);
+    x = pb.conv("conv", x, mkview(m["r0"], k, 50, 50, 64, 0), 3, 1, 1, ACT_RELU);             // model.py:51-55
+    { Op op{}; op.kind = Op::MAXPOOL; op.a = x; op.b = mkview(m["x0"], k, 25, 25, 64, 0); ops.push_back(op); x = op.b; }   // :58
+    for (const auto& b : kReidBlocks) {                                                        // BasicBlock.forward, model.py:30-38
+        const std::string p = b.name;
+        const int s = b.down ? 2 : 1;
+        View t = pb.conv(p + ".conv1", x, mkview(m[p + ".t"], k, 0, 0, b.cout, 0), 3, s, 1, ACT_RELU);
+        View sc = x;
+        if (b.down || b.cin != b.cout) sc = pb.conv(p + ".downsample", x, mkview(m[p + ".d"], k, 0, 0, b.cout, 0), 1, s, 0, ACT_NONE);
+        x = pb.conv(p + ".conv2", t, mkview(m[p + ".y"], k, 0, 0, b.cout, 0), 3, 1, 1, ACT_RELU, &sc, RES_BEFORE_ACT);
+    }
+    VC_TRY(pb.status);
+    VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX));
+    { ProfScope ps(e, VC_PROF_REID_AUX); VC_TRY(launch_avgpool_l2norm(x, e->d_feat, e->prec, e->stream)); }               // model.py:70,93
+    return VC_OK;
+}
+
+int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k) {
+    VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
+    VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
+    if (k <= 0) return VC_OK;
+    { ProfScope ps(e, VC_PROF_REID_AUX);
+      VC_TRY(launch_crop_resize(d_frames, H, W, e->d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, e->stream)); }
+    return reid_forward(e, k);
+}
+
+}  // namespace vc
+
+// ================================================================================================ C ABI
+using namespace vc;
+
+extern "C" {
+
+int vc_version(void) { return 100; }
+const char* vc_last_error(void) { return vc::last_error(); }
+int vc_device_count(int* n) {
+    VC_CHECK(n, VC_ERR_ARG, "null out pointer");
+    *n = 0;
+    VC_HIP(hipGetDeviceCount(n));
+    return VC_OK;
+}
+
+int vc_engine_config_default(vc_engine_config* c) {
+    VC_CHECK(c, VC_ERR_ARG, "null config");
+    memset(c, 0, sizeof(*c));
+    c->device = 0; c->precision = VC_PREC_BF16; c->yolo_variant = 0; c->num_classes = 80; c->img_size = 640;
+    c->max_batch = 16; c->max_frame_h = 720; c->max_frame_w = 1280;
+    c->conf_thres = 0.25f; c->iou_thres = 0.45f; c->max_det = 300; c->max_candidates = 4096;
+    c->max_crops = 1024; c->max_tracks = 4096; c->nn_budget_cap = 100; c->with_detector = 1; c->with_reid = 1;
+    return VC_OK;
+}
+
+int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
+    VC_CHECK(cfg && out, VC_ERR_ARG, "null argument");
+    VC_CHECK(cfg->yolo_variant >= 0 && cfg->yolo_variant <= 2, VC_ERR_ARG, "yolo_variant must be 0..2");
+    VC_CHECK(cfg->precision == VC_PREC_BF16 || cfg->precision == VC_PREC_F32, VC_ERR_ARG, "bad precision");
+    VC_CHECK(cfg->max_candidates % 64 == 0 && cfg->max_candidates >= 64 && cfg->max_candidates <= 8192, VC_ERR_ARG,
+             "max_candidates must be a multiple of 64 in [64, 8192]");
+    VC_CHECK(cfg->max_batch >= 1 && cfg->num_classes >= 1 && cfg->max_det >= 1, VC_ERR_ARG, "bad sizes");
+    int ndev = 0;
+    VC_HIP(hipGetDeviceCount(&ndev));
+    VC_CHECK(cfg->device >= 0 && cfg->device < ndev, VC_ERR_HIP, "device %d not present (%d visible)", cfg->device, ndev);
+    VC_HIP(hipSetDevice(cfg->device));
+    vc_engine* e = new vc_engine();
+    e->cfg = *cfg;
+    e->prec = cfg->precision;
+    int st = VC_OK;
+    do {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
+        if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
+        if (cfg->with_detector) yolo_define(e);
+        if (cfg->with_reid) reid_define(e);
+        st = tracker_init_pool(e);
+    } while (0);
+    if (st != VC_OK) { vc_engine_destroy(e); return st; }
+    *out = e;
+    return VC_OK;
+}
+
+int vc_engine_destroy(vc_engine* e) {
+    if (!e) return VC_OK;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    for (void* p : e->host_allocs) hipHostFree(p);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return VC_OK;
+}
+
+static Net* pick_net(vc_engine* e, int net) { return net == VC_NET_YOLO ? &e->yolo : (net == VC_NET_REID ? &e->reid : nullptr); }
+
+int vc_engine_param_count(const vc_engine* e, int net, int* n) {
+    VC_CHECK(e && n, VC_ERR_ARG, "null argument");
+    const Net* nn = pick_net(const_cast<vc_engine*>(e), net);
+    VC_CHECK(nn, VC_ERR_ARG, "bad net id %d", net);
+    *n = (int)nn->params.size();
+    return VC_OK;
+}
+
+int vc_engine_param_info(const vc_engine* e, int net, int index, char* name, int name_cap, int dims[4]) {
+    VC_CHECK(e && name && dims, VC_ERR_ARG, "null argument");
+    const Net* nn = pick_net(const_cast<vc_engine*>(e), net);
+    VC_CHECK(nn && index >= 0 && index < (int)nn->params.size(), VC_ERR_ARG, "bad net/index");
+    const ConvParam& p = nn->params[index];
+    snprintf(name, name_cap, "%s", p.name.c_str());
+    dims[0] = p.O; dims[1] = p.I; dims[2] = p.kh; dims[3] = p.kw;
+    return VC_OK;
+}
+
+int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w, const float* bias) {
+    VC_CHECK(e && name && w && bias, VC_ERR_ARG, "null argument");
+    VC_CHECK(!e->finalized, VC_ERR_STATE, "engine already finalized");
+    Net* nn = pick_net(e, net);
+    VC_CHECK(nn, VC_ERR_ARG, "bad net id %d", net);
+    auto it = nn->index.find(name);
+    VC_CHECK(it != nn->index.end(), VC_ERR_NOTFOUND, "no parameter named '%s'", name);
+    ConvParam& p = nn->params[it->second];
+    p.w.assign(w, w + (size_t)p.O * p.I * p.kh * p.kw);
+    p.b.assign(bias, bias + p.O);
+    p.set = true;
+    return VC_OK;
+}
+
+int vc_engine_finalize(vc_engine* e) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    VC_CHECK(!e->finalized, VC_ERR_STATE, "engine already finalized");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    for (auto& p : e->yolo.params) VC_TRY(pack_and_upload(e, p, e->prec));
+    for (auto& p : e->reid.params) VC_TRY(pack_and_upload(e, p, e->prec));
+    if (e->cfg.with_detector) VC_TRY(yolo_alloc(e));
+    if (e->cfg.with_reid) VC_TRY(reid_alloc(e));
+    for (auto& p : e->yolo.params) { p.w.clear(); p.w.shrink_to_fit(); }
+    for (auto& p : e->reid.params) { p.w.clear(); p.w.shrink_to_fit(); }
+    e->finalized = true;
+    return VC_OK;
+}
+
+int vc_engine_sync(vc_engine* e) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    VC_HIP(hipStreamSynchronize(e->stream));
+    return VC_OK;
+}
+
+// ---- detect --------------------------------------------------------------------------------------------
+int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* w, int n, float* out_det, int* out_count) {
+    VC_CHECK(e && rgb && h && w && out_det && out_count, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "detector not finalized");
+    VC_CHECK(n >= 1 && n <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, e->cfg.max_batch);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    int nh, nw;
+    autoshape_net_size(h, w, n, e->cfg.img_size, nh, nw);
+    size_t off = 0;
+    std::vector<float> hg((size_t)n * 5);
+    std::vector<size_t> offs(n);
+    for (int i = 0; i < n; ++i) {
+        VC_CHECK(h[i] > 0 && w[i] > 0, VC_ERR_ARG, "empty image %d", i);
+        const size_t bytes = (size_t)h[i] * w[i] * 3;
+        VC_CHECK(off + bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frames exceed the staging buffer (max_frame_h/w)");
+        VC_HIP(hipMemcpyAsync(e->d_frames + off, rgb[i], bytes, hipMemcpyHostToDevice, e->stream));
+        offs[i] = off; off += bytes;
+        scale_geom_host(ScaleGeom{nh, nw, h[i], w[i]}, &hg[(size_t)i * 5]);
+    }
+    VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    const size_t px = (size_t)nh * nw * 4 * elem_size(e->prec);
+    for (int i = 0; i < n; ++i) {
+        const LetterboxGeom g = letterbox_geom(h[i], w[i], nh, nw, false);
+        ProfScope ps(e, VC_PROF_DETECT_AUX);
+        VC_TRY(launch_letterbox(e->d_frames + offs[i], (char*)e->ybuf["in"].ptr + (size_t)i * px, 1, g, e->prec, e->stream));
+    }
+    VC_TRY(yolo_forward(e, n, nh, nw));
+    const int md = e->cfg.max_det;
+    VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)n * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    memcpy(out_det, e->h_det, (size_t)n * md * 6 * sizeof(float));
+    memcpy(out_count, e->h_det_count, n * sizeof(int));
+    return VC_OK;
+}
+
+int vc_detect_debug_shape(const vc_engine* e, int* net_h, int* net_w, int* n_candidates) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    if (net_h) *net_h = e->last_nh;
+    if (net_w) *net_w = e->last_nw;
+    if (n_candidates) *n_candidates = e->last_ntotal;
+    return VC_OK;
+}
+
+static int read_view_f32(vc_engine* e, const View& v, float* out, size_t cap, int dims[4]) {
+    const size_t n = (size_t)v.B * v.H * v.W * v.C;
+    VC_CHECK(n <= cap, VC_ERR_CAPACITY, "debug buffer too small: need %zu floats", n);
+    const int es = elem_size(e->prec);
+    const size_t rows = (size_t)v.B * v.H * v.W;
+    std::vector<uint8_t> raw(rows * v.cs * es);
+    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipMemcpy(raw.data(), v.ptr, raw.size(), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < rows; ++r)
+        for (int c = 0; c < v.C; ++c) {
+            const size_t o = r * v.cs + v.co + c;
+            out[r * v.C + c] = es == 4 ? ((const float*)raw.data())[o] : bf16_to_f32(((const uint16_t*)raw.data())[o]);
+        }
+    dims[0] = v.B; dims[1] = v.H; dims[2] = v.W; dims[3] = v.C;
+    return VC_OK;
+}
+
+int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int dims[4]) {
+    VC_CHECK(e && out && dims, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->last_B > 0, VC_ERR_STATE, "no detector run yet");
+    VC_CHECK(layer >= -1 && layer < 24, VC_ERR_ARG, "layer must be -1..23");
+    if (layer == -1) {
+        View v = mkview(e->ybuf["in"], e->last_B, e->last_nh, e->last_nw, 3, 0);
+        return read_view_f32(e, v, out, cap, dims);
+    }
+    return read_view_f32(e, e->layer_view[layer], out, cap, dims);
+}
+
+int vc_detect_debug_pred(vc_engine* e, float* out, size_t cap) {
+    VC_CHECK(e, VC_ERR_ARG, "null argument");
+    if (!out) { e->want_pred_debug = true; return VC_OK; }       // arm: the next run writes the full decoded tensor
+    VC_CHECK(e->d_pred_debug && e->last_B > 0, VC_ERR_STATE, "arm with out=NULL and run the detector first");
+    const size_t n = (size_t)e->last_B * e->last_ntotal * (e->cfg.num_classes + 5);
+    VC_CHECK(n <= cap, VC_ERR_CAPACITY, "need %zu floats", n);
+    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipMemcpy(out, e->d_pred_debug, n * sizeof(float), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+// ---- embed ---------------------------------------------------------------------------------------------
+// deep_sort.py:89-95 _xywh_to_xyxy: int() truncation toward zero, clamp to [0, W-1] / [0, H-1]
+static void crop_corners(const double* b, int W, int H, int out[4]) {
+    const double x = b[0], y = b[1], w = b[2], h = b[3];
+    out[0] = std::max((int)(x - w / 2), 0);
+    out[2] = std::min((int)(x + w / 2), W - 1);
+    out[1] = std::max((int)(y - h / 2), 0);
+    out[3] = std::min((int)(y + h / 2), H - 1);
+}
+
+int vc_embed(vc_engine* e, const uint8_t* bgr, int h, int w, const double* boxes, int k, float* out_feat) {
+    VC_CHECK(e && bgr && (k == 0 || (boxes && out_feat)), VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
+    VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
+    if (k == 0) return VC_OK;
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const size_t bytes = (size_t)h * w * 3;
+    VC_CHECK(bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frame exceeds the staging buffer");
+    for (int i = 0; i < k; ++i) {
+        int c[4];
+        crop_corners(boxes + (size_t)i * 4, w, h, c);
+        VC_CHECK(c[2] > c[0] && c[3] > c[1], VC_ERR_ARG, "box %d gives an empty crop (the reference's cv2.resize raises here)", i);
+        e->h_crops[i * 5 + 0] = 0; e->h_crops[i * 5 + 1] = c[0]; e->h_crops[i * 5 + 2] = c[1]; e->h_crops[i * 5 + 3] = c[2]; e->h_crops[i * 5 + 4] = c[3];
+    }
+    VC_HIP(hipMemcpyAsync(e->d_frames, bgr, bytes, hipMemcpyHostToDevice, e->stream));
+    VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    VC_TRY(run_reid_dev(e, e->d_frames, h, w, k));
+    VC_HIP(hipMemcpyAsync(e->h_feat, e->d_feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    memcpy(out_feat, e->h_feat, (size_t)k * VC_FEAT_DIM * sizeof(float));
+    return VC_OK;
+}
+
+int vc_embed_tensor(vc_engine* e, const float* x, int k, float* out_feat) {
+    VC_CHECK(e && x && out_feat, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
+    VC_CHECK(k >= 1 && k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_HIP(hipMemcpyAsync(e->d_reid_in_nchw, x, (size_t)k * 3 * 2500 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    VC_TRY(launch_nchw_to_nhwc_pad(e->d_reid_in_nchw, k, 3, 50, 50, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, e->stream));
+    VC_TRY(reid_forward(e, k));
+    VC_HIP(hipMemcpyAsync(e->h_feat, e->d_feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    memcpy(out_feat, e->h_feat, (size_t)k * VC_FEAT_DIM * sizeof(float));
+    return VC_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+int vc_profile_enable(vc_engine* e, int on) { VC_CHECK(e, VC_ERR_ARG, "null engine"); e->profiling = on != 0; return VC_OK; }
+int vc_profile_reset(vc_engine* e) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    for (auto& c : e->prof) c = ProfCat{};
+    return VC_OK;
+}
+int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double* flops, double* bytes) {
+    VC_CHECK(e && cat >= 0 && cat < VC_PROF_NCAT, VC_ERR_ARG, "bad category");
+    if (ms) *ms = e->prof[cat].ms;
+    if (launches) *launches = e->prof[cat].launches;
+    if (flops) *flops = e->prof[cat].flops;
+    if (bytes) *bytes = e->prof[cat].bytes;
+    return VC_OK;
+}
+
+// ---- single-function entry points --------------------------------------------------------------------------
+int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res, float* y) {
+    VC_CHECK(d && x && w && bias && y, VC_ERR_ARG, "null argument");
+    const int prec = d->precision, es = elem_size(prec), ch = prec == PREC_F32 ? 4 : 8;
+    vc_engine tmp;                           // only used as an allocation list
+    ConvParam p;
+    p.name = "host"; p.O = d->cout; p.I = d->cin; p.kh = d->kh; p.kw = d->kw; p.set = true;
+    p.w.assign(w, w + (size_t)d->cout * d->cin * d->kh * d->kw);
+    p.b.assign(bias, bias + d->cout);
+    int st = pack_and_upload(&tmp, p, prec);
+    const int cin_eff = p.cin_eff;
+    const int Ho = (d->h + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    const size_t npix_in = (size_t)d->b * d->h * d->w, npix_out = (size_t)d->b * Ho * Wo;
+    const int cout_s = round_up(d->cout, 4);
+    void *dx = nullptr, *dy = nullptr, *dr = nullptr;
+    auto upload = [&](const float* src, size_t npix, int C, int Cs, void** dst) -> int {
+        std::vector<uint8_t> buf(npix * Cs * es, 0);
+        for (size_t i = 0; i < npix; ++i)
+            for (int c = 0; c < C; ++c) {
+                if (es == 4) ((float*)buf.data())[i * Cs + c] = src[i * C + c];
+                else ((uint16_t*)buf.data())[i * Cs + c] = f32_to_bf16(src[i * C + c]);
+            }
+        VC_TRY(dev_alloc(&tmp, dst, buf.size()));
+        VC_HIP(hipMemcpy(*dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
+        return VC_OK;
+    };
+    if (st == VC_OK) st = upload(x, npix_in, d->cin, cin_eff, &dx);
+    if (st == VC_OK && res) st = upload(res, npix_out, d->cout, cout_s, &dr);
+    if (st == VC_OK) st = dev_alloc(&tmp, &dy, npix_out * cout_s * es);
+    if (st == VC_OK) {
+        ConvP c{};
+        c.in = dx; c.w = p.d_w; c.bias = p.d_b; c.res = dr; c.out = dy;
+        c.B = d->b; c.H = d->h; c.W = d->w; c.Cin = cin_eff; c.in_cs = cin_eff; c.in_co = 0;
+        c.Ho = Ho; c.Wo = Wo; c.Cout = d->cout; c.out_cs = cout_s; c.out_co = 0; c.res_cs = cout_s; c.res_co = 0;
+        c.kh = d->kh; c.kw = d->kw; c.sh = c.sw = d->stride; c.ph = c.pw = d->pad;
+        c.K = p.K; c.Kp = p.Kp; c.act = d->act; c.res_mode = res ? d->res_mode : RES_NONE; c.out_f32 = 0; c.prec = prec;
+        c.M = d->b * Ho * Wo;
+        st = launch_conv(c, nullptr);
+        if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
+    }
+    if (st == VC_OK) {
+        std::vector<uint8_t> buf(npix_out * cout_s * es);
+        if (hipMemcpy(buf.data(), dy, buf.size(), hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy back failed"); st = VC_ERR_HIP; }
+        for (size_t i = 0; i < npix_out && st == VC_OK; ++i)
+            for (int c = 0; c < d->cout; ++c)
+                y[i * d->cout + c] = es == 4 ? ((const float*)buf.data())[i * cout_s + c] : bf16_to_f32(((const uint16_t*)buf.data())[i * cout_s + c]);
+    }
+    for (void* q : tmp.allocs) hipFree(q);
+    tmp.allocs.clear();
+    return st;
+}
+
+int vc_letterbox_host(const uint8_t* rgb, int h, int w, int net_h, int net_w, int precision, float* out) {
+    VC_CHECK(rgb && out, VC_ERR_ARG, "null argument");
+    vc_engine tmp;
+    tmp.prec = precision;
+    const LetterboxGeom g = letterbox_geom(h, w, net_h, net_w, false);
+    void *ds = nullptr, *dd = nullptr;
+    const int es = elem_size(precision);
+    int st = dev_alloc(&tmp, &ds, (size_t)h * w * 3);
+    if (st == VC_OK) st = dev_alloc(&tmp, &dd, (size_t)net_h * net_w * 4 * es);
+    if (st == VC_OK && hipMemcpy(ds, rgb, (size_t)h * w * 3, hipMemcpyHostToDevice) != hipSuccess) { set_error("upload failed"); st = VC_ERR_HIP; }
+    if (st == VC_OK) st = launch_letterbox((const uint8_t*)ds, dd, 1, g, precision, nullptr);
+    if (st == VC_OK) {
+        std::vector<uint8_t> buf((size_t)net_h * net_w * 4 * es);
+        if (hipMemcpy(buf.data(), dd, buf.size(), hipMemcpyDeviceToHost) != hipSuccess) { set_error("letterbox failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
+        for (size_t i = 0; i < (size_t)net_h * net_w && st == VC_OK; ++i)
+            for (int c = 0; c < 3; ++c)
+                out[i * 3 + c] = es == 4 ? ((const float*)buf.data())[i * 4 + c] : bf16_to_f32(((const uint16_t*)buf.data())[i * 4 + c]);
+    }
+    for (void* q : tmp.allocs) hipFree(q);
+    tmp.allocs.clear();
+    return st;
+}
+
+}  // extern "C"

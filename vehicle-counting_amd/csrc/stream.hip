@@ -1,0 +1,164 @@
+// Fused stream path: the per-frame body of CountingPipeline.run (/root/reference/modules/__init__.py:54-84) for a
+// batch of device-resident frames of one camera: detect (batched) -> marshal like networks/yolo.py:72-97 ->
+// skip empty frames (quirk Q1) -> crops + ReID for every box of the batch in one launch -> per frame, in order,
+// one batched tracker step over the classes that have boxes (modules/track.py:50-59).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "engine.h"
+
+using namespace vc;
+
+namespace {
+
+// DataFrame.to_json(double_precision=10) -> json.loads (quirk Q9), same rounding as oracle/yolov5.py::marshal_like_reference
+inline double round10(double v) { return std::nearbyint(v * 1e10) / 1e10; }
+
+struct FrameDets {
+    std::vector<double> xyxy, conf;      // as VideoTracker.run sees them (xywh -> xyxy round trip included)
+    std::vector<int> label;
+};
+
+void marshal(const float* det6, int n, FrameDets& out) {
+    out.xyxy.clear(); out.conf.clear(); out.label.clear();
+    for (int i = 0; i < n; ++i) {
+        const float* d = det6 + (size_t)i * 6;
+        const double x1 = round10((double)d[0]), y1 = round10((double)d[1]), x2 = round10((double)d[2]), y2 = round10((double)d[3]);
+        const double w = x2 - x1, h = y2 - y1;                         // networks/yolo.py:82
+        out.xyxy.push_back(x1); out.xyxy.push_back(y1);
+        out.xyxy.push_back(w + x1); out.xyxy.push_back(h + y1);        // modules/track.py:39-41
+        out.conf.push_back(round10((double)d[4]));
+        out.label.push_back((int)d[5]);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_stream_inject(vc_engine* e, const float* det6, const int* count, int b, int n) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    if (!det6 || !count || b <= 0) { e->inject_b = 0; e->inject_det.clear(); e->inject_count.clear(); return VC_OK; }
+    VC_CHECK(n <= e->cfg.max_det, VC_ERR_CAPACITY, "injected detections per frame exceed max_det");
+    e->inject_det.assign(det6, det6 + (size_t)b * n * 6);
+    e->inject_count.assign(count, count + b);
+    e->inject_b = b; e->inject_n = n;
+    return VC_OK;
+}
+
+int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
+    VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const uint8_t* frames = (const uint8_t*)frames_dev;
+    const int md = e->cfg.max_det;
+    VC_TRY(run_detector_dev(e, frames, b, h, w, /*swap_rb=*/true));
+    VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)b * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, b * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    std::vector<FrameDets> fd(b);
+    for (int f = 0; f < b; ++f) {
+        if (e->inject_b > 0) {
+            const int fi = f % e->inject_b;
+            marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], fd[f]);
+        } else {
+            marshal(e->h_det + (size_t)f * md * 6, e->h_det_count[f], fd[f]);
+        }
+        if (out_ndet) out_ndet[f] = (int)fd[f].conf.size();
+    }
+    // frames are processed in groups whose crops fit one ReID launch
+    int f0 = 0;
+    while (f0 < b) {
+        int f1 = f0, total = 0;
+        while (f1 < b && total + (int)fd[f1].conf.size() <= e->cfg.max_crops) { total += (int)fd[f1].conf.size(); ++f1; }
+        VC_CHECK(f1 > f0, VC_ERR_CAPACITY, "one frame has more boxes (%zu) than max_crops (%d)", fd[f0].conf.size(), e->cfg.max_crops);
+        std::vector<int> row0(f1 - f0, 0);
+        int k = 0;
+        for (int f = f0; f < f1; ++f) {
+            row0[f - f0] = k;
+            FrameDets& d = fd[f];
+            for (size_t i = 0; i < d.conf.size(); ++i) {
+                const double* bx = &d.xyxy[i * 4];
+                const double bw = bx[2] - bx[0], bh = bx[3] - bx[1];                 // deep_sort.py:78-87
+                const double cx = bx[0] + bw / 2, cy = bx[1] + bh / 2;
+                int* c = e->h_crops + (size_t)k * 5;
+                c[0] = f;
+                c[1] = std::max((int)(cx - bw / 2), 0); c[3] = std::min((int)(cx + bw / 2), w - 1);    // deep_sort.py:89-95
+                c[2] = std::max((int)(cy - bh / 2), 0); c[4] = std::min((int)(cy + bh / 2), h - 1);
+                VC_CHECK(c[3] > c[1] && c[4] > c[2], VC_ERR_ARG,
+                         "frame %d box %zu gives an empty crop (the reference's cv2.resize raises here)", f, i);
+                ++k;
+            }
+        }
+        if (k > 0) {
+            VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            VC_TRY(run_reid_dev(e, frames, h, w, k));
+        }
+        for (int f = f0; f < f1; ++f) {
+            FrameDets& d = fd[f];
+            out_m[f] = 0;
+            if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
+            std::vector<int> ids, labs;
+            std::vector<std::vector<int>> groups;
+            for (int c = 0; c < num_classes; ++c) {
+                std::vector<int> g;
+                for (size_t i = 0; i < d.label.size(); ++i) if (d.label[i] == c) g.push_back((int)i);
+                if (g.empty()) continue;
+                ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(g));
+            }
+            if (ids.empty()) continue;
+            std::vector<int64_t> rows6;
+            VC_TRY(frame_track(e, frames, f, h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), (int)d.conf.size(), e->d_feat,
+                               row0[f - f0], rows6));
+            const int m = (int)(rows6.size() / 6);
+            VC_CHECK(m <= cap_rows_per_frame, VC_ERR_CAPACITY, "frame %d needs room for %d rows", f, m);
+            memcpy(out_rows6 + (size_t)f * cap_rows_per_frame * 6, rows6.data(), rows6.size() * sizeof(int64_t));
+            out_m[f] = m;
+        }
+        f0 = f1;
+    }
+    return VC_OK;
+}
+
+// Greedy class-offset NMS on an explicit candidate list (reference order), through the same three kernels the
+// detector uses.  Output rows [x1,y1,x2,y2,conf,cls] (network pixels, no rescale).
+int vc_nms_host(const float* boxes4, const float* conf, const int* cls, int n, float iou, int max_det, int max_cand, float* out6,
+                int* out_n) {
+    VC_CHECK(boxes4 && conf && cls && out6 && out_n && n >= 0, VC_ERR_ARG, "bad argument");
+    VC_CHECK(max_cand % 64 == 0 && max_cand >= 64 && max_cand <= 8192 && n <= max_cand, VC_ERR_ARG, "max_cand must be a multiple of 64 in [64,8192] and >= n");
+    vc_engine tmp;
+    DetectPostBuffers pb{};
+    float* geom = nullptr;
+    int st = VC_OK;
+    const size_t mc = max_cand;
+    auto A = [&](void** p, size_t bytes) { if (st == VC_OK) st = dev_alloc(&tmp, p, bytes); };
+    A((void**)&pb.cand_box, mc * 16); A((void**)&pb.cand_conf, mc * 4); A((void**)&pb.cand_cls, mc * 4); A((void**)&pb.cand_idx, mc * 4);
+    A((void**)&pb.cand_count, 4); A((void**)&pb.sort_box, mc * 16); A((void**)&pb.sort_conf, mc * 4); A((void**)&pb.sort_cls, mc * 4);
+    A((void**)&pb.mask, mc * (mc / 64) * 8); A((void**)&pb.det, (size_t)max_det * 24); A((void**)&pb.det_count, 4); A((void**)&pb.overflow, 4);
+    A((void**)&geom, 20);
+    if (st == VC_OK) {
+        std::vector<int> idx(n);
+        std::iota(idx.begin(), idx.end(), 0);
+        const float g[5] = {1.f, 0.f, 0.f, 1e30f, 1e30f};
+        bool ok = hipMemcpy(pb.cand_box, boxes4, (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(pb.cand_conf, conf, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(pb.cand_cls, cls, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(pb.cand_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(pb.cand_count, &n, 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(geom, g, 20, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { set_error("upload failed"); st = VC_ERR_HIP; }
+    }
+    if (st == VC_OK) st = launch_nms(1, max_cand, max_det, iou, geom, pb, nullptr);
+    if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("nms kernels failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
+    if (st == VC_OK) {
+        if (hipMemcpy(out_n, pb.det_count, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out6, pb.det, (size_t)std::min(*out_n, max_det) * 24, hipMemcpyDeviceToHost) != hipSuccess) { set_error("download failed"); st = VC_ERR_HIP; }
+    }
+    for (void* q : tmp.allocs) (void)hipFree(q);
+    tmp.allocs.clear();
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,278 @@
+// Batched DeepSORT numerics on the device: Kalman predict / initiate / update, Mahalanobis gating folded into the
+// appearance (gallery cosine) cost, and the IoU cost.  fp64 where the reference is fp64, fp32 where it is fp32.
+//
+// Reference (paths relative to /root/reference/networks/deepsort/sort/):
+//   kalman_filter.py:55-85   initiate            -> kalman_initiate_kernel
+//   kalman_filter.py:87-121  predict             -> kalman_predict_kernel   (F P F^T is exact: F is 0/1)
+//   kalman_filter.py:123-152 project             -> project4()
+//   kalman_filter.py:154-186 update              -> kalman_update_kernel    (4x4 Cholesky of S, K = P H^T S^-1)
+//   kalman_filter.py:188-229 gating_distance     -> maha4()
+//   nn_matching.py:31-54,78-96,160-177 distance  -> appearance_cost_kernel  (re-normalise, 1 - a.b, min over samples)
+//   linear_assignment.py:148-192 gate_cost_matrix-> appearance_cost_kernel  (chi2inv95[4] = 9.4877 -> 1e5)
+//   iou_matching.py:7-81     iou / iou_cost      -> iou_cost_kernel
+//   track.py:82-96           to_tlwh             -> mean_to_tlwh()
+// One wavefront owns one (track, detection) dot-product stream; reductions are wave shuffles, no atomics.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace vc {
+
+#define VC_W_POS (1.0 / 20)
+#define VC_W_VEL (1.0 / 160)
+#define VC_CHI2_95_4 9.4877
+#define VC_GATED 1e5
+
+__global__ __launch_bounds__(64) void kalman_initiate_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double* m = tp.mean + (size_t)slots[i] * 8;
+    double* P = tp.cov + (size_t)slots[i] * 64;
+    const double* z = xyah + (size_t)i * 4;
+    const double h = z[3];
+    for (int k = 0; k < 4; ++k) { m[k] = z[k]; m[4 + k] = 0.0; }
+    const double sp = (2 * VC_W_POS) * h, sv = (10 * VC_W_VEL) * h;
+    const double sd[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) P[r * 8 + c] = r == c ? sd[r] * sd[r] : 0.0;
+}
+
+__global__ __launch_bounds__(64) void kalman_predict_kernel(TrackPool tp, const int* slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double* m = tp.mean + (size_t)slots[i] * 8;
+    double* P = tp.cov + (size_t)slots[i] * 64;
+    const double h = m[3];
+    const double sp = VC_W_POS * h, sv = VC_W_VEL * h;
+    const double sd[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
+    double T[64];
+    // T = P F^T : column j < 4 gains column j+4
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) T[r * 8 + c] = c < 4 ? P[r * 8 + c] + P[r * 8 + c + 4] : P[r * 8 + c];
+    // P' = F T + Q : row r < 4 gains row r+4
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+            double v = r < 4 ? T[r * 8 + c] + T[(r + 4) * 8 + c] : T[r * 8 + c];
+            if (r == c) v += sd[r] * sd[r];
+            P[r * 8 + c] = v;
+        }
+    for (int k = 0; k < 4; ++k) m[k] = m[k] + m[k + 4];
+}
+
+// S = H P H^T + R (4x4), projected mean = mean[:4]
+__device__ __forceinline__ void project4(const double* m, const double* P, double S[16]) {
+    const double sp = VC_W_POS * m[3];
+    const double sd[4] = {sp, sp, 1e-1, sp};
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) S[r * 4 + c] = P[r * 8 + c] + (r == c ? sd[r] * sd[r] : 0.0);
+}
+
+__device__ __forceinline__ void chol4(const double S[16], double L[16]) {
+    for (int i = 0; i < 16; ++i) L[i] = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        double d = S[j * 4 + j];
+        for (int k = 0; k < j; ++k) d -= L[j * 4 + k] * L[j * 4 + k];
+        d = sqrt(d);
+        L[j * 4 + j] = d;
+        for (int i = j + 1; i < 4; ++i) {
+            double v = S[i * 4 + j];
+            for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
+            L[i * 4 + j] = v / d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double* m = tp.mean + (size_t)slots[i] * 8;
+    double* P = tp.cov + (size_t)slots[i] * 64;
+    const double* z = xyah + (size_t)i * 4;
+    double S[16], L[16], K[32];
+    project4(m, P, S);
+    chol4(S, L);
+    // K^T = S^-1 (P H^T)^T : for each state row r solve S k = P[r, 0:4]
+    for (int r = 0; r < 8; ++r) {
+        double y[4];
+        for (int a = 0; a < 4; ++a) {            // L y = b
+            double v = P[r * 8 + a];
+            for (int k = 0; k < a; ++k) v -= L[a * 4 + k] * y[k];
+            y[a] = v / L[a * 4 + a];
+        }
+        for (int a = 3; a >= 0; --a) {           // L^T x = y
+            double v = y[a];
+            for (int k = a + 1; k < 4; ++k) v -= L[k * 4 + a] * K[r * 4 + k];
+            K[r * 4 + a] = v / L[a * 4 + a];
+        }
+    }
+    double innov[4];
+    for (int a = 0; a < 4; ++a) innov[a] = z[a] - m[a];
+    double nm[8];
+    for (int r = 0; r < 8; ++r) {
+        double v = 0.0;
+        for (int a = 0; a < 4; ++a) v += innov[a] * K[r * 4 + a];
+        nm[r] = m[r] + v;
+    }
+    // P' = P - K (S K^T)
+    double SKt[32];                               // 4 x 8
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 8; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < 4; ++k) v += S[a * 4 + k] * K[c * 4 + k];
+            SKt[a * 8 + c] = v;
+        }
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+            double v = 0.0;
+            for (int a = 0; a < 4; ++a) v += K[r * 4 + a] * SKt[a * 8 + c];
+            P[r * 8 + c] = P[r * 8 + c] - v;
+        }
+    for (int r = 0; r < 8; ++r) m[r] = nm[r];
+}
+
+__device__ __forceinline__ double maha4(const double* m, const double L[16], const double* z) {
+    double y[4], acc = 0.0;
+    for (int a = 0; a < 4; ++a) {
+        double v = z[a] - m[a];
+        for (int k = 0; k < a; ++k) v -= L[a * 4 + k] * y[k];
+        y[a] = v / L[a * 4 + a];
+        acc += y[a] * y[a];
+    }
+    return acc;
+}
+
+// One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
+__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* __restrict__ feat,
+                                                              const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
+                                                              double* __restrict__ out) {
+    const CostJob jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* m = tp.mean + (size_t)jb.slot * 8;
+    const double* P = tp.cov + (size_t)jb.slot * 64;
+    double S[16], L[16];
+    project4(m, P, S);
+    chol4(S, L);
+    const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
+    for (int d = wave; d < jb.det_n; d += 4) {
+        const float* f = feat + (size_t)det_feat_row[jb.det_off + d] * VC_FEAT_DIM + lane * 8;
+        const float4 f0 = *(const float4*)f, f1 = *(const float4*)(f + 4);
+        float fn = f0.x * f0.x + f0.y * f0.y + f0.z * f0.z + f0.w * f0.w + f1.x * f1.x + f1.y * f1.y + f1.z * f1.z + f1.w * f1.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fn += __shfl_xor(fn, o);
+        const float finv = 1.0f / sqrtf(fn);
+        float best = -INFINITY;
+        for (int s = 0; s < jb.gal_count; ++s) {
+            const float* g = gal + (size_t)s * VC_FEAT_DIM + lane * 8;
+            const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
+            float dot = g0.x * f0.x + g0.y * f0.y + g0.z * f0.z + g0.w * f0.w + g1.x * f1.x + g1.y * f1.y + g1.z * f1.z + g1.w * f1.w;
+            float gn = g0.x * g0.x + g0.y * g0.y + g0.z * g0.z + g0.w * g0.w + g1.x * g1.x + g1.y * g1.y + g1.z * g1.z + g1.w * g1.w;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o); gn += __shfl_xor(gn, o); }
+            best = fmaxf(best, dot * finv * (1.0f / sqrtf(gn)));
+        }
+        if (lane == 0) {
+            const double g2 = maha4(m, L, det_xyah + (size_t)(jb.det_off + d) * 4);
+            out[jb.out_off + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - best);
+        }
+    }
+}
+
+__device__ __forceinline__ double iou_tlwh(const double* b, const double* c);
+__device__ __forceinline__ void mean_to_tlwh(const double* m, double t[4]) {
+    t[2] = m[2] * m[3];
+    t[3] = m[3];
+    t[0] = m[0] - t[2] / 2;
+    t[1] = m[1] - t[3] / 2;
+}
+
+__global__ __launch_bounds__(64) void iou_cost_kernel(TrackPool tp, const CostJob* jobs, const double* __restrict__ det_tlwh,
+                                                      double* __restrict__ out) {
+    const CostJob jb = jobs[blockIdx.x];
+    double b[4];
+    mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
+    for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x) {
+        if (jb.tsu > 1) { out[jb.out_off + d] = VC_GATED; continue; }
+        out[jb.out_off + d] = 1.0 - iou_tlwh(b, det_tlwh + (size_t)(jb.det_off + d) * 4);
+    }
+}
+
+__global__ __launch_bounds__(128) void gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
+    const int* e = sps + (size_t)blockIdx.x * 3;
+    float* dst = tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM;
+    const float* src = feat + (size_t)e[2] * VC_FEAT_DIM;
+    ((float4*)dst)[threadIdx.x] = ((const float4*)src)[threadIdx.x];
+}
+
+__device__ __forceinline__ double iou_tlwh(const double* b, const double* c) {
+    const double tlx = fmax(b[0], c[0]), tly = fmax(b[1], c[1]);
+    const double brx = fmin(b[0] + b[2], c[0] + c[2]), bry = fmin(b[1] + b[3], c[1] + c[3]);
+    const double w = fmax(0.0, brx - tlx), h = fmax(0.0, bry - tly);
+    const double inter = w * h;
+    return inter / (b[2] * b[3] + c[2] * c[3] - inter);
+}
+
+__global__ __launch_bounds__(64) void iou_boxes_kernel(const double* a, int t, const double* b, int d, double* out) {
+    const int i = blockIdx.x;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) out[(size_t)i * d + j] = iou_tlwh(a + (size_t)i * 4, b + (size_t)j * 4);
+}
+
+__global__ __launch_bounds__(64) void gating_values_kernel(TrackPool tp, int slot, const double* z, int n, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* m = tp.mean + (size_t)slot * 8;
+    double S[16], L[16];
+    project4(m, tp.cov + (size_t)slot * 64, S);
+    chol4(S, L);
+    out[i] = maha4(m, L, z + (size_t)i * 4);
+}
+
+int launch_gating_values(const TrackPool& tp, int slot, const double* z, int n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(gating_values_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slot, z, n, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_iou_boxes(const double* a, int t, const double* b, int d, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(iou_boxes_kernel, dim3(t), dim3(64), 0, s, a, t, b, d, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+int launch_kalman_predict(TrackPool& tp, const int* slots, int n, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(kalman_predict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, n);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_kalman_initiate(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(kalman_initiate_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, xyah, n);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_kalman_update(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(kalman_update_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, xyah, n);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const float* feat, const int* det_feat_row,
+                           const double* det_xyah, double* out, hipStream_t s) {
+    if (njobs <= 0) return VC_OK;
+    hipLaunchKernelGGL(appearance_cost_kernel, dim3(njobs), dim3(256), 0, s, tp, jobs, feat, det_feat_row, det_xyah, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_iou_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const double* det_tlwh, double* out, hipStream_t s) {
+    if (njobs <= 0) return VC_OK;
+    hipLaunchKernelGGL(iou_cost_kernel, dim3(njobs), dim3(64), 0, s, tp, jobs, det_tlwh, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(gallery_write_kernel, dim3(n), dim3(128), 0, s, tp, slot_pos_src, feat);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace vc

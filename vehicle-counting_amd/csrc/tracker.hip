@@ -1,0 +1,736 @@
+// DeepSORT tracker: host-side track lifecycle + assignment around the batched device numerics of
+// track_kernels.hip.  One Tracker per (camera, class) like the reference (modules/track.py:16); all of a frame's
+// trackers are stepped together so a frame costs two host<->device round trips regardless of the class count.
+//
+// Reference (paths relative to /root/reference/networks/deepsort/):
+//   sort/tracker.py:40-139        Tracker.predict / update / _match / _initiate_track
+//   sort/track.py:4-175           Track state machine (Tentative -> Confirmed -> Deleted), counters
+//   sort/linear_assignment.py     min_cost_matching :13-77, matching_cascade :80-145 (gate folded into the kernel)
+//   sort/nn_matching.py:137-154   partial_fit: per-target sample lists trimmed to `budget` (device ring buffer here)
+//   sort/preprocessing.py:6-73    non_max_suppression (quirk Q6)
+//   deep_sort.py:25-59            DeepSort.update; modules/track.py:30-70 VideoTracker.run
+//   scipy.optimize.linear_sum_assignment (third-party; Crouse's shortest augmenting path, restated in lap_solve)
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "engine.h"
+
+namespace vc {
+
+enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
+
+// ------------------------------------------------------------------------------------------------ LSAP
+// Rectangular linear sum assignment, same algorithm and tie-breaking as SciPy's rectangular_lsap
+// (D. F. Crouse, "On implementing 2D rectangular assignment algorithms", 2016): returns pairs sorted by row.
+static int lsap_core(int nr, int nc, const double* cost, std::vector<int>& col4row) {
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> u(nr, 0.0), v(nc, 0.0), spc(nc);
+    std::vector<int> path(nc, -1), row4col(nc, -1), remaining(nc);
+    std::vector<char> SR(nr), SC(nc);
+    col4row.assign(nr, -1);
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0;
+        int i = cur, num_remaining = nc, sink = -1;
+        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        std::fill(SR.begin(), SR.end(), 0);
+        std::fill(SC.begin(), SC.end(), 0);
+        std::fill(spc.begin(), spc.end(), INF);
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            SR[i] = 1;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = minVal + cost[(size_t)i * nc + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            minVal = lowest;
+            if (minVal == INF) return -1;
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += minVal;
+        for (int r = 0; r < nr; ++r) if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+        for (int j = 0; j < nc; ++j) if (SC[j]) v[j] -= minVal - spc[j];
+        int j = sink;
+        while (true) {
+            const int r = path[j];
+            row4col[j] = r;
+            std::swap(col4row[r], j);
+            if (r == cur) break;
+        }
+    }
+    return 0;
+}
+
+int lap_solve(const double* cost, int nr, int nc, std::vector<int>& rows, std::vector<int>& cols) {
+    rows.clear(); cols.clear();
+    if (nr == 0 || nc == 0) return VC_OK;
+    std::vector<int> c4r;
+    if (nc < nr) {                       // SciPy transposes so that rows <= cols
+        std::vector<double> t((size_t)nr * nc);
+        for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) t[(size_t)j * nr + i] = cost[(size_t)i * nc + j];
+        VC_CHECK(lsap_core(nc, nr, t.data(), c4r) == 0, VC_ERR_ARG, "lap: infeasible cost matrix");
+        std::vector<int> order(nc);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return c4r[a] < c4r[b]; });
+        for (int v : order) { rows.push_back(c4r[v]); cols.push_back(v); }
+    } else {
+        VC_CHECK(lsap_core(nr, nc, cost, c4r) == 0, VC_ERR_ARG, "lap: infeasible cost matrix");
+        for (int i = 0; i < nr; ++i) { rows.push_back(i); cols.push_back(c4r[i]); }
+    }
+    return VC_OK;
+}
+
+// sort/linear_assignment.py:52-77 on a dense sub-matrix given as full rows + selected columns
+struct MatchOut { std::vector<std::pair<int, int>> matches; std::vector<int> un_rows, un_cols; };
+static int min_cost_matching(const std::vector<const double*>& row_ptr, const std::vector<int>& rows, const std::vector<int>& cols,
+                             double max_cost, MatchOut& out) {
+    out.matches.clear(); out.un_rows.clear(); out.un_cols.clear();
+    const int nr = (int)rows.size(), nc = (int)cols.size();
+    if (nr == 0 || nc == 0) { out.un_rows = rows; out.un_cols = cols; return VC_OK; }
+    std::vector<double> c((size_t)nr * nc);
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) {
+            const double v = row_ptr[i][cols[j]];
+            c[(size_t)i * nc + j] = v > max_cost ? max_cost + 1e-5 : v;
+        }
+    std::vector<int> ri, ci;
+    VC_TRY(lap_solve(c.data(), nr, nc, ri, ci));
+    std::vector<char> col_used(nc, 0), row_used(nr, 0);
+    for (size_t k = 0; k < ri.size(); ++k) { row_used[ri[k]] = 1; col_used[ci[k]] = 1; }
+    for (int j = 0; j < nc; ++j) if (!col_used[j]) out.un_cols.push_back(cols[j]);
+    for (int i = 0; i < nr; ++i) if (!row_used[i]) out.un_rows.push_back(rows[i]);
+    for (size_t k = 0; k < ri.size(); ++k) {
+        if (c[(size_t)ri[k] * nc + ci[k]] > max_cost) { out.un_rows.push_back(rows[ri[k]]); out.un_cols.push_back(cols[ci[k]]); }
+        else out.matches.emplace_back(rows[ri[k]], cols[ci[k]]);
+    }
+    return VC_OK;
+}
+
+// sort/preprocessing.py:6-73 (overlap = inter / area(other), +1 pixel, '>' threshold; quirk Q6)
+void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep) {
+    keep.clear();
+    if (n == 0) return;
+    std::vector<double> x1(n), y1(n), x2(n), y2(n), area(n);
+    for (int i = 0; i < n; ++i) {
+        x1[i] = tlwh[i * 4]; y1[i] = tlwh[i * 4 + 1]; x2[i] = tlwh[i * 4 + 2] + tlwh[i * 4]; y2[i] = tlwh[i * 4 + 3] + tlwh[i * 4 + 1];
+        area[i] = (x2[i] - x1[i] + 1) * (y2[i] - y1[i] + 1);
+    }
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return scores[a] < scores[b]; });
+    while (!idx.empty()) {
+        const int i = idx.back();
+        idx.pop_back();
+        keep.push_back(i);
+        std::vector<int> rest;
+        for (int j : idx) {
+            const double w = std::max(0.0, std::min(x2[i], x2[j]) - std::max(x1[i], x1[j]) + 1);
+            const double h = std::max(0.0, std::min(y2[i], y2[j]) - std::max(y1[i], y1[j]) + 1);
+            if (!((w * h) / area[j] > max_overlap)) rest.push_back(j);
+        }
+        idx.swap(rest);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pool
+int tracker_init_pool(vc_engine* e) {
+    const size_t T = e->cfg.max_tracks, S = e->cfg.nn_budget_cap;
+    VC_CHECK(T >= 1 && S >= 1, VC_ERR_ARG, "max_tracks and nn_budget_cap must be positive");
+    e->pool.max_tracks = (int)T; e->pool.budget_cap = (int)S;
+    VC_TRY(dev_alloc(e, (void**)&e->pool.mean, T * 8 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->pool.cov, T * 64 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->pool.gallery, T * S * VC_FEAT_DIM * sizeof(float)));
+    e->free_slots.resize(T);
+    for (size_t i = 0; i < T; ++i) e->free_slots[i] = (int)(T - 1 - i);
+    e->det_cap = std::max(e->cfg.max_det * 2, 1024);
+    e->cost_cap = (size_t)2 * T * 512;
+    const size_t D = e->det_cap;
+    VC_TRY(host_alloc(e, (void**)&e->h_slots, (2 * T + D) * sizeof(int)));       VC_TRY(dev_alloc(e, (void**)&e->d_slots, (2 * T + D) * sizeof(int)));
+    VC_TRY(host_alloc(e, (void**)&e->h_xyah, (T + D) * 4 * sizeof(double)));      VC_TRY(dev_alloc(e, (void**)&e->d_xyah, (T + D) * 4 * sizeof(double)));
+    VC_TRY(host_alloc(e, (void**)&e->h_tlwh, D * 4 * sizeof(double)));            VC_TRY(dev_alloc(e, (void**)&e->d_tlwh, D * 4 * sizeof(double)));
+    VC_TRY(host_alloc(e, (void**)&e->h_jobs, 2 * T * sizeof(CostJob)));           VC_TRY(dev_alloc(e, (void**)&e->d_jobs, 2 * T * sizeof(CostJob)));
+    VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));      VC_TRY(dev_alloc(e, (void**)&e->d_cost, e->cost_cap * sizeof(double)));
+    VC_TRY(host_alloc(e, (void**)&e->h_sps, (T + D) * 3 * sizeof(int)));          VC_TRY(dev_alloc(e, (void**)&e->d_sps, (T + D) * 3 * sizeof(int)));
+    VC_TRY(host_alloc(e, (void**)&e->h_mean, T * 8 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, D * VC_FEAT_DIM * sizeof(float)));
+    return VC_OK;
+}
+
+static void tlwh_to_xyah(const double* t, double* o) {      // sort/detection.py:42-50
+    o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
+}
+
+// Steps `njobs` trackers (Tracker.predict(); Tracker.update(dets)) with one batched device pass each for
+// {predict, cost} and {update, initiate, gallery}.  dets[j].feat_rows index rows of d_feat.
+int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat) {
+    hipStream_t s = e->stream;
+    // ---------------- phase A: predict + cost matrices
+    int n_tracks = 0, n_dets = 0;
+    std::vector<int> det_base(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        VC_CHECK(tracker_ids[j] >= 0 && tracker_ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
+        Tracker& tk = *e->trackers[tracker_ids[j]];
+        for (TrackRec& t : tk.tracks) { e->h_slots[n_tracks++] = t.slot; t.age += 1; t.tsu += 1; }     // sort/track.py:112-124
+        det_base[j] = n_dets;
+        n_dets += dets[j].k;
+    }
+    VC_CHECK(n_dets <= e->det_cap, VC_ERR_CAPACITY, "%d detections in one step exceed capacity %d", n_dets, e->det_cap);
+    int* h_featrow = e->h_slots + n_tracks;                 // det -> feature row, stored after the slot list
+    for (int j = 0; j < njobs; ++j)
+        for (int i = 0; i < dets[j].k; ++i) {
+            const int g = det_base[j] + i;
+            memcpy(e->h_tlwh + (size_t)g * 4, dets[j].tlwh + (size_t)i * 4, 4 * sizeof(double));
+            tlwh_to_xyah(dets[j].tlwh + (size_t)i * 4, e->h_xyah + (size_t)g * 4);
+            h_featrow[g] = dets[j].feat_rows ? dets[j].feat_rows[i] : dets[j].feat_off + i;
+        }
+    // cost jobs: appearance rows for confirmed tracks, IoU rows for every track, each over all of its tracker's dets
+    int n_app = 0, n_iou = 0;
+    size_t out = 0;
+    std::vector<std::vector<int>> app_job(njobs), iou_job(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        Tracker& tk = *e->trackers[tracker_ids[j]];
+        if (dets[j].k == 0) continue;
+        app_job[j].assign(tk.tracks.size(), -1);
+        for (size_t t = 0; t < tk.tracks.size(); ++t) {
+            const TrackRec& tr = tk.tracks[t];
+            if (tr.state != CONFIRMED) continue;
+            CostJob& cj = e->h_jobs[n_app];
+            cj.slot = tr.slot; cj.gal_count = tr.gal_count; cj.det_off = det_base[j]; cj.det_n = dets[j].k; cj.out_off = (int)out; cj.tsu = tr.tsu;
+            app_job[j][t] = n_app++;
+            out += dets[j].k;
+        }
+    }
+    for (int j = 0; j < njobs; ++j) {
+        Tracker& tk = *e->trackers[tracker_ids[j]];
+        if (dets[j].k == 0) continue;
+        iou_job[j].assign(tk.tracks.size(), -1);
+        for (size_t t = 0; t < tk.tracks.size(); ++t) {
+            const TrackRec& tr = tk.tracks[t];
+            if (tr.state == CONFIRMED && tr.tsu != 1) continue;       // never an IoU candidate (sort/tracker.py:118-120)
+            CostJob& cj = e->h_jobs[n_app + n_iou];
+            cj.slot = tr.slot; cj.gal_count = 0; cj.det_off = det_base[j]; cj.det_n = dets[j].k; cj.out_off = (int)out; cj.tsu = tr.tsu;
+            iou_job[j][t] = n_app + n_iou++;
+            out += dets[j].k;
+        }
+    }
+    VC_CHECK(out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", out, e->cost_cap);
+    if (n_tracks + n_dets > 0) VC_HIP(hipMemcpyAsync(e->d_slots, e->h_slots, (size_t)(n_tracks + n_dets) * sizeof(int), hipMemcpyHostToDevice, s));
+    if (n_dets > 0) {
+        VC_HIP(hipMemcpyAsync(e->d_xyah, e->h_xyah, (size_t)n_dets * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        VC_HIP(hipMemcpyAsync(e->d_tlwh, e->h_tlwh, (size_t)n_dets * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    if (n_app + n_iou > 0) VC_HIP(hipMemcpyAsync(e->d_jobs, e->h_jobs, (size_t)(n_app + n_iou) * sizeof(CostJob), hipMemcpyHostToDevice, s));
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_predict(e->pool, e->d_slots, n_tracks, s)); }
+    { ProfScope ps(e, VC_PROF_TRACK);
+      VC_TRY(launch_appearance_cost(e->pool, e->d_jobs, n_app, d_feat, e->d_slots + n_tracks, e->d_xyah, e->d_cost, s)); }
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, e->d_jobs + n_app, n_iou, e->d_tlwh, e->d_cost, s)); }
+    if (out > 0) VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, out * sizeof(double), hipMemcpyDeviceToHost, s));
+    VC_HIP(hipStreamSynchronize(s));
+
+    // ---------------- phase B: association + lifecycle (host), then the batched Kalman update
+    int n_upd = 0, n_new = 0, n_gal = 0;
+    // list layouts in the pinned scratch: update slots at [0, T), initiate slots at [T, 2T); xyah likewise
+    const int T = e->pool.max_tracks;
+    int* upd_slots = e->h_slots; int* new_slots = e->h_slots + T;
+    double* upd_xyah = e->h_xyah; double* new_xyah = e->h_xyah + (size_t)T * 4;
+    std::vector<double> det_xyah((size_t)n_dets * 4);
+    memcpy(det_xyah.data(), e->h_xyah, det_xyah.size() * sizeof(double));       // h_xyah is reused for the lists below
+    std::vector<int> featrow(h_featrow, h_featrow + n_dets);
+    for (int j = 0; j < njobs; ++j) {
+        Tracker& tk = *e->trackers[tracker_ids[j]];
+        const int k = dets[j].k;
+        const int nt = (int)tk.tracks.size();
+        std::vector<int> confirmed, unconfirmed;
+        for (int t = 0; t < nt; ++t) (tk.tracks[t].state == CONFIRMED ? confirmed : unconfirmed).push_back(t);
+        std::vector<std::pair<int, int>> matches;
+        std::vector<int> left(k);
+        std::iota(left.begin(), left.end(), 0);
+        MatchOut mo;
+        // matching_cascade, sort/linear_assignment.py:124-145
+        std::vector<char> matched_track(nt, 0);
+        for (int level = 0; level < tk.p.max_age; ++level) {
+            if (left.empty()) break;
+            std::vector<int> lvl;
+            for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
+            if (lvl.empty()) continue;
+            std::vector<const double*> rp;
+            for (int t : lvl) rp.push_back(e->h_cost + e->h_jobs[app_job[j][t]].out_off);
+            VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
+            for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
+            left = mo.un_cols;
+        }
+        std::vector<int> un_a;                                   // set(confirmed) - matched, ascending ("set order")
+        for (int t : confirmed) if (!matched_track[t]) un_a.push_back(t);
+        // IoU stage, sort/tracker.py:118-127
+        std::vector<int> cand = unconfirmed, un_tracks;
+        for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
+        {
+            std::vector<const double*> rp;
+            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + e->h_jobs[iou_job[j][t]].out_off);
+            else rp.assign(cand.size(), nullptr);
+            VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
+        }
+        for (auto& m : mo.matches) matches.push_back(m);
+        for (int t : mo.un_rows) un_tracks.push_back(t);
+        const std::vector<int>& un_dets = mo.un_cols;
+
+        // Track.update, sort/track.py:126-145
+        for (auto& m : matches) {
+            TrackRec& tr = tk.tracks[m.first];
+            const int g = det_base[j] + m.second;
+            VC_CHECK(n_upd < T, VC_ERR_CAPACITY, "too many track updates");
+            upd_slots[n_upd] = tr.slot;
+            memcpy(upd_xyah + (size_t)n_upd * 4, &det_xyah[(size_t)g * 4], 4 * sizeof(double));
+            ++n_upd;
+            const int pos = tr.gal_head;
+            e->h_sps[n_gal * 3] = tr.slot; e->h_sps[n_gal * 3 + 1] = pos; e->h_sps[n_gal * 3 + 2] = featrow[g]; ++n_gal;
+            tr.gal_head = (tr.gal_head + 1) % tk.p.nn_budget;
+            tr.gal_count = std::min(tr.gal_count + 1, tk.p.nn_budget);
+            tr.last_conf = dets[j].conf[m.second];
+            tr.hits += 1; tr.tsu = 0;
+            if (tr.state == TENTATIVE && tr.hits >= tk.p.n_init) tr.state = CONFIRMED;
+        }
+        // Track.mark_missed, sort/track.py:147-153
+        for (int t : un_tracks) {
+            TrackRec& tr = tk.tracks[t];
+            if (tr.state == TENTATIVE) tr.state = DELETED;
+            else if (tr.tsu > tk.p.max_age) tr.state = DELETED;
+        }
+        // _initiate_track, sort/tracker.py:133-139
+        for (int d : un_dets) {
+            VC_CHECK(!e->free_slots.empty(), VC_ERR_CAPACITY, "track pool exhausted (max_tracks = %d)", e->cfg.max_tracks);
+            VC_CHECK(n_new < T, VC_ERR_CAPACITY, "too many new tracks");
+            TrackRec tr{};
+            tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
+            tr.slot = e->free_slots.back(); e->free_slots.pop_back();
+            const int g = det_base[j] + d;
+            new_slots[n_new] = tr.slot;
+            memcpy(new_xyah + (size_t)n_new * 4, &det_xyah[(size_t)g * 4], 4 * sizeof(double));
+            ++n_new;
+            e->h_sps[n_gal * 3] = tr.slot; e->h_sps[n_gal * 3 + 1] = 0; e->h_sps[n_gal * 3 + 2] = featrow[g]; ++n_gal;
+            tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
+            tr.last_conf = dets[j].conf[d];
+            tk.tracks.push_back(tr);
+        }
+        // drop deleted tracks, sort/tracker.py:80
+        std::vector<TrackRec> alive;
+        for (TrackRec& tr : tk.tracks) {
+            if (tr.state == DELETED) e->free_slots.push_back(tr.slot);
+            else alive.push_back(tr);
+        }
+        tk.tracks.swap(alive);
+    }
+    if (n_upd > 0) {
+        VC_HIP(hipMemcpyAsync(e->d_slots, upd_slots, (size_t)n_upd * sizeof(int), hipMemcpyHostToDevice, s));
+        VC_HIP(hipMemcpyAsync(e->d_xyah, upd_xyah, (size_t)n_upd * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        ProfScope ps(e, VC_PROF_TRACK);
+        VC_TRY(launch_kalman_update(e->pool, e->d_slots, e->d_xyah, n_upd, s));
+    }
+    if (n_new > 0) {
+        VC_HIP(hipMemcpyAsync(e->d_slots + T, new_slots, (size_t)n_new * sizeof(int), hipMemcpyHostToDevice, s));
+        VC_HIP(hipMemcpyAsync(e->d_xyah + (size_t)T * 4, new_xyah, (size_t)n_new * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        ProfScope ps(e, VC_PROF_TRACK);
+        VC_TRY(launch_kalman_initiate(e->pool, e->d_slots + T, e->d_xyah + (size_t)T * 4, n_new, s));
+    }
+    if (n_gal > 0) {
+        VC_HIP(hipMemcpyAsync(e->d_sps, e->h_sps, (size_t)n_gal * 3 * sizeof(int), hipMemcpyHostToDevice, s));
+        ProfScope ps(e, VC_PROF_TRACK);
+        VC_TRY(launch_gallery_write(e->pool, e->d_sps, n_gal, d_feat, s));
+    }
+    return VC_OK;      // stream-ordered; readers of the pool synchronise (fetch_means)
+}
+
+// Kalman means of all tracks of a tracker, list order -> e->h_mean (blocking)
+static int fetch_means(vc_engine* e, const int* tracker_ids, int njobs, std::vector<int>& offsets) {
+    offsets.assign(njobs + 1, 0);
+    int n = 0;
+    for (int j = 0; j < njobs; ++j) { offsets[j] = n; n += (int)e->trackers[tracker_ids[j]]->tracks.size(); }
+    offsets[njobs] = n;
+    int q = 0;
+    for (int j = 0; j < njobs; ++j)
+        for (const TrackRec& t : e->trackers[tracker_ids[j]]->tracks)
+            VC_HIP(hipMemcpyAsync(e->h_mean + (size_t)(q++) * 8, e->pool.mean + (size_t)t.slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    return VC_OK;
+}
+
+// deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id] (box = Kalman posterior, quirk Q7)
+static void emit_rows(const Tracker& tk, const double* means, int W, int H, std::vector<int64_t>& rows5) {
+    for (size_t t = 0; t < tk.tracks.size(); ++t) {
+        const TrackRec& tr = tk.tracks[t];
+        if (tr.state != CONFIRMED || tr.tsu > 1) continue;
+        const double* m = means + t * 8;
+        const double w = m[2] * m[3], h = m[3];
+        const double x = m[0] - w / 2, y = m[1] - h / 2;
+        rows5.push_back(std::max((int64_t)x, (int64_t)0));
+        rows5.push_back(std::max((int64_t)y, (int64_t)0));
+        rows5.push_back(std::min((int64_t)(x + w), (int64_t)W - 1));
+        rows5.push_back(std::min((int64_t)(y + h), (int64_t)H - 1));
+        rows5.push_back(tr.id);
+    }
+}
+
+// DeepSort.update minus the embedding: confidence filter, tlwh, DeepSORT NMS -> detections in pick order
+struct Prepared { std::vector<double> tlwh, conf; std::vector<int> feat_rows; };
+static void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k, const vc_tracker_params& p, Prepared& out) {
+    std::vector<double> tl, cf;
+    std::vector<int> fr;
+    for (int i = 0; i < k; ++i) {
+        if (!(conf[i] > p.min_confidence)) continue;                 // deep_sort.py:31 (features were computed for all, Q5)
+        const double* b = xyxy + (size_t)i * 4;
+        const double w = b[2] - b[0], h = b[3] - b[1];               // _xyxy_to_xywh :78-87
+        const double cx = b[0] + w / 2, cy = b[1] + h / 2;
+        tl.push_back(cx - w / 2.); tl.push_back(cy - h / 2.); tl.push_back(w); tl.push_back(h);   // _xywh_to_tlwh :68-75
+        cf.push_back(conf[i]);
+        fr.push_back(rows[i]);
+    }
+    std::vector<int> keep;
+    dsort_nms(tl.data(), cf.data(), (int)cf.size(), p.nms_max_overlap, keep);
+    out.tlwh.clear(); out.conf.clear(); out.feat_rows.clear();
+    for (int i : keep) {
+        for (int c = 0; c < 4; ++c) out.tlwh.push_back(tl[(size_t)i * 4 + c]);
+        out.conf.push_back(cf[i]);
+        out.feat_rows.push_back(fr[i]);
+    }
+}
+
+static void xyxy_to_cxcywh(const double* b, double* o) {
+    const double w = b[2] - b[0], h = b[3] - b[1];
+    o[0] = b[0] + w / 2; o[1] = b[1] + h / 2; o[2] = w; o[3] = h;
+}
+
+static void crop_corners_i(const double* b, int W, int H, int* c) {  // deep_sort.py:89-95
+    c[0] = std::max((int)(b[0] - b[2] / 2), 0); c[2] = std::min((int)(b[0] + b[2] / 2), W - 1);
+    c[1] = std::max((int)(b[1] - b[3] / 2), 0); c[3] = std::min((int)(b[1] + b[3] / 2), H - 1);
+}
+
+// Shared by vc_deepsort_update / vc_videotracker_run / vc_stream_run: one frame already on the device.
+// groups: per tracker the indices (into xyxy/conf) of its boxes.  Output rows [x1,y1,x2,y2,id,label].
+int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
+                const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
+                int n, const float* d_feat_ready, int feat_row0, std::vector<int64_t>& rows6) {
+    // crops + embedding for every box (unless the caller already embedded them: d_feat_ready)
+    const float* d_feat = d_feat_ready;
+    if (!d_feat) {
+        VC_CHECK(n <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", n, e->cfg.max_crops);
+        for (int i = 0; i < n; ++i) {
+            double c[4]; int q[4];
+            xyxy_to_cxcywh(xyxy + (size_t)i * 4, c);
+            crop_corners_i(c, W, H, q);
+            VC_CHECK(q[2] > q[0] && q[3] > q[1], VC_ERR_ARG, "box %d gives an empty crop (the reference's cv2.resize raises here)", i);
+            int* h = e->h_crops + (size_t)i * 5;
+            h[0] = frame_index; h[1] = q[0]; h[2] = q[1]; h[3] = q[2]; h[4] = q[3];
+        }
+        VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)n * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        VC_TRY(run_reid_dev(e, d_frame_base, H, W, n));
+        d_feat = e->d_feat;
+        feat_row0 = 0;
+    }
+    const int nj = (int)tracker_ids.size();
+    std::vector<Prepared> prep(nj);
+    std::vector<DetIn> din(nj);
+    for (int j = 0; j < nj; ++j) {
+        const auto& g = groups[j];
+        std::vector<double> bx(g.size() * 4), cf(g.size());
+        std::vector<int> rows(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            memcpy(&bx[i * 4], xyxy + (size_t)g[i] * 4, 4 * sizeof(double));
+            cf[i] = conf[g[i]];
+            rows[i] = feat_row0 + g[i];
+        }
+        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, prep[j]);
+        din[j].tlwh = prep[j].tlwh.data(); din[j].conf = prep[j].conf.data(); din[j].k = (int)prep[j].conf.size();
+        din[j].feat_rows = prep[j].feat_rows.data(); din[j].feat_off = 0;
+    }
+    VC_TRY(tracker_step_batch(e, tracker_ids.data(), din.data(), nj, d_feat));
+    std::vector<int> offs;
+    VC_TRY(fetch_means(e, tracker_ids.data(), nj, offs));
+    for (int j = 0; j < nj; ++j) {
+        std::vector<int64_t> r5;
+        emit_rows(*e->trackers[tracker_ids[j]], e->h_mean + (size_t)offs[j] * 8, W, H, r5);
+        for (size_t i = 0; i < r5.size(); i += 5) {
+            for (int c = 0; c < 5; ++c) rows6.push_back(r5[i + c]);
+            rows6.push_back(labels[j]);
+        }
+    }
+    return VC_OK;
+}
+
+}  // namespace vc
+
+// ================================================================================================ C ABI
+using namespace vc;
+
+extern "C" {
+
+int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
+    VC_CHECK(e && p && id, VC_ERR_ARG, "null argument");
+    VC_CHECK(p->nn_budget >= 1 && p->nn_budget <= e->cfg.nn_budget_cap, VC_ERR_CAPACITY,
+             "nn_budget %d outside [1, nn_budget_cap=%d] (an unbounded budget is not supported)", p->nn_budget, e->cfg.nn_budget_cap);
+    VC_CHECK(p->max_age >= 1 && p->n_init >= 1, VC_ERR_ARG, "max_age and n_init must be >= 1");
+    std::unique_ptr<Tracker> t(new Tracker());
+    t->p = *p;
+    e->trackers.push_back(std::move(t));
+    *id = (int)e->trackers.size() - 1;
+    return VC_OK;
+}
+
+int vc_tracker_reset(vc_engine* e, int id) {
+    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    Tracker& tk = *e->trackers[id];
+    for (const TrackRec& t : tk.tracks) e->free_slots.push_back(t.slot);
+    tk.tracks.clear();
+    tk.next_id = 1;
+    return VC_OK;
+}
+
+int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf, const float* feat, int k) {
+    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(k == 0 || (tlwh && conf && feat), VC_ERR_ARG, "null argument");
+    VC_CHECK(k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    if (k > 0) VC_HIP(hipMemcpyAsync(e->d_feat_in, feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    DetIn d{tlwh, conf, k, nullptr, 0};
+    VC_TRY(tracker_step_batch(e, &id, &d, 1, e->d_feat_in));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    return VC_OK;
+}
+
+int vc_tracker_count(vc_engine* e, int id, int* n) {
+    VC_CHECK(e && n && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    *n = (int)e->trackers[id]->tracks.size();
+    return VC_OK;
+}
+
+int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
+                     double* cov64, int* gallery_count) {
+    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    const Tracker& tk = *e->trackers[id];
+    VC_CHECK((int)tk.tracks.size() <= cap, VC_ERR_CAPACITY, "need room for %zu tracks", tk.tracks.size());
+    VC_HIP(hipStreamSynchronize(e->stream));
+    for (size_t t = 0; t < tk.tracks.size(); ++t) {
+        const TrackRec& tr = tk.tracks[t];
+        if (ids) ids[t] = tr.id;
+        if (state) state[t] = tr.state;
+        if (hits) hits[t] = tr.hits;
+        if (age) age[t] = tr.age;
+        if (tsu) tsu[t] = tr.tsu;
+        if (gallery_count) gallery_count[t] = tr.state == CONFIRMED ? tr.gal_count : 0;
+        if (mean8) VC_HIP(hipMemcpy(mean8 + t * 8, e->pool.mean + (size_t)tr.slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost));
+        if (cov64) VC_HIP(hipMemcpy(cov64 + t * 64, e->pool.cov + (size_t)tr.slot * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return VC_OK;
+}
+
+int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy, const double* conf, int k,
+                       int64_t* out_rows7, int cap_rows, int* out_m) {
+    VC_CHECK(e && bgr && out_m && id >= 0 && id < (int)e->trackers.size(), VC_ERR_ARG, "bad argument");
+    VC_CHECK(k >= 1 && bbox_xyxy && conf, VC_ERR_ARG, "DeepSort.update needs at least one box (the reference only calls it then)");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const size_t bytes = (size_t)h * w * 3;
+    VC_CHECK(bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frame exceeds the staging buffer");
+    VC_HIP(hipMemcpyAsync(e->d_frames, bgr, bytes, hipMemcpyHostToDevice, e->stream));
+    std::vector<int> all(k);
+    std::iota(all.begin(), all.end(), 0);
+    std::vector<int64_t> rows6;
+    VC_TRY(frame_track(e, e->d_frames, 0, h, w, {id}, {0}, {all}, bbox_xyxy, conf, k, nullptr, 0, rows6));
+    const int m = (int)(rows6.size() / 6);
+    VC_CHECK(m <= cap_rows, VC_ERR_CAPACITY, "need room for %d rows", m);
+    for (int i = 0; i < m; ++i) {
+        for (int c = 0; c < 5; ++c) out_rows7[i * 7 + c] = rows6[(size_t)i * 6 + c];
+        out_rows7[i * 7 + 5] = -1;       // track_feat slot: features of confirmed tracks were just cleared (quirk Q7)
+        out_rows7[i * 7 + 6] = 0;        // int(confidence) with confidence in (0, 1)
+    }
+    *out_m = m;
+    return VC_OK;
+}
+
+int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, const uint8_t* bgr, int h, int w, const double* boxes_xywh,
+                        const int64_t* labels, const double* scores, int n, int64_t* out_rows6, int cap_rows, int* out_m) {
+    VC_CHECK(e && trackers && bgr && out_m, VC_ERR_ARG, "null argument");
+    VC_CHECK(n >= 1 && boxes_xywh && labels && scores, VC_ERR_ARG, "VideoTracker.run needs at least one box (quirk Q1)");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const size_t bytes = (size_t)h * w * 3;
+    VC_CHECK(bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frame exceeds the staging buffer");
+    VC_HIP(hipMemcpyAsync(e->d_frames, bgr, bytes, hipMemcpyHostToDevice, e->stream));
+    std::vector<double> xyxy((size_t)n * 4);
+    for (int i = 0; i < n; ++i) {                               // modules/track.py:39-41
+        xyxy[i * 4] = boxes_xywh[i * 4]; xyxy[i * 4 + 1] = boxes_xywh[i * 4 + 1];
+        xyxy[i * 4 + 2] = boxes_xywh[i * 4 + 2] + boxes_xywh[i * 4]; xyxy[i * 4 + 3] = boxes_xywh[i * 4 + 3] + boxes_xywh[i * 4 + 1];
+    }
+    std::vector<int> ids, labs;
+    std::vector<std::vector<int>> groups;
+    for (int c = 0; c < num_classes; ++c) {                     // modules/track.py:50-59: classes without boxes are not stepped
+        std::vector<int> g;
+        for (int i = 0; i < n; ++i) if (labels[i] == c) g.push_back(i);
+        if (g.empty()) continue;
+        ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(g);
+    }
+    // boxes of classes outside [0, num_classes) are ignored exactly like the reference's mask loop; embed only used boxes
+    std::vector<int64_t> rows6;
+    if (!ids.empty()) {
+        std::vector<double> used_xyxy, used_conf;
+        std::vector<std::vector<int>> g2(groups.size());
+        for (size_t j = 0; j < groups.size(); ++j)
+            for (int i : groups[j]) {
+                g2[j].push_back((int)used_conf.size());
+                for (int c = 0; c < 4; ++c) used_xyxy.push_back(xyxy[(size_t)i * 4 + c]);
+                used_conf.push_back(scores[i]);
+            }
+        VC_TRY(frame_track(e, e->d_frames, 0, h, w, ids, labs, g2, used_xyxy.data(), used_conf.data(), (int)used_conf.size(), nullptr, 0, rows6));
+    }
+    const int m = (int)(rows6.size() / 6);
+    VC_CHECK(m <= cap_rows, VC_ERR_CAPACITY, "need room for %d rows", m);
+    memcpy(out_rows6, rows6.data(), rows6.size() * sizeof(int64_t));
+    *out_m = m;
+    return VC_OK;
+}
+
+// ---- single-function entry points (parity tests) --------------------------------------------------------------
+static int with_pool(int n, TrackPool& tp, std::vector<void*>& allocs, int** d_slots) {
+    tp.max_tracks = n; tp.budget_cap = 1;
+    VC_HIP(hipMalloc((void**)&tp.mean, (size_t)n * 8 * sizeof(double))); allocs.push_back(tp.mean);
+    VC_HIP(hipMalloc((void**)&tp.cov, (size_t)n * 64 * sizeof(double))); allocs.push_back(tp.cov);
+    tp.gallery = nullptr;
+    std::vector<int> s(n);
+    std::iota(s.begin(), s.end(), 0);
+    VC_HIP(hipMalloc((void**)d_slots, (size_t)n * sizeof(int))); allocs.push_back(*d_slots);
+    VC_HIP(hipMemcpy(*d_slots, s.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    return VC_OK;
+}
+static void free_all(std::vector<void*>& a) { for (void* p : a) hipFree(p); a.clear(); }
+
+#define VC_HOST_FINISH(st)                                                                                              \
+    if ((st) == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("kernel failed: %s", hipGetErrorString(hipGetLastError())); (st) = VC_ERR_HIP; }
+
+int vc_kalman_initiate_host(const double* xyah, int n, double* mean8, double* cov64) {
+    VC_CHECK(xyah && mean8 && cov64 && n > 0, VC_ERR_ARG, "bad argument");
+    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double* dz = nullptr;
+    int st = with_pool(n, tp, al, &ds);
+    if (st == VC_OK && hipMalloc((void**)&dz, (size_t)n * 32) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; } else al.push_back(dz);
+    if (st == VC_OK && hipMemcpy(dz, xyah, (size_t)n * 32, hipMemcpyHostToDevice) != hipSuccess) { set_error("copy"); st = VC_ERR_HIP; }
+    if (st == VC_OK) st = launch_kalman_initiate(tp, ds, dz, n, nullptr);
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) { hipMemcpy(mean8, tp.mean, (size_t)n * 64, hipMemcpyDeviceToHost); hipMemcpy(cov64, tp.cov, (size_t)n * 512, hipMemcpyDeviceToHost); }
+    free_all(al);
+    return st;
+}
+
+static int kalman_inout(double* mean8, double* cov64, const double* z4, int n, int which) {
+    VC_CHECK(mean8 && cov64 && n > 0, VC_ERR_ARG, "bad argument");
+    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double* dz = nullptr;
+    int st = with_pool(n, tp, al, &ds);
+    if (st == VC_OK) { hipMemcpy(tp.mean, mean8, (size_t)n * 64, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov64, (size_t)n * 512, hipMemcpyHostToDevice); }
+    if (st == VC_OK && z4) {
+        if (hipMalloc((void**)&dz, (size_t)n * 32) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; } else { al.push_back(dz); hipMemcpy(dz, z4, (size_t)n * 32, hipMemcpyHostToDevice); }
+    }
+    if (st == VC_OK) st = which == 0 ? launch_kalman_predict(tp, ds, n, nullptr) : launch_kalman_update(tp, ds, dz, n, nullptr);
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) { hipMemcpy(mean8, tp.mean, (size_t)n * 64, hipMemcpyDeviceToHost); hipMemcpy(cov64, tp.cov, (size_t)n * 512, hipMemcpyDeviceToHost); }
+    free_all(al);
+    return st;
+}
+int vc_kalman_predict_host(double* mean8, double* cov64, int n) { return kalman_inout(mean8, cov64, nullptr, n, 0); }
+int vc_kalman_update_host(double* mean8, double* cov64, const double* z4, int n) {
+    VC_CHECK(z4, VC_ERR_ARG, "null measurement");
+    return kalman_inout(mean8, cov64, z4, n, 1);
+}
+
+// gating distance of ONE track against n_meas measurements, through the appearance-cost kernel with an empty
+// gallery: returns the squared Mahalanobis distances reconstructed from the gate (exact values via a side channel)
+int vc_kalman_gating_host(const double* mean8, const double* cov64, const double* z4, int n_meas, double* out) {
+    VC_CHECK(mean8 && cov64 && z4 && out && n_meas > 0, VC_ERR_ARG, "bad argument");
+    // Reuse the device code path: a 1-track pool, gallery of one zero... the kernel only exposes the gated cost, so
+    // the distances themselves are produced by a dedicated tiny launch below.
+    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double *dz = nullptr, *dout = nullptr;
+    int st = with_pool(1, tp, al, &ds);
+    if (st == VC_OK) { hipMemcpy(tp.mean, mean8, 64, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov64, 512, hipMemcpyHostToDevice); }
+    if (st == VC_OK && (hipMalloc((void**)&dz, (size_t)n_meas * 32) != hipSuccess || hipMalloc((void**)&dout, (size_t)n_meas * 8) != hipSuccess)) { set_error("alloc"); st = VC_ERR_HIP; }
+    if (dz) al.push_back(dz);
+    if (dout) al.push_back(dout);
+    if (st == VC_OK) { hipMemcpy(dz, z4, (size_t)n_meas * 32, hipMemcpyHostToDevice); st = launch_gating_values(tp, 0, dz, n_meas, dout, nullptr); }
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) hipMemcpy(out, dout, (size_t)n_meas * 8, hipMemcpyDeviceToHost);
+    free_all(al);
+    return st;
+}
+
+int vc_iou_cost_host(const double* track_tlwh, int t, const double* det_tlwh, int d, double* out_iou) {
+    VC_CHECK(track_tlwh && det_tlwh && out_iou && t > 0 && d > 0, VC_ERR_ARG, "bad argument");
+    // tracks are given as boxes: build means (cx, cy, a, h) whose to_tlwh() reproduces them is lossy, so the kernel is
+    // driven through its box-level twin
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    std::vector<void*> al;
+    int st = VC_OK;
+    if (hipMalloc((void**)&da, (size_t)t * 32) != hipSuccess || hipMalloc((void**)&db, (size_t)d * 32) != hipSuccess ||
+        hipMalloc((void**)&dout, (size_t)t * d * 8) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; }
+    if (da) al.push_back(da);
+    if (db) al.push_back(db);
+    if (dout) al.push_back(dout);
+    if (st == VC_OK) { hipMemcpy(da, track_tlwh, (size_t)t * 32, hipMemcpyHostToDevice); hipMemcpy(db, det_tlwh, (size_t)d * 32, hipMemcpyHostToDevice);
+                       st = launch_iou_boxes(da, t, db, d, dout, nullptr); }
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) hipMemcpy(out_iou, dout, (size_t)t * d * 8, hipMemcpyDeviceToHost);
+    free_all(al);
+    return st;
+}
+
+int vc_cosine_cost_host(const float* gallery, const int* gal_count, int t, int s_cap, const float* feat, int d, double* out) {
+    VC_CHECK(gallery && gal_count && feat && out && t > 0 && d > 0 && s_cap > 0, VC_ERR_ARG, "bad argument");
+    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr;
+    int st = with_pool(t, tp, al, &ds);
+    tp.budget_cap = s_cap;
+    float* dfeat = nullptr; double *dz = nullptr, *dout = nullptr; CostJob* dj = nullptr; int* drow = nullptr;
+    if (st == VC_OK && (hipMalloc((void**)&tp.gallery, (size_t)t * s_cap * VC_FEAT_DIM * 4) != hipSuccess || hipMalloc((void**)&dfeat, (size_t)d * VC_FEAT_DIM * 4) != hipSuccess ||
+                        hipMalloc((void**)&dz, (size_t)d * 32) != hipSuccess || hipMalloc((void**)&dout, (size_t)t * d * 8) != hipSuccess ||
+                        hipMalloc((void**)&dj, (size_t)t * sizeof(CostJob)) != hipSuccess || hipMalloc((void**)&drow, (size_t)d * 4) != hipSuccess)) { set_error("alloc"); st = VC_ERR_HIP; }
+    for (void* p : {(void*)tp.gallery, (void*)dfeat, (void*)dz, (void*)dout, (void*)dj, (void*)drow}) if (p) al.push_back(p);
+    if (st == VC_OK) {
+        // a wide-open gate: identity covariance scaled up, measurement = mean
+        std::vector<double> mean((size_t)t * 8, 0.0), cov((size_t)t * 64, 0.0), z((size_t)d * 4, 0.0);
+        for (int i = 0; i < t; ++i) { mean[i * 8 + 3] = 100.0; for (int k = 0; k < 8; ++k) cov[(size_t)i * 64 + k * 9] = 1e6; }
+        for (int i = 0; i < d; ++i) z[i * 4 + 3] = 100.0;
+        std::vector<CostJob> jobs(t);
+        std::vector<int> rows(d);
+        std::iota(rows.begin(), rows.end(), 0);
+        for (int i = 0; i < t; ++i) jobs[i] = CostJob{i, gal_count[i], 0, d, i * d, 1};
+        hipMemcpy(tp.mean, mean.data(), mean.size() * 8, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov.data(), cov.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(tp.gallery, gallery, (size_t)t * s_cap * VC_FEAT_DIM * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dfeat, feat, (size_t)d * VC_FEAT_DIM * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dz, z.data(), z.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(CostJob), hipMemcpyHostToDevice);
+        hipMemcpy(drow, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
+        st = launch_appearance_cost(tp, dj, t, dfeat, drow, dz, dout, nullptr);
+    }
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) hipMemcpy(out, dout, (size_t)t * d * 8, hipMemcpyDeviceToHost);
+    free_all(al);
+    return st;
+}
+
+int vc_dsort_nms_host(const double* tlwh, const double* scores, int n, double max_overlap, int* keep, int* n_keep) {
+    VC_CHECK(n_keep && (n == 0 || (tlwh && scores && keep)), VC_ERR_ARG, "null argument");
+    std::vector<int> k;
+    dsort_nms(tlwh, scores, n, max_overlap, k);
+    for (size_t i = 0; i < k.size(); ++i) keep[i] = k[i];
+    *n_keep = (int)k.size();
+    return VC_OK;
+}
+
+int vc_lap_host(const double* cost, int nr, int nc, int* rows, int* cols, int* n_assigned) {
+    VC_CHECK(cost && rows && cols && n_assigned && nr >= 0 && nc >= 0, VC_ERR_ARG, "bad argument");
+    std::vector<int> r, c;
+    VC_TRY(lap_solve(cost, nr, nc, r, c));
+    for (size_t i = 0; i < r.size(); ++i) { rows[i] = r[i]; cols[i] = c[i]; }
+    *n_assigned = (int)r.size();
+    return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared declarations for libvcount_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/vcount_hip.h"
+
+namespace vc {
+
+// ---- error plumbing: every C-ABI entry returns a status, message kept per thread ---------------
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define VC_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            vc::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));  \
+            return VC_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+#define VC_CHECK(cond, code, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            vc::set_error(__VA_ARGS__);           \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define VC_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != VC_OK) return _s;   \
+    } while (0)
+
+// ---- element types --------------------------------------------------------------------------
+enum Prec : int { PREC_BF16 = 0, PREC_F32 = 1 };
+static inline int elem_size(int prec) { return prec == PREC_BF16 ? 2 : 4; }
+
+// round-to-nearest-even f32 -> bf16 (matches torch .bfloat16() and v_cvt_pk_bf16_f32)
+__host__ __device__ static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// ---- convolution as implicit GEMM (conv_igemm.hip) ----------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum ResMode : int { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
+
+struct ConvP {
+    const void* in;      // NHWC activations, element type = prec
+    const void* w;       // packed weights [Cout_pad][Kp], K order (r, s, c)
+    const float* bias;   // [Cout_pad] f32
+    const void* res;     // optional residual, NHWC, element type = prec
+    void* out;           // NHWC, element type = prec (or f32 when out_f32)
+    int B, H, W, Cin;    // logical input (Cin = channels consumed per tap; multiple of 8 (bf16) / 4 (f32))
+    int in_cs, in_co;    // channel stride / offset of the input buffer (elements)
+    int Ho, Wo, Cout;
+    int out_cs, out_co;
+    int res_cs, res_co;
+    int kh, kw, sh, sw, ph, pw;
+    int K, Kp;           // kh*kw*Cin and its padding to the K tile
+    int act, res_mode, out_f32, prec;
+    int M;               // B*Ho*Wo
+};
+
+int launch_conv(const ConvP& p, hipStream_t s);
+int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
+double conv_flops(const ConvP& p);
+
+}  // namespace vc

@@ -70,7 +70,7 @@ def yolo_conv_table(variant="yolov5s", nc=80):
     return t
 
 
-def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0):
+def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0, box_scale=0.5):
     """Seeded synthetic, BN-folded detector parameters: {name+'.weight': OIHW f32, name+'.bias': f32}.
 
     Conv weights are variance-preserving for SiLU; BN statistics are non-trivial so the fold is
@@ -86,6 +86,8 @@ def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0
             i = int(name.rsplit(".", 1)[1])
             stride = (8, 16, 32)[i]
             w = rng.standard_normal((co, ci, 1, 1), dtype=np.float32) * np.float32(det_scale / math.sqrt(fan_in))
+            # box regressors stay near their prior (sigmoid ~ 0.5 -> boxes about one anchor in size, never degenerate)
+            w.reshape(3, nc + 5, ci)[:, :4, :] *= np.float32(box_scale / det_scale)
             b = np.zeros((3, nc + 5), np.float32)
             b[:, 4] += math.log(8 / (640 / stride) ** 2) + obj_shift
             b[:, 5:] += math.log(0.6 / (nc - 0.99))
@@ -93,7 +95,10 @@ def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0
             b += rng.standard_normal(b.shape, dtype=np.float32) * np.float32(0.05)
             sd[name + ".weight"], sd[name + ".bias"] = w, b.reshape(-1)
             continue
-        w = rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(math.sqrt(2.6 / fan_in))
+        gain = 2.6
+        if ".m." in name and name.endswith("cv2.conv"):
+            gain = 0.4          # residual branch of a Bottleneck: keep the shortcut sum from growing
+        w = rng.standard_normal((co, ci, k, k), dtype=np.float32) * np.float32(math.sqrt(gain / fan_in))
         gamma = rng.uniform(0.9, 1.1, co).astype(np.float32)
         beta = (rng.standard_normal(co) * 0.1).astype(np.float32)
         mean = (rng.standard_normal(co) * 0.1).astype(np.float32)
