@@ -243,8 +243,6 @@ static int yolo_alloc(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&e->d_geom, B * 5 * sizeof(float)));
     VC_TRY(host_alloc(e, (void**)&e->h_det, B * md * 6 * sizeof(float)));
     VC_TRY(host_alloc(e, (void**)&e->h_det_count, B * sizeof(int)));
-    e->d_frames_bytes = B * (size_t)e->cfg.max_frame_h * e->cfg.max_frame_w * 3;
-    VC_TRY(dev_alloc(e, (void**)&e->d_frames, e->d_frames_bytes));
     return VC_OK;
 }
 
@@ -583,6 +581,8 @@ int vc_engine_finalize(vc_engine* e) {
     VC_HIP(hipSetDevice(e->cfg.device));
     for (auto& p : e->yolo.params) VC_TRY(pack_and_upload(e, p, e->prec));
     for (auto& p : e->reid.params) VC_TRY(pack_and_upload(e, p, e->prec));
+    e->d_frames_bytes = (size_t)e->cfg.max_batch * e->cfg.max_frame_h * e->cfg.max_frame_w * 3;     // staging for host frames
+    VC_TRY(dev_alloc(e, (void**)&e->d_frames, e->d_frames_bytes));
     if (e->cfg.with_detector) VC_TRY(yolo_alloc(e));
     if (e->cfg.with_reid) VC_TRY(reid_alloc(e));
     for (auto& p : e->yolo.params) { p.w.clear(); p.w.shrink_to_fit(); }
