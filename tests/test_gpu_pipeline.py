@@ -1,0 +1,51 @@
+"""GPU: end-to-end parity of the CSV artefact (SURVEY.md 8d ladder step 4) -- the oracle's per-video loop against the
+product's reference-shaped loop (host frames) and its fused stream path (device frames), fp32 mode."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from oracle import pipeline as op  # noqa: E402
+from vehicle_counting_amd.pipeline import CountingPipeline, FrameSource  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+
+NC = 8
+TRACK_CFG = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+
+
+def key(rows):
+    return [(r["label"], r["track_id"], r["frame_id"], r["direction"], r["fframe"], r["lframe"]) for r in rows]
+
+
+def test_csv_parity(golden_dir, tmp_path):
+    T, H, W = 18, 360, 640
+    frames = synth_frames(T, H, W, n_obj=6, seed=3)
+    ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+    zone = os.path.join(golden_dir, "cam_04_halfres.json")
+    ref_rows, ref_counts, n_det = op.run_video(frames, ysd, rsd, TRACK_CFG, zone, nc=NC)
+    assert sum(n_det) > 50 and len(ref_rows) > 10, (n_det, len(ref_rows))
+
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=str(tmp_path))
+    cam_cfg = {"cam": {"cam_04": {"tracking_config": TRACK_CFG}}}
+    for mode in ("loop", "stream"):
+        eng = E.Engine(ysd, rsd, precision="f32", num_classes=NC, max_batch=8, max_frame_hw=(H, W), max_crops=512,
+                       max_tracks=1024, nn_budget_cap=60)
+        pipe = CountingPipeline(args, cfg, cam_cfg, engine=eng, class_names=[f"c{i}" for i in range(NC)])
+        src = FrameSource(frames)
+        rows, counts = pipe.run(src, "cam_04", zone) if mode == "loop" else pipe.run_stream(src, "cam_04", zone, batch=8)
+        # track_id / label / frame / direction / first-last frame exact; boxes within 1 px (int truncation of an fp64 state
+        # that only depends on fp32-identical detections); fpoint/lpoint within 0.5
+        assert key(rows) == key(ref_rows), mode
+        for r, q in zip(rows, ref_rows):
+            assert np.abs(np.array(r["box"]) - np.array(q["box"])).max() <= 1, (mode, r, q)
+            assert np.abs(np.array(r["fpoint"]) - np.array(q["fpoint"])).max() <= 0.5
+            assert np.abs(np.array(r["lpoint"]) - np.array(q["lpoint"])).max() <= 0.5
+        assert counts == ref_counts, mode
+        assert os.path.exists(os.path.join(str(tmp_path), "cam_04.csv"))
+        eng.close()

@@ -1,0 +1,134 @@
+"""Zone filter, direction assignment, CSV rows and per-direction counts.
+
+Host-side post-pass, run once per video on the rows the HIP tracker produced; it mirrors the reference's
+functions one to one (names, argument meaning, quirks):
+
+  load_zone_anno               utilities/counting/utils.py:128-137
+  check_bbox_intersect_polygon utilities/counting/bb_polygon.py:96-114 (any bbox corner inside shapes[0], Q12)
+  find_best_match_direction    utilities/counting/utils.py:139-152     (strict '>' from 0, first key fallback, Q11)
+  save_tracking_to_csv         utilities/counting/utils.py:154-198
+  count_frame_directions       utilities/counting/utils.py:276-297     (end state: one count per track)
+"""
+from __future__ import annotations
+
+import csv
+import json
+import math
+
+
+def load_zone_anno(zone_path):
+    with open(zone_path, "r") as f:
+        anno = json.load(f)
+    directions = {}
+    for shape in anno["shapes"]:
+        if shape["label"].startswith("direction"):
+            directions[shape["label"][-2:]] = shape["points"]
+    return anno["shapes"][0]["points"], directions
+
+
+def _orient(p, q, r):
+    v = (q[1] - p[1]) * (r[0] - q[0]) - (q[0] - p[0]) * (r[1] - q[1])
+    if v == 0:
+        return 0
+    return 1 if v > 0 else 2
+
+
+def _on_segment(p, q, r):
+    return (q[0] <= max(p[0], r[0]) and q[0] >= min(p[0], r[0]) and q[1] <= max(p[1], r[1]) and q[1] >= min(p[1], r[1]))
+
+
+def _intersect(p1, q1, p2, q2):
+    o1, o2 = _orient(p1, q1, p2), _orient(p1, q1, q2)
+    o3, o4 = _orient(p2, q2, p1), _orient(p2, q2, q1)
+    if o1 != o2 and o3 != o4:
+        return True
+    if o1 == 0 and _on_segment(p1, p2, q1):
+        return True
+    if o2 == 0 and _on_segment(p1, q2, q1):
+        return True
+    if o3 == 0 and _on_segment(p2, p1, q2):
+        return True
+    return o4 == 0 and _on_segment(p2, q1, q2)
+
+
+def is_point_in_polygon(polygon, point):
+    extreme = (point[0], 1e9)
+    count = 0
+    n = len(polygon)
+    for i in range(n):
+        a, b = polygon[i], polygon[(i + 1) % n]
+        if _intersect(a, b, point, extreme):
+            if _orient(a, point, b) == 0:
+                return _on_segment(a, point, b)
+            count += 1
+    return count % 2 == 1
+
+
+def check_bbox_intersect_polygon(polygon, bbox):
+    x1, y1, x2, y2 = bbox
+    for corner in ((x1, y1), (x2, y1), (x2, y2), (x1, y2)):
+        if is_point_in_polygon(polygon, corner):
+            return True
+    return False
+
+
+def cosin_similarity(a2d, b2d):
+    ax, ay = float(a2d[1][0] - a2d[0][0]), float(a2d[1][1] - a2d[0][1])
+    bx, by = float(b2d[1][0] - b2d[0][0]), float(b2d[1][1] - b2d[0][1])
+    den = math.sqrt(ax * ax + ay * ay) * math.sqrt(bx * bx + by * by)      # np.linalg.norm == sqrt(dot(x, x))
+    num = ax * bx + ay * by
+    if den == 0.0:
+        return float("nan") if num == 0.0 else math.copysign(float("inf"), num)
+    return num / den
+
+
+def find_best_match_direction(obj_vector, paths):
+    keys = list(paths.keys())
+    best_score, best_match = 0, keys[0]
+    for k in keys:
+        score = cosin_similarity(obj_vector, paths[k])
+        if score > best_score:
+            best_score, best_match = score, k
+    return best_match
+
+
+def _centre(box):
+    return ((box[2] + box[0]) / 2, (box[3] + box[1]) / 2)
+
+
+def csv_records(track_dict):
+    """Rows of save_tracking_to_csv (colour omitted: the reference draws it from an unseeded RNG, Q10)."""
+    rows = []
+    for label_id in range(len(track_dict)):
+        for track_id, rec in track_dict[label_id].items():
+            boxes, frames = rec["boxes"], rec["frames"]
+            fpoint, lpoint = _centre(boxes[0]), _centre(boxes[-1])
+            for box, frame in zip(boxes, frames):
+                rows.append({"track_id": int(track_id), "frame_id": int(frame), "box": [int(v) for v in box],
+                             "color": rec.get("color", ""), "label": label_id, "direction": rec["direction"],
+                             "fpoint": (float(fpoint[0]), float(fpoint[1])), "lpoint": (float(lpoint[0]), float(lpoint[1])),
+                             "fframe": int(frames[0]), "lframe": int(frames[-1])})
+    return rows
+
+
+COLUMNS = ["track_id", "frame_id", "box", "color", "label", "direction", "fpoint", "lpoint", "fframe", "lframe"]
+
+
+def save_tracking_to_csv(track_dict, filename):
+    rows = csv_records(track_dict)
+    with open(filename, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(COLUMNS)
+        for r in rows:
+            w.writerow([r["track_id"], r["frame_id"], str(r["box"]), r["color"], r["label"], r["direction"],
+                        str(r["fpoint"]), str(r["lpoint"]), r["fframe"], r["lframe"]])
+    return rows
+
+
+def count_directions(rows, direction_keys, num_classes):
+    """End state of count_frame_directions over all frames: count[direction][label] += 1 at each track's last frame."""
+    counts = {d: [0] * num_classes for d in direction_keys}
+    for r in rows:
+        if r["lframe"] == r["frame_id"]:
+            counts[r["direction"]][r["label"]] += 1
+    return counts

@@ -1,0 +1,76 @@
+"""DeepSort / VideoTracker / VideoCounting: drop-ins for /root/reference/networks/deepsort/deep_sort.py:15-59 and
+/root/reference/modules/track.py:9-137 on top of the HIP engine (same constructor arguments, same return shapes)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .counting import (check_bbox_intersect_polygon, find_best_match_direction, load_zone_anno, save_tracking_to_csv)
+
+
+class DeepSort:
+    """deep_sort.py:15-59.  `model_path` is accepted for signature compatibility; the ReID weights live in the engine."""
+
+    def __init__(self, model_path, max_dist=0.2, min_confidence=0.3, nms_max_overlap=1.0, max_iou_distance=0.7, max_age=70,
+                 n_init=3, nn_budget=100, use_cuda=True, engine=None):
+        if engine is None:
+            raise ValueError("DeepSort needs the HIP engine (there is no CPU path)")
+        self.engine = engine
+        self.tracker_id = engine.tracker_create(max_dist=max_dist, min_confidence=min_confidence, nms_max_overlap=nms_max_overlap,
+                                                max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, nn_budget=nn_budget)
+
+    def update(self, bbox_xyxy, confidences, ori_img):
+        rows = self.engine.deepsort_update(self.tracker_id, bbox_xyxy, confidences, ori_img)
+        return rows if len(rows) > 0 else []          # deep_sort.py:57-59
+
+
+class VideoTracker:
+    """modules/track.py:9-70: one DeepSORT per class; `run` steps only the classes that have boxes in the frame."""
+
+    def __init__(self, num_classes, cam_config, video_info, deepsort_chepoint=None, engine=None):
+        cfg = cam_config["tracking_config"]
+        self.num_classes = num_classes
+        self.video_info = video_info
+        self.num_frames = video_info.get("num_frames") if video_info else None
+        self.engine = engine
+        self.deepsort = [DeepSort(deepsort_chepoint, max_dist=cfg["MAX_DIST"], min_confidence=cfg["MIN_CONFIDENCE"],
+                                  nms_max_overlap=cfg["NMS_MAX_OVERLAP"], max_iou_distance=cfg["MAX_IOU_DISTANCE"],
+                                  max_age=cfg["MAX_AGE"], n_init=cfg["N_INIT"], nn_budget=cfg["NN_BUDGET"], use_cuda=1,
+                                  engine=engine) for _ in range(num_classes)]
+        self.tracker_ids = [d.tracker_id for d in self.deepsort]
+
+    def run(self, image, boxes, labels, scores):
+        rows = self.engine.videotracker_run(self.tracker_ids, image, boxes, labels, scores)
+        return {"tracks": [int(r[4]) for r in rows], "boxes": rows[:, :4].copy() if len(rows) else np.array([]),
+                "labels": [int(r[5]) for r in rows], "scores": []}
+
+    def rows_to_result(self, rows):
+        return {"tracks": [int(r[4]) for r in rows], "boxes": rows[:, :4].copy() if len(rows) else np.array([]),
+                "labels": [int(r[5]) for r in rows], "scores": []}
+
+
+class VideoCounting:
+    """modules/track.py:73-137 (zone filter -> per (label, track) lists -> direction -> CSV)."""
+
+    def __init__(self, class_names, zone_path, minimum_length=4):
+        self.class_names = class_names
+        self.num_classes = len(class_names)
+        self.track_dict = [{} for _ in range(self.num_classes)]
+        self.minimum_length = minimum_length            # stored and never used by the reference either (Q15)
+        self.zone_path = zone_path
+        self.polygons, self.directions = load_zone_anno(zone_path)
+
+    def run(self, frames, tracks, labels, boxes, output_path=None):
+        for frame_id, track_id, label_id, box in zip(frames, tracks, labels, boxes):
+            if check_bbox_intersect_polygon(self.polygons, box):
+                rec = self.track_dict[label_id].setdefault(track_id, {"boxes": [], "frames": [], "color": ""})
+                rec["boxes"].append(box)
+                rec["frames"].append(frame_id)
+        for label_id in range(self.num_classes):
+            for rec in self.track_dict[label_id].values():
+                fb, lb = rec["boxes"][0], rec["boxes"][-1]
+                first = ((fb[2] + fb[0]) / 2, (fb[3] + fb[1]) / 2)
+                last = ((lb[2] + lb[0]) / 2, (lb[3] + lb[1]) / 2)
+                rec["direction"] = find_best_match_direction((first, last), self.directions)
+        if output_path is not None:
+            save_tracking_to_csv(self.track_dict, output_path)
+        return self.track_dict
