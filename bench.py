@@ -1,0 +1,152 @@
+"""bench.py -- end-to-end frames/s of the detect + NMS + ReID + track hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of B = 16 synthetic 640x640 frames of ONE camera stream per GPU
+(BASELINE.json configs[1]: YOLOv5s 640x640, bf16 convs): letterbox -> YOLOv5s conv stack -> decode -> NMS -> crops ->
+ReID CNN -> per-class DeepSORT step, frames already resident in HBM.  Each rank owns its own camera stream (weak
+scaling); the only collective is the all-gather of the per-camera count tensors at the end.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from vehicle_counting_amd import _lib as L  # noqa: E402
+from vehicle_counting_amd import parallel  # noqa: E402
+from vehicle_counting_amd.counting import count_directions, csv_records  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.track import VideoCounting  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+
+B = 16                 # frames per step
+H = W = 640
+NC = 80
+N_OBJ = 12
+CLIP = 128             # distinct synthetic frames per stream (cycled)
+TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
+
+
+def cpu_baseline(ysd, rsd, frames, n_frames):
+    """The oracle (CPU port of the reference path) timed on this box's host cores over a bounded sample."""
+    from oracle import pipeline as op
+    cfg = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    op.run_video(frames[:1], ysd, rsd, cfg, ZONE, nc=NC)            # warm the CPU kernels
+    t0 = time.perf_counter()
+    _, _, nd = op.run_video(frames[:n_frames], ysd, rsd, cfg, ZONE, nc=NC)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {n_frames} frames of the rank-0 stream through oracle/pipeline.py (torch-CPU fp32 YOLOv5s + ReID, "
+                      f"NumPy/SciPy DeepSORT), {int(np.mean(nd))} det/frame, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_from_env("nccl" if args.gpus > 1 else None)
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    ysd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=1.0)
+    rsd = synth_reid(1702)
+    eng = E.Engine(ysd, rsd, device=local, precision="bf16", model_name="yolov5s", num_classes=NC, max_batch=B,
+                   max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
+    trackers = [eng.tracker_create(**TRACK) for _ in range(NC)]
+    frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank)          # one camera stream per rank
+    d_frames = torch.from_numpy(frames).to(dev)                                 # resident in HBM before the timed region
+    obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
+    ndet_total = [0, 0]
+
+    def step(i, record):
+        f0 = (i * B) % CLIP
+        rows, nd = eng.stream_run(trackers, d_frames[f0:f0 + B].data_ptr(), B, H, W)
+        if record:
+            ndet_total[0] += int(nd.sum()); ndet_total[1] += B
+            for k, r in enumerate(rows):
+                for row in r:
+                    obj["frames"].append(i * B + k + 1); obj["tracks"].append(int(row[4]))
+                    obj["labels"].append(int(row[5])); obj["boxes"].append(row[:4].copy())
+
+    def sync_all():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        step(i, False)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    # end of run: per-camera counts (VideoCounting) merged with the one collective of the design
+    counter = VideoCounting([str(c) for c in range(NC)], ZONE)
+    td = counter.run(obj["frames"], obj["tracks"], obj["labels"], obj["boxes"])
+    rows = csv_records(td)
+    dirs = list(counter.directions.keys())
+    local_counts = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)[None]
+    all_counts = parallel.allgather_counts(local_counts, device=dev if world > 1 else None)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel (implicit-GEMM conv): HIP events around every conv launch on the engine's own
+    # stream, over extra instrumented steps (event bracketing perturbs the pipeline, so it is kept out of the timed steps)
+    eng.profile(True); eng.profile_reset()
+    for i in range(2):
+        step(args.warmup + args.steps + i, False)
+    eng.sync()
+    conv = eng.profile_read(L.PROF_CONV)
+    cats = {n: eng.profile_read(c) for n, c in (("conv", L.PROF_CONV), ("detect_aux", L.PROF_DETECT_AUX),
+                                                ("reid_aux", L.PROF_REID_AUX), ("track", L.PROF_TRACK))}
+    eng.profile(False)
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "end-to-end frames/sec (detect+NMS+ReID+track), YOLOv5s 640px",
+            "value": world * args.steps * B / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])",
+                       "frames_per_step": B, "frame_hw": [H, W], "num_classes": NC, "det_per_frame": ndet_total[0] / max(ndet_total[1], 1),
+                       "weights": "seeded synthetic (no checkpoints available)", "streams": world,
+                       "counts_allgather_shape": list(all_counts.shape)},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "vc::conv_igemm_kernel<*> (all YOLOv5s + ReID conv launches of a step)",
+                         "launches_per_step": conv["launches"] / 2, "avg_launch_us": conv["ms"] * 1e3 / max(conv["launches"], 1),
+                         "algorithmic_gflop_per_step": conv["flops"] / 2 / 1e9},
+            "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ysd, rsd, frames, args.cpu_frames)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
