@@ -149,6 +149,7 @@ int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int*
 int vc_profile_enable(vc_engine* e, int on);   /* brackets every launch with hipEvents on its own stream; disables graphs */
 int vc_profile_read(vc_engine* e, int category, double* total_ms, int64_t* launches, double* flops, double* bytes);
 int vc_profile_reset(vc_engine* e);
+int vc_profile_ops(vc_engine* e, char* buf, size_t cap);   /* per-conv-launch lines "conv M= N= K= ... ms= tflops=" recorded while profiling */
 int vc_engine_sync(vc_engine* e);
 
 /* ---- single-function entry points (parity tests; each runs the device kernel on host arrays) ------- */

@@ -1,0 +1,108 @@
+"""CPU: host-side product logic (counting / CSV, marshal, weight folding, plan tables) against the golden vectors."""
+import io
+import json
+import os
+import types
+
+import numpy as np
+
+from oracle import yolov5 as oy
+from vehicle_counting_amd import counting as pc
+from vehicle_counting_amd.detect import ImageDetect
+from vehicle_counting_amd.synth import synth_frames, synth_tracks
+from vehicle_counting_amd.weights import fold_bn, fold_reid, synth_reid, synth_yolo, yolo_conv_table
+
+
+def test_counting_against_reference_golden(golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "counting.json")))
+    poly, dirs = pc.load_zone_anno(os.path.join(golden_dir, "cam_04.json"))
+    assert poly == g["zone"] and dirs == g["directions"]
+    for rec in g["boxes"]:
+        assert pc.check_bbox_intersect_polygon(poly, rec["box"]) == rec["inside"]
+    sq = [[0, 0], [10, 0], [10, 10], [0, 10]]
+    for rec in g["points"]:
+        assert pc.is_point_in_polygon(poly if rec["poly"] == "zone" else sq, rec["pt"]) == rec["inside"], rec
+    for rec in g["vectors"][:-1]:
+        assert pc.find_best_match_direction(rec["vec"], g["two_dirs"]) == rec["best"]
+    assert pc.find_best_match_direction(g["vectors"][-1]["vec"], {"01": dirs["01"]}) == g["vectors"][-1]["best"]
+    td = [dict() for _ in range(3)]
+    for r in g["csv_tracks"]:
+        boxes = [np.array(b) for b in r["boxes"]]
+        fb, lb = boxes[0], boxes[-1]
+        vec = (((fb[2] + fb[0]) / 2, (fb[3] + fb[1]) / 2), ((lb[2] + lb[0]) / 2, (lb[3] + lb[1]) / 2))
+        td[r["label"]][r["track"]] = {"boxes": boxes, "frames": r["frames"], "color": "x",
+                                      "direction": pc.find_best_match_direction(vec, g["two_dirs"])}
+    out = os.path.join(str(tmp_path), "t.csv")
+    rows = pc.save_tracking_to_csv(td, out)
+    import pandas as pd
+    got = pd.read_csv(out, dtype={"direction": str})
+    ref = pd.read_csv(io.StringIO(g["csv_text"]), dtype={"direction": str})
+    assert list(got.columns) == list(ref.columns)
+    for col in ("track_id", "frame_id", "box", "label", "direction", "fframe", "lframe"):
+        assert got[col].tolist() == ref[col].tolist(), col
+    # fpoint / lpoint: the reference's text is numpy-repr dependent ("(np.float64(133.0), ...)" under NumPy 2); compare values
+    import re
+    for col in ("fpoint", "lpoint"):
+        for a, b in zip(got[col], ref[col]):
+            assert [float(v) for v in re.findall(r"-?\d+\.\d+", a)] == [float(v) for v in re.findall(r"-?\d+\.\d+", b)][-2:] or \
+                   [float(v) for v in re.findall(r"-?\d+\.?\d*", a)] == [float(v) for v in re.findall(r"\((?:np\.float64\()?(-?\d+\.?\d*)", b)] + \
+                   [float(v) for v in re.findall(r", (?:np\.float64\()?(-?\d+\.?\d*)", b)]
+    assert pc.count_directions(rows, list(g["two_dirs"].keys()), 3) == g["counts"]
+
+
+def test_marshal_matches_oracle_and_empty_contract():
+    det = np.array([[10.123456789, 20.5, 110.25, 220.125, 0.87654321, 3.0]], np.float32)
+    a, b = ImageDetect._marshal(det), oy.marshal_like_reference(det)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    e = ImageDetect._marshal(np.zeros((0, 6), np.float32))
+    assert len(e["bboxes"]) == 0 and e["bboxes"].shape == (0,)          # networks/yolo.py:91-96 -> `len(boxes) == 0` upstream
+
+
+def test_conv_tables_agree_and_match_published_size():
+    a = {(n, ci, co, k) for n, ci, co, k in yolo_conv_table("yolov5s", 80)}
+    b = {(n, ci, co, k) for n, ci, co, k, s, p, act in oy.conv_specs("yolov5s", 80)}
+    assert a == b and len(a) == 60
+    params = sum(ci * co * k * k + co for n, ci, co, k in a)
+    assert abs(params - 7.2259e6) < 1e4                                  # upstream: 7.2 M parameters
+    assert len(yolo_conv_table("yolov5m", 80)) == 82 and len(yolo_conv_table("yolov5l", 80)) == 104
+    # analytic GFLOPs at 640x640: 16.43 for yolov5s
+    fl = 0
+    hw = {0: 320}
+    import re
+    stride = {"0": 2, "1": 4, "2": 4, "3": 8, "4": 8, "5": 16, "6": 16, "7": 32, "8": 32, "9": 32, "10": 32, "13": 16, "14": 16, "17": 8,
+              "18": 16, "20": 16, "21": 32, "23": 32}
+    for n, ci, co, k in yolo_conv_table("yolov5s", 80):
+        idx = n.split(".")[1]
+        if idx == "24":
+            s = (8, 16, 32)[int(n.rsplit(".", 1)[1])]
+        else:
+            s = stride[idx]
+        fl += 2 * (640 // s) ** 2 * ci * co * k * k
+    assert abs(fl / 1e9 - 16.43) < 0.2, fl / 1e9
+
+
+def test_fold_bn_equals_conv_then_bn():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((8, 4, 3, 3)).astype(np.float32)
+    g, b, m, v = rng.uniform(0.5, 1.5, 8), rng.standard_normal(8), rng.standard_normal(8), rng.uniform(0.5, 1.5, 8)
+    x = torch.from_numpy(rng.standard_normal((2, 4, 9, 9)).astype(np.float32))
+    ref = F.batch_norm(F.conv2d(x, torch.from_numpy(w), None, padding=1), torch.tensor(m, dtype=torch.float32), torch.tensor(v, dtype=torch.float32),
+                       torch.tensor(g, dtype=torch.float32), torch.tensor(b, dtype=torch.float32), False, 0.0, 1e-3)
+    fw, fb = fold_bn(w, None, g.astype(np.float32), b.astype(np.float32), m.astype(np.float32), v.astype(np.float32), 1e-3)
+    got = F.conv2d(x, torch.from_numpy(fw), torch.from_numpy(fb), padding=1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    f = fold_reid(synth_reid(1))
+    assert set(f) >= {"conv", "layer2.0.downsample", "layer4.1.conv2"} and f["layer2.0.downsample"][0].shape == (128, 64, 1, 1)
+
+
+def test_synthetic_inputs_are_deterministic():
+    a, b = synth_frames(2, 90, 160, 3, 5), synth_frames(2, 90, 160, 3, 5)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.uint8 and a.shape == (2, 90, 160, 3)
+    t = synth_tracks(2, 90, 160, 3, 5)
+    assert t[0][0].shape == (3, 4) and t[0][1].dtype == np.int64
+    s1, s2 = synth_yolo("yolov5s", 8, 3), synth_yolo("yolov5s", 8, 3)
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)

@@ -1,0 +1,20 @@
+"""Per-conv-launch timing of one bench step (profiling mode: hipEvents around every launch on the engine stream)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.synth import synth_frames
+from vehicle_counting_amd.weights import synth_reid, synth_yolo
+B, H, W, NC = 16, 640, 640, 80
+eng = E.Engine(synth_yolo("yolov5s", nc=NC, det_scale=4.0, obj_shift=1.0), synth_reid(), precision="bf16", num_classes=NC, max_batch=B,
+               max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
+tr = [eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60) for _ in range(NC)]
+fr = torch.from_numpy(synth_frames(B, H, W, 12, 1702)).cuda()
+for _ in range(3): eng.stream_run(tr, fr.data_ptr(), B, H, W)
+eng.profile(True); eng.profile_reset()
+eng.stream_run(tr, fr.data_ptr(), B, H, W)
+lines = eng.profile_ops().strip().split("\n")
+tot = 0
+for l in lines:
+    print(l); tot += float(l.split("ms=")[1].split()[0])
+print("total conv ms", tot, "launches", len(lines))

@@ -77,6 +77,7 @@ SIGNATURES = {
     "vc_profile_enable": [_vp, _i],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
     "vc_profile_reset": [_vp],
+    "vc_profile_ops": [_vp, C.c_char_p, C.c_size_t],
     "vc_conv2d_host": [_P(ConvDesc), _pf, _pf, _pf, _pf, _pf],
     "vc_kalman_initiate_host": [_pd, _i, _pd, _pd],
     "vc_kalman_predict_host": [_pd, _pd, _i],

@@ -99,14 +99,10 @@ struct vc_engine {
     vc::TrackPool pool{};
     std::vector<int> free_slots;
     std::vector<std::unique_ptr<vc::Tracker>> trackers;
-    // per-step scratch (pinned host + device mirrors)
-    int* h_slots = nullptr; int* d_slots = nullptr;
-    double* h_xyah = nullptr; double* d_xyah = nullptr;
-    double* h_tlwh = nullptr; double* d_tlwh = nullptr;
-    vc::CostJob* h_jobs = nullptr; vc::CostJob* d_jobs = nullptr;
+    // per-step scratch: one pinned staging block mirrored on the device, cost matrices, posterior means
+    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0;
     double* h_cost = nullptr; double* d_cost = nullptr;
-    int* h_sps = nullptr; int* d_sps = nullptr;
-    double* h_mean = nullptr;
+    double* h_mean = nullptr; double* d_mean_out = nullptr;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
     size_t cost_cap = 0;
     int det_cap = 0;
@@ -115,6 +111,8 @@ struct vc_engine {
     bool profiling = false;
     vc::ProfCat prof[VC_PROF_NCAT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string op_log;                          // per-launch lines "name M N K tile ms" while profiling
+    double last_ms = 0;
 
     // ---- stream injection -----------------------------------------------------------------------------
     std::vector<float> inject_det;
@@ -138,7 +136,8 @@ struct ProfScope {
 int tracker_init_pool(vc_engine* e);
 // detections of one tracker for one step; feature of det i = d_feat row (feat_rows ? feat_rows[i] : feat_off + i)
 struct DetIn { const double* tlwh; const double* conf; int k; const int* feat_rows; int feat_off; };
-int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat);
+int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat,
+                       std::vector<int>* mean_offsets);
 int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
                 const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
                 int n, const float* d_feat_ready, int feat_row0, std::vector<int64_t>& rows6);

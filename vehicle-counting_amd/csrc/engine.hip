@@ -48,6 +48,7 @@ ProfScope::~ProfScope() {
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     ProfCat& c = e->prof[cat];
     c.ms += ms; c.flops += flops; c.bytes += bytes; c.launches += 1;
+    e->last_ms = ms;
 }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -321,8 +322,17 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat) {
                 const double es = elem_size(op.conv.prec);
                 const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
-                ProfScope ps(e, VC_PROF_CONV, fl, by);
-                VC_TRY(launch_conv(op.conv, e->stream));
+                {
+                    ProfScope ps(e, VC_PROF_CONV, fl, by);
+                    VC_TRY(launch_conv(op.conv, e->stream));
+                }
+                if (e->profiling && e->op_log.size() < (1u << 20)) {
+                    char line[256];
+                    const ConvP& c = op.conv;
+                    snprintf(line, sizeof(line), "%s M=%d N=%d K=%d k=%dx%d s=%d ms=%.4f tflops=%.1f\n", c.M > 0 ? "conv" : "?", c.M, c.Cout, c.K,
+                             c.kh, c.kw, c.sh, e->last_ms, fl / (e->last_ms * 1e-3) / 1e12);
+                    e->op_log += line;
+                }
                 break;
             }
             case Op::SPPF: { ProfScope ps(e, aux_cat); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, e->stream)); break; }
@@ -732,6 +742,12 @@ int vc_profile_enable(vc_engine* e, int on) { VC_CHECK(e, VC_ERR_ARG, "null engi
 int vc_profile_reset(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     for (auto& c : e->prof) c = ProfCat{};
+    e->op_log.clear();
+    return VC_OK;
+}
+int vc_profile_ops(vc_engine* e, char* buf, size_t cap) {
+    VC_CHECK(e && buf && cap > 0, VC_ERR_ARG, "bad argument");
+    snprintf(buf, cap, "%s", e->op_log.c_str());
     return VC_OK;
 }
 int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double* flops, double* bytes) {

@@ -98,6 +98,8 @@ int launch_gating_values(const TrackPool& tp, int slot, const double* z, int n, 
 int launch_iou_boxes(const double* a, int t, const double* b, int d, double* out, hipStream_t s);
 //   out[out_off + i] = tsu > 1 ? 1e5 : 1 - IoU(track tlwh, det tlwh)
 int launch_iou_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const double* det_tlwh, double* out, hipStream_t s);
+// out[i][0:8] = mean[slots[i]]
+int launch_gather_means(const TrackPool& tp, const int* slots, int n, double* out, hipStream_t s);
 // gallery append: copy feat[src[i]] into gallery[slot[i]][pos[i]]
 int launch_gallery_write(TrackPool& tp, const int* slot_pos_src /* n x 3 */, int n, const float* feat, hipStream_t s);
 

@@ -268,6 +268,16 @@ int launch_iou_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const d
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
+__global__ __launch_bounds__(256) void gather_means_kernel(TrackPool tp, const int* __restrict__ slots, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * 8) out[i] = tp.mean[(size_t)slots[i >> 3] * 8 + (i & 7)];
+}
+int launch_gather_means(const TrackPool& tp, const int* slots, int n, double* out, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(gather_means_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, s, tp, slots, n, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
 int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {
     if (n <= 0) return VC_OK;
     hipLaunchKernelGGL(gallery_write_kernel, dim3(n), dim3(128), 0, s, tp, slot_pos_src, feat);

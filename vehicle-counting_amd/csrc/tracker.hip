@@ -140,6 +140,8 @@ void dsort_nms(const double* tlwh, const double* scores, int n, double max_overl
 }
 
 // ------------------------------------------------------------------------------------------------ pool
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
 int tracker_init_pool(vc_engine* e) {
     const size_t T = e->cfg.max_tracks, S = e->cfg.nn_budget_cap;
     VC_CHECK(T >= 1 && S >= 1, VC_ERR_ARG, "max_tracks and nn_budget_cap must be positive");
@@ -152,13 +154,15 @@ int tracker_init_pool(vc_engine* e) {
     e->det_cap = std::max(e->cfg.max_det * 2, 1024);
     e->cost_cap = (size_t)2 * T * 512;
     const size_t D = e->det_cap;
-    VC_TRY(host_alloc(e, (void**)&e->h_slots, (2 * T + D) * sizeof(int)));       VC_TRY(dev_alloc(e, (void**)&e->d_slots, (2 * T + D) * sizeof(int)));
-    VC_TRY(host_alloc(e, (void**)&e->h_xyah, (T + D) * 4 * sizeof(double)));      VC_TRY(dev_alloc(e, (void**)&e->d_xyah, (T + D) * 4 * sizeof(double)));
-    VC_TRY(host_alloc(e, (void**)&e->h_tlwh, D * 4 * sizeof(double)));            VC_TRY(dev_alloc(e, (void**)&e->d_tlwh, D * 4 * sizeof(double)));
-    VC_TRY(host_alloc(e, (void**)&e->h_jobs, 2 * T * sizeof(CostJob)));           VC_TRY(dev_alloc(e, (void**)&e->d_jobs, 2 * T * sizeof(CostJob)));
-    VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));      VC_TRY(dev_alloc(e, (void**)&e->d_cost, e->cost_cap * sizeof(double)));
-    VC_TRY(host_alloc(e, (void**)&e->h_sps, (T + D) * 3 * sizeof(int)));          VC_TRY(dev_alloc(e, (void**)&e->d_sps, (T + D) * 3 * sizeof(int)));
+    // one pinned staging block per phase, mirrored on the device: a phase costs ONE host->device copy
+    e->stage_cap = align16((T + D) * 4) + 2 * align16(D * 32) + align16(2 * T * sizeof(CostJob)) +      // phase A
+                   2 * align16(T * 4) + 2 * align16((T + D) * 32) + align16((T + D) * 12) + 256;          // phase B (superset)
+    VC_TRY(host_alloc(e, (void**)&e->h_stage, e->stage_cap));
+    VC_TRY(dev_alloc(e, (void**)&e->d_stage, e->stage_cap));
+    VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_cost, e->cost_cap * sizeof(double)));
     VC_TRY(host_alloc(e, (void**)&e->h_mean, T * 8 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_mean_out, T * 8 * sizeof(double)));
     VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, D * VC_FEAT_DIM * sizeof(float)));
     return VC_OK;
 }
@@ -167,30 +171,54 @@ static void tlwh_to_xyah(const double* t, double* o) {      // sort/detection.py
     o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
 }
 
+// bump allocator over the pinned staging block; device addresses mirror host offsets
+struct Stage {
+    char* h; char* d; size_t cap, off = 0;
+    template <class T> T* take(size_t n, T** dev) {
+        T* p = (T*)(h + off);
+        *dev = (T*)(d + off);
+        off = align16(off + n * sizeof(T));
+        return p;
+    }
+};
+
 // Steps `njobs` trackers (Tracker.predict(); Tracker.update(dets)) with one batched device pass each for
-// {predict, cost} and {update, initiate, gallery}.  dets[j].feat_rows index rows of d_feat.
-int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat) {
+// {predict, cost} and {update, initiate, gallery, mean gather}; each phase is one H2D copy, a few launches and one
+// D2H copy.  dets[j].feat_rows index rows of d_feat.  On return (stream-ordered, NOT synchronised) e->h_mean will hold
+// the posterior means of every live track of the stepped trackers in (job, list) order; mean_offsets[j] = first row.
+int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat,
+                       std::vector<int>* mean_offsets) {
     hipStream_t s = e->stream;
     // ---------------- phase A: predict + cost matrices
     int n_tracks = 0, n_dets = 0;
     std::vector<int> det_base(njobs);
     for (int j = 0; j < njobs; ++j) {
         VC_CHECK(tracker_ids[j] >= 0 && tracker_ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
-        Tracker& tk = *e->trackers[tracker_ids[j]];
-        for (TrackRec& t : tk.tracks) { e->h_slots[n_tracks++] = t.slot; t.age += 1; t.tsu += 1; }     // sort/track.py:112-124
+        n_tracks += (int)e->trackers[tracker_ids[j]]->tracks.size();
         det_base[j] = n_dets;
         n_dets += dets[j].k;
     }
     VC_CHECK(n_dets <= e->det_cap, VC_ERR_CAPACITY, "%d detections in one step exceed capacity %d", n_dets, e->det_cap);
-    int* h_featrow = e->h_slots + n_tracks;                 // det -> feature row, stored after the slot list
+    Stage st{e->h_stage, e->d_stage, e->stage_cap};
+    int *d_slots, *d_featrow; double *d_xyah, *d_tlwh; CostJob* d_jobs;
+    int* h_slots = st.take<int>(n_tracks, &d_slots);
+    int* h_featrow = st.take<int>(n_dets, &d_featrow);
+    double* h_xyah = st.take<double>((size_t)n_dets * 4, &d_xyah);
+    double* h_tlwh = st.take<double>((size_t)n_dets * 4, &d_tlwh);
+    CostJob* h_jobs = st.take<CostJob>((size_t)2 * n_tracks, &d_jobs);
+    {
+        int q = 0;
+        for (int j = 0; j < njobs; ++j)
+            for (TrackRec& t : e->trackers[tracker_ids[j]]->tracks) { h_slots[q++] = t.slot; t.age += 1; t.tsu += 1; }   // sort/track.py:112-124
+    }
     for (int j = 0; j < njobs; ++j)
         for (int i = 0; i < dets[j].k; ++i) {
             const int g = det_base[j] + i;
-            memcpy(e->h_tlwh + (size_t)g * 4, dets[j].tlwh + (size_t)i * 4, 4 * sizeof(double));
-            tlwh_to_xyah(dets[j].tlwh + (size_t)i * 4, e->h_xyah + (size_t)g * 4);
+            memcpy(h_tlwh + (size_t)g * 4, dets[j].tlwh + (size_t)i * 4, 4 * sizeof(double));
+            tlwh_to_xyah(dets[j].tlwh + (size_t)i * 4, h_xyah + (size_t)g * 4);
             h_featrow[g] = dets[j].feat_rows ? dets[j].feat_rows[i] : dets[j].feat_off + i;
         }
-    // cost jobs: appearance rows for confirmed tracks, IoU rows for every track, each over all of its tracker's dets
+    // cost jobs: appearance rows for confirmed tracks, IoU rows for every possible IoU candidate, each over all of its tracker's dets
     int n_app = 0, n_iou = 0;
     size_t out = 0;
     std::vector<std::vector<int>> app_job(njobs), iou_job(njobs);
@@ -201,8 +229,7 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         for (size_t t = 0; t < tk.tracks.size(); ++t) {
             const TrackRec& tr = tk.tracks[t];
             if (tr.state != CONFIRMED) continue;
-            CostJob& cj = e->h_jobs[n_app];
-            cj.slot = tr.slot; cj.gal_count = tr.gal_count; cj.det_off = det_base[j]; cj.det_n = dets[j].k; cj.out_off = (int)out; cj.tsu = tr.tsu;
+            h_jobs[n_app] = CostJob{tr.slot, tr.gal_count, det_base[j], dets[j].k, (int)out, tr.tsu};
             app_job[j][t] = n_app++;
             out += dets[j].k;
         }
@@ -214,35 +241,30 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         for (size_t t = 0; t < tk.tracks.size(); ++t) {
             const TrackRec& tr = tk.tracks[t];
             if (tr.state == CONFIRMED && tr.tsu != 1) continue;       // never an IoU candidate (sort/tracker.py:118-120)
-            CostJob& cj = e->h_jobs[n_app + n_iou];
-            cj.slot = tr.slot; cj.gal_count = 0; cj.det_off = det_base[j]; cj.det_n = dets[j].k; cj.out_off = (int)out; cj.tsu = tr.tsu;
+            h_jobs[n_app + n_iou] = CostJob{tr.slot, 0, det_base[j], dets[j].k, (int)out, tr.tsu};
             iou_job[j][t] = n_app + n_iou++;
             out += dets[j].k;
         }
     }
     VC_CHECK(out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", out, e->cost_cap);
-    if (n_tracks + n_dets > 0) VC_HIP(hipMemcpyAsync(e->d_slots, e->h_slots, (size_t)(n_tracks + n_dets) * sizeof(int), hipMemcpyHostToDevice, s));
-    if (n_dets > 0) {
-        VC_HIP(hipMemcpyAsync(e->d_xyah, e->h_xyah, (size_t)n_dets * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-        VC_HIP(hipMemcpyAsync(e->d_tlwh, e->h_tlwh, (size_t)n_dets * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (st.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage, e->h_stage, st.off, hipMemcpyHostToDevice, s));
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_predict(e->pool, d_slots, n_tracks, s)); }
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_appearance_cost(e->pool, d_jobs, n_app, d_feat, d_featrow, d_xyah, e->d_cost, s)); }
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, d_jobs + n_app, n_iou, d_tlwh, e->d_cost, s)); }
+    if (out > 0) {
+        VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, out * sizeof(double), hipMemcpyDeviceToHost, s));
+        VC_HIP(hipStreamSynchronize(s));
     }
-    if (n_app + n_iou > 0) VC_HIP(hipMemcpyAsync(e->d_jobs, e->h_jobs, (size_t)(n_app + n_iou) * sizeof(CostJob), hipMemcpyHostToDevice, s));
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_predict(e->pool, e->d_slots, n_tracks, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK);
-      VC_TRY(launch_appearance_cost(e->pool, e->d_jobs, n_app, d_feat, e->d_slots + n_tracks, e->d_xyah, e->d_cost, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, e->d_jobs + n_app, n_iou, e->d_tlwh, e->d_cost, s)); }
-    if (out > 0) VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, out * sizeof(double), hipMemcpyDeviceToHost, s));
-    VC_HIP(hipStreamSynchronize(s));
 
     // ---------------- phase B: association + lifecycle (host), then the batched Kalman update
-    int n_upd = 0, n_new = 0, n_gal = 0;
-    // list layouts in the pinned scratch: update slots at [0, T), initiate slots at [T, 2T); xyah likewise
-    const int T = e->pool.max_tracks;
-    int* upd_slots = e->h_slots; int* new_slots = e->h_slots + T;
-    double* upd_xyah = e->h_xyah; double* new_xyah = e->h_xyah + (size_t)T * 4;
-    std::vector<double> det_xyah((size_t)n_dets * 4);
-    memcpy(det_xyah.data(), e->h_xyah, det_xyah.size() * sizeof(double));       // h_xyah is reused for the lists below
+    // the phase-A block is consumed (the stream was synchronised or nothing depended on it): keep what is still needed
+    std::vector<double> det_xyah(h_xyah, h_xyah + (size_t)n_dets * 4);
     std::vector<int> featrow(h_featrow, h_featrow + n_dets);
+    std::vector<int> job_out(h_jobs ? n_app + n_iou : 0);
+    for (int i = 0; i < n_app + n_iou; ++i) job_out[i] = h_jobs[i].out_off;
+    if (out == 0 && st.off > 0) VC_HIP(hipStreamSynchronize(s));     // the staging block is about to be rewritten
+    std::vector<int> upd_slots, new_slots, sps;
+    std::vector<double> upd_xyah, new_xyah;
     for (int j = 0; j < njobs; ++j) {
         Tracker& tk = *e->trackers[tracker_ids[j]];
         const int k = dets[j].k;
@@ -261,7 +283,7 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
             for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
             if (lvl.empty()) continue;
             std::vector<const double*> rp;
-            for (int t : lvl) rp.push_back(e->h_cost + e->h_jobs[app_job[j][t]].out_off);
+            for (int t : lvl) rp.push_back(e->h_cost + job_out[app_job[j][t]]);
             VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
             for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
             left = mo.un_cols;
@@ -273,7 +295,7 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
         {
             std::vector<const double*> rp;
-            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + e->h_jobs[iou_job[j][t]].out_off);
+            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + job_out[iou_job[j][t]]);
             else rp.assign(cand.size(), nullptr);
             VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
         }
@@ -285,12 +307,9 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         for (auto& m : matches) {
             TrackRec& tr = tk.tracks[m.first];
             const int g = det_base[j] + m.second;
-            VC_CHECK(n_upd < T, VC_ERR_CAPACITY, "too many track updates");
-            upd_slots[n_upd] = tr.slot;
-            memcpy(upd_xyah + (size_t)n_upd * 4, &det_xyah[(size_t)g * 4], 4 * sizeof(double));
-            ++n_upd;
-            const int pos = tr.gal_head;
-            e->h_sps[n_gal * 3] = tr.slot; e->h_sps[n_gal * 3 + 1] = pos; e->h_sps[n_gal * 3 + 2] = featrow[g]; ++n_gal;
+            upd_slots.push_back(tr.slot);
+            upd_xyah.insert(upd_xyah.end(), &det_xyah[(size_t)g * 4], &det_xyah[(size_t)g * 4] + 4);
+            sps.push_back(tr.slot); sps.push_back(tr.gal_head); sps.push_back(featrow[g]);
             tr.gal_head = (tr.gal_head + 1) % tk.p.nn_budget;
             tr.gal_count = std::min(tr.gal_count + 1, tk.p.nn_budget);
             tr.last_conf = dets[j].conf[m.second];
@@ -306,15 +325,13 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         // _initiate_track, sort/tracker.py:133-139
         for (int d : un_dets) {
             VC_CHECK(!e->free_slots.empty(), VC_ERR_CAPACITY, "track pool exhausted (max_tracks = %d)", e->cfg.max_tracks);
-            VC_CHECK(n_new < T, VC_ERR_CAPACITY, "too many new tracks");
             TrackRec tr{};
             tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
             tr.slot = e->free_slots.back(); e->free_slots.pop_back();
             const int g = det_base[j] + d;
-            new_slots[n_new] = tr.slot;
-            memcpy(new_xyah + (size_t)n_new * 4, &det_xyah[(size_t)g * 4], 4 * sizeof(double));
-            ++n_new;
-            e->h_sps[n_gal * 3] = tr.slot; e->h_sps[n_gal * 3 + 1] = 0; e->h_sps[n_gal * 3 + 2] = featrow[g]; ++n_gal;
+            new_slots.push_back(tr.slot);
+            new_xyah.insert(new_xyah.end(), &det_xyah[(size_t)g * 4], &det_xyah[(size_t)g * 4] + 4);
+            sps.push_back(tr.slot); sps.push_back(0); sps.push_back(featrow[g]);
             tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
             tr.last_conf = dets[j].conf[d];
             tk.tracks.push_back(tr);
@@ -327,38 +344,39 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         }
         tk.tracks.swap(alive);
     }
-    if (n_upd > 0) {
-        VC_HIP(hipMemcpyAsync(e->d_slots, upd_slots, (size_t)n_upd * sizeof(int), hipMemcpyHostToDevice, s));
-        VC_HIP(hipMemcpyAsync(e->d_xyah, upd_xyah, (size_t)n_upd * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-        ProfScope ps(e, VC_PROF_TRACK);
-        VC_TRY(launch_kalman_update(e->pool, e->d_slots, e->d_xyah, n_upd, s));
+    // one staging block again: update list, initiate list, gallery writes, slots whose means the caller wants back
+    Stage sb{e->h_stage, e->d_stage, e->stage_cap};
+    const int n_upd = (int)upd_slots.size(), n_new = (int)new_slots.size(), n_gal = (int)sps.size() / 3;
+    int n_out = 0;
+    if (mean_offsets) {
+        mean_offsets->assign(njobs + 1, 0);
+        for (int j = 0; j < njobs; ++j) { (*mean_offsets)[j] = n_out; n_out += (int)e->trackers[tracker_ids[j]]->tracks.size(); }
+        (*mean_offsets)[njobs] = n_out;
     }
-    if (n_new > 0) {
-        VC_HIP(hipMemcpyAsync(e->d_slots + T, new_slots, (size_t)n_new * sizeof(int), hipMemcpyHostToDevice, s));
-        VC_HIP(hipMemcpyAsync(e->d_xyah + (size_t)T * 4, new_xyah, (size_t)n_new * 4 * sizeof(double), hipMemcpyHostToDevice, s));
-        ProfScope ps(e, VC_PROF_TRACK);
-        VC_TRY(launch_kalman_initiate(e->pool, e->d_slots + T, e->d_xyah + (size_t)T * 4, n_new, s));
+    int *d_upd, *d_new, *d_sps, *d_outs; double *d_uz, *d_nz;
+    int* h_upd = sb.take<int>(n_upd, &d_upd);
+    int* h_new = sb.take<int>(n_new, &d_new);
+    double* h_uz = sb.take<double>((size_t)n_upd * 4, &d_uz);
+    double* h_nz = sb.take<double>((size_t)n_new * 4, &d_nz);
+    int* h_sp = sb.take<int>((size_t)n_gal * 3, &d_sps);
+    int* h_outs = sb.take<int>(n_out, &d_outs);
+    VC_CHECK(sb.off <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
+    if (n_upd) { memcpy(h_upd, upd_slots.data(), n_upd * sizeof(int)); memcpy(h_uz, upd_xyah.data(), (size_t)n_upd * 32); }
+    if (n_new) { memcpy(h_new, new_slots.data(), n_new * sizeof(int)); memcpy(h_nz, new_xyah.data(), (size_t)n_new * 32); }
+    if (n_gal) memcpy(h_sp, sps.data(), sps.size() * sizeof(int));
+    if (n_out) {
+        int q = 0;
+        for (int j = 0; j < njobs; ++j) for (const TrackRec& t : e->trackers[tracker_ids[j]]->tracks) h_outs[q++] = t.slot;
     }
-    if (n_gal > 0) {
-        VC_HIP(hipMemcpyAsync(e->d_sps, e->h_sps, (size_t)n_gal * 3 * sizeof(int), hipMemcpyHostToDevice, s));
-        ProfScope ps(e, VC_PROF_TRACK);
-        VC_TRY(launch_gallery_write(e->pool, e->d_sps, n_gal, d_feat, s));
+    if (sb.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage, e->h_stage, sb.off, hipMemcpyHostToDevice, s));
+    if (n_upd) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_update(e->pool, d_upd, d_uz, n_upd, s)); }
+    if (n_new) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_initiate(e->pool, d_new, d_nz, n_new, s)); }
+    if (n_gal) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gallery_write(e->pool, d_sps, n_gal, d_feat, s)); }
+    if (n_out) {
+        { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gather_means(e->pool, d_outs, n_out, e->d_mean_out, s)); }
+        VC_HIP(hipMemcpyAsync(e->h_mean, e->d_mean_out, (size_t)n_out * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
-    return VC_OK;      // stream-ordered; readers of the pool synchronise (fetch_means)
-}
-
-// Kalman means of all tracks of a tracker, list order -> e->h_mean (blocking)
-static int fetch_means(vc_engine* e, const int* tracker_ids, int njobs, std::vector<int>& offsets) {
-    offsets.assign(njobs + 1, 0);
-    int n = 0;
-    for (int j = 0; j < njobs; ++j) { offsets[j] = n; n += (int)e->trackers[tracker_ids[j]]->tracks.size(); }
-    offsets[njobs] = n;
-    int q = 0;
-    for (int j = 0; j < njobs; ++j)
-        for (const TrackRec& t : e->trackers[tracker_ids[j]]->tracks)
-            VC_HIP(hipMemcpyAsync(e->h_mean + (size_t)(q++) * 8, e->pool.mean + (size_t)t.slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    VC_HIP(hipStreamSynchronize(e->stream));
-    return VC_OK;
+    return VC_OK;      // stream-ordered; callers synchronise before reading h_mean or stepping again
 }
 
 // deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id] (box = Kalman posterior, quirk Q7)
@@ -449,9 +467,9 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
         din[j].tlwh = prep[j].tlwh.data(); din[j].conf = prep[j].conf.data(); din[j].k = (int)prep[j].conf.size();
         din[j].feat_rows = prep[j].feat_rows.data(); din[j].feat_off = 0;
     }
-    VC_TRY(tracker_step_batch(e, tracker_ids.data(), din.data(), nj, d_feat));
     std::vector<int> offs;
-    VC_TRY(fetch_means(e, tracker_ids.data(), nj, offs));
+    VC_TRY(tracker_step_batch(e, tracker_ids.data(), din.data(), nj, d_feat, &offs));
+    VC_HIP(hipStreamSynchronize(e->stream));
     for (int j = 0; j < nj; ++j) {
         std::vector<int64_t> r5;
         emit_rows(*e->trackers[tracker_ids[j]], e->h_mean + (size_t)offs[j] * 8, W, H, r5);
@@ -498,7 +516,7 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
     VC_HIP(hipSetDevice(e->cfg.device));
     if (k > 0) VC_HIP(hipMemcpyAsync(e->d_feat_in, feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice, e->stream));
     DetIn d{tlwh, conf, k, nullptr, 0};
-    VC_TRY(tracker_step_batch(e, &id, &d, 1, e->d_feat_in));
+    VC_TRY(tracker_step_batch(e, &id, &d, 1, e->d_feat_in, nullptr));
     VC_HIP(hipStreamSynchronize(e->stream));
     return VC_OK;
 }

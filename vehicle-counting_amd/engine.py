@@ -195,6 +195,11 @@ class Engine:
     def profile_reset(self):
         L.check(L.lib().vc_profile_reset(self._h))
 
+    def profile_ops(self):
+        buf = C.create_string_buffer(1 << 20)
+        L.check(L.lib().vc_profile_ops(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def profile_read(self, cat):
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         L.check(L.lib().vc_profile_read(self._h, cat, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
