@@ -134,6 +134,9 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
 /* ---- fused stream path: the per-frame body of CountingPipeline.run on device-resident frames -------- */
 /* frames_dev: device pointer to B x H x W x 3 uint8 *BGR* frames (cv2.VideoCapture order; the RGB view
  * the detector needs is taken on the fly).  Results per frame: rows [x1,y1,x2,y2,track_id,label]. */
+/* vc_stream_submit enqueues the detector for a batch and returns at once (at most two outstanding); vc_stream_run consumes
+ * submissions in order (submitting itself when none is pending), so `submit(i+1); run(i)` overlaps detect(i+1) with track(i). */
+int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w);
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);
 /* Detection injection for throughput studies: replaces the detector's NMS output of the next
@@ -170,6 +173,8 @@ int vc_cosine_cost_host(const float* gallery, const int* gal_count, int t, int s
 int vc_dsort_nms_host(const double* tlwh, const double* scores, int n, double max_overlap, int* keep, int* n_keep);
 int vc_lap_host(const double* cost, int nr, int nc, int* row4col_rows, int* cols, int* n_assigned);
 int vc_letterbox_host(const uint8_t* rgb, int h, int w, int net_h, int net_w, int precision, float* out_nhwc3);
+/* VideoCounting.run zone filter (modules/track.py:102-104): inside[i] = any corner of boxes[i] in the polygon. Host only. */
+int vc_zone_filter_host(const double* polygon_xy, int n_points, const int64_t* boxes_xyxy, int n, uint8_t* inside);
 /* candidates (already conf-filtered, in the reference's candidate order): boxes xyxy, conf, class -> kept rows */
 int vc_nms_host(const float* boxes4, const float* conf, const int* cls, int n, float iou, int max_det, int max_cand,
                 float* out6, int* out_n);

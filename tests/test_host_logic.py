@@ -19,6 +19,10 @@ def test_counting_against_reference_golden(golden_dir, tmp_path):
     assert poly == g["zone"] and dirs == g["directions"]
     for rec in g["boxes"]:
         assert pc.check_bbox_intersect_polygon(poly, rec["box"]) == rec["inside"]
+    np.testing.assert_array_equal(pc.zone_mask(poly, [r["box"] for r in g["boxes"]]), [r["inside"] for r in g["boxes"]])
+    sqb = [[0, 0, 0, 0], [10, 5, 10, 5], [11, 5, 11, 5], [5, -1, 5, -1], [10, 10, 10, 10], [0, -3, 0, -3], [10, -3, 10, -3], [3, 3, 20, 20]]
+    sq_poly = [[0, 0], [10, 0], [10, 10], [0, 10]]
+    np.testing.assert_array_equal(pc.zone_mask(sq_poly, sqb), [pc.check_bbox_intersect_polygon(sq_poly, b) for b in sqb])
     sq = [[0, 0], [10, 0], [10, 10], [0, 10]]
     for rec in g["points"]:
         assert pc.is_point_in_polygon(poly if rec["poly"] == "zone" else sq, rec["pt"]) == rec["inside"], rec

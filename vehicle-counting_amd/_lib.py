@@ -74,6 +74,7 @@ SIGNATURES = {
     "vc_videotracker_run": [_vp, _pi, _i, _pu8, _i, _i, _pd, _pl, _pd, _i, _pl, _i, _pi],
     "vc_stream_run": [_vp, _pi, _i, _vp, _i, _i, _i, _pl, _i, _pi, _pi],
     "vc_stream_inject": [_vp, _pf, _pi, _i, _i],
+    "vc_stream_submit": [_vp, _vp, _i, _i, _i],
     "vc_profile_enable": [_vp, _i],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
     "vc_profile_reset": [_vp],
@@ -88,6 +89,7 @@ SIGNATURES = {
     "vc_dsort_nms_host": [_pd, _pd, _i, _d, _pi, _pi],
     "vc_lap_host": [_pd, _i, _i, _pi, _pi, _pi],
     "vc_letterbox_host": [_pu8, _i, _i, _i, _i, _i, _pf],
+    "vc_zone_filter_host": [_pd, _i, _pl, _i, _pu8],
     "vc_nms_host": [_pf, _pf, _pi, _i, _f, _i, _i, _pf, _pi],
 }
 _RESTYPE = {"vc_last_error": C.c_char_p}

@@ -72,6 +72,20 @@ def check_bbox_intersect_polygon(polygon, bbox):
     return False
 
 
+def zone_mask(polygon, boxes):
+    """check_bbox_intersect_polygon for many integer boxes at once through the library's host routine (same arithmetic)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib as L
+    b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int64).reshape(-1, 4))
+    poly = np.ascontiguousarray(np.asarray(polygon, dtype=np.float64).reshape(-1, 2))
+    out = np.zeros(len(b), np.uint8)
+    L.check(L.lib().vc_zone_filter_host(L.ptr(poly, C.c_double), len(poly), L.ptr(b, C.c_int64), len(b), L.ptr(out, C.c_uint8)))
+    return out.astype(bool)
+
+
 def cosin_similarity(a2d, b2d):
     ax, ay = float(a2d[1][0] - a2d[0][0]), float(a2d[1][1] - a2d[0][1])
     bx, by = float(b2d[1][0] - b2d[0][0]), float(b2d[1][1] - b2d[0][1])

@@ -65,7 +65,9 @@ struct Tracker {
 struct vc_engine {
     vc_engine_config cfg{};
     int prec = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // ReID + tracker
+    hipStream_t dstream = nullptr;   // detector (runs ahead of the tracker on the next batch)
+    hipEvent_t ev_det[2] = {nullptr, nullptr};
     bool finalized = false;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
@@ -85,6 +87,12 @@ struct vc_engine {
     int last_B = 0, last_nh = 0, last_nw = 0, last_ntotal = 0;
     float* h_det = nullptr;                      // pinned [max_batch][max_det][6]
     int* h_det_count = nullptr;                  // pinned [max_batch]
+    float* h_det2[2] = {nullptr, nullptr};       // pinned detector outputs of the (up to) two submissions in flight
+    int* h_det_count2[2] = {nullptr, nullptr};
+    float* h_geom = nullptr;                     // pinned [2][max_batch][5]
+    unsigned geom_seq = 0, submit_seq = 0;
+    struct Pending { const void* frames; int b, h, w, slot; };
+    std::vector<Pending> pending;
 
     // ---- ReID ---------------------------------------------------------------------------------------
     vc::Net reid;
@@ -100,7 +108,8 @@ struct vc_engine {
     std::vector<int> free_slots;
     std::vector<std::unique_ptr<vc::Tracker>> trackers;
     // per-step scratch: one pinned staging block mirrored on the device, cost matrices, posterior means
-    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0;
+    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0;     // phase A block
+    char* h_stage2 = nullptr; char* d_stage2 = nullptr;                          // phase B block
     double* h_cost = nullptr; double* d_cost = nullptr;
     double* h_mean = nullptr; double* d_mean_out = nullptr;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
@@ -129,18 +138,37 @@ int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k);   
 int prof_launch(vc_engine* e, int cat, double flops, double bytes, int status);
 struct ProfScope {
     vc_engine* e; int cat; double flops, bytes;
-    ProfScope(vc_engine* e_, int cat_, double flops_ = 0, double bytes_ = 0);
+    hipStream_t s;
+    ProfScope(vc_engine* e_, int cat_, double flops_ = 0, double bytes_ = 0, hipStream_t s_ = nullptr);
     ~ProfScope();
 };
 // tracker.hip
 int tracker_init_pool(vc_engine* e);
-// detections of one tracker for one step; feature of det i = d_feat row (feat_rows ? feat_rows[i] : feat_off + i)
-struct DetIn { const double* tlwh; const double* conf; int k; const int* feat_rows; int feat_off; };
-int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat,
-                       std::vector<int>* mean_offsets);
+struct Prepared { std::vector<double> tlwh, conf; std::vector<int> feat_rows; };   // filtered + NMS'ed detections of one tracker
+struct StepCtx {
+    std::vector<int> ids, labels;          // trackers stepped together (the classes of one frame) and their labels
+    std::vector<Prepared> prep;
+    int W = 0, H = 0;
+    bool all_means = false;
+    // phase A products
+    int n_dets = 0, n_app = 0, n_iou = 0;
+    size_t out = 0;
+    std::vector<int> det_base, job_out, featrow;
+    std::vector<std::vector<int>> app_job, iou_job;
+    std::vector<double> det_xyah;
+    // phase B products
+    struct Emit { int row; int64_t id; int label; };
+    std::vector<Emit> emit;
+    std::vector<int> mean_offsets;
+};
+int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat);
+int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat);
+void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6);
+void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
+               const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0);
 int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
                 const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
-                int n, const float* d_feat_ready, int feat_row0, std::vector<int64_t>& rows6);
+                int n, std::vector<int64_t>& rows6);
 int lap_solve(const double* cost, int nr, int nc, std::vector<int>& row_of_col_rows, std::vector<int>& cols);
 void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep);
 }  // namespace vc

@@ -37,12 +37,13 @@ int host_alloc(vc_engine* e, void** p, size_t bytes) {
     return VC_OK;
 }
 
-ProfScope::ProfScope(vc_engine* e_, int cat_, double flops_, double bytes_) : e(e_), cat(cat_), flops(flops_), bytes(bytes_) {
-    if (e->profiling) hipEventRecord(e->ev0, e->stream);
+ProfScope::ProfScope(vc_engine* e_, int cat_, double flops_, double bytes_, hipStream_t s_)
+    : e(e_), cat(cat_), flops(flops_), bytes(bytes_), s(s_ ? s_ : e_->stream) {
+    if (e->profiling) hipEventRecord(e->ev0, s);
 }
 ProfScope::~ProfScope() {
     if (!e->profiling) return;
-    hipEventRecord(e->ev1, e->stream);
+    hipEventRecord(e->ev1, s);
     hipEventSynchronize(e->ev1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
@@ -242,6 +243,11 @@ static int yolo_alloc(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&pb.det_count, B * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&pb.overflow, B * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&e->d_geom, B * 5 * sizeof(float)));
+    VC_TRY(host_alloc(e, (void**)&e->h_geom, 2 * B * 5 * sizeof(float)));
+    for (int k = 0; k < 2; ++k) {
+        VC_TRY(host_alloc(e, (void**)&e->h_det2[k], B * md * 6 * sizeof(float)));
+        VC_TRY(host_alloc(e, (void**)&e->h_det_count2[k], B * sizeof(int)));
+    }
     VC_TRY(host_alloc(e, (void**)&e->h_det, B * md * 6 * sizeof(float)));
     VC_TRY(host_alloc(e, (void**)&e->h_det_count, B * sizeof(int)));
     return VC_OK;
@@ -314,7 +320,7 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     return pb.status;
 }
 
-static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat) {
+static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStream_t s) {
     for (const Op& op : ops) {
         switch (op.kind) {
             case Op::CONV: {
@@ -323,8 +329,8 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat) {
                 const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
                 {
-                    ProfScope ps(e, VC_PROF_CONV, fl, by);
-                    VC_TRY(launch_conv(op.conv, e->stream));
+                    ProfScope ps(e, VC_PROF_CONV, fl, by, s);
+                    VC_TRY(launch_conv(op.conv, s));
                 }
                 if (e->profiling && e->op_log.size() < (1u << 20)) {
                     char line[256];
@@ -335,9 +341,9 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat) {
                 }
                 break;
             }
-            case Op::SPPF: { ProfScope ps(e, aux_cat); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, e->stream)); break; }
-            case Op::UPSAMPLE: { ProfScope ps(e, aux_cat); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, e->stream)); break; }
-            case Op::MAXPOOL: { ProfScope ps(e, aux_cat); VC_TRY(launch_maxpool3s2(op.a, op.b, e->prec, e->stream)); break; }
+            case Op::SPPF: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, s)); break; }
+            case Op::UPSAMPLE: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, s)); break; }
+            case Op::MAXPOOL: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_maxpool3s2(op.a, op.b, e->prec, s)); break; }
         }
     }
     return VC_OK;
@@ -367,9 +373,10 @@ static LetterboxGeom letterbox_geom(int h0, int w0, int nh, int nw, bool swap_rb
 }
 
 static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
+    hipStream_t ds = e->dstream;
     std::vector<Op> ops;
     VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
-    VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX));
+    VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
     // decode + NMS
     const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 4);
     DecodeLevel lv[3];
@@ -392,8 +399,8 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
         }
         dbg = e->d_pred_debug;
     }
-    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_decode(lv, 3, B, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, dbg, base, e->stream)); }
-    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_nms(B, e->cfg.max_candidates, e->cfg.max_det, e->cfg.iou_thres, e->d_geom, e->post, e->stream)); }
+    { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds); VC_TRY(launch_decode(lv, 3, B, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, dbg, base, ds)); }
+    { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds); VC_TRY(launch_nms(B, e->cfg.max_candidates, e->cfg.max_det, e->cfg.iou_thres, e->d_geom, e->post, ds)); }
     return VC_OK;
 }
 
@@ -403,13 +410,11 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     int nh, nw;
     autoshape_net_size(&h, &w, 1, e->cfg.img_size, nh, nw);
     const LetterboxGeom g = letterbox_geom(h, w, nh, nw, swap_rb);
-    float geom[5];
-    scale_geom_host(ScaleGeom{nh, nw, h, w}, geom);
-    std::vector<float> hg((size_t)B * 5);
-    for (int b = 0; b < B; ++b) memcpy(&hg[b * 5], geom, sizeof(geom));
-    VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    VC_HIP(hipStreamSynchronize(e->stream));      // hg is a stack-lifetime vector
-    { ProfScope ps(e, VC_PROF_DETECT_AUX); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->stream)); }
+    float* hg = e->h_geom + (size_t)(e->geom_seq++ & 1) * e->cfg.max_batch * 5;      // two pinned slots: two submissions may be in flight
+    scale_geom_host(ScaleGeom{nh, nw, h, w}, hg);
+    for (int b = 1; b < B; ++b) memcpy(hg + (size_t)b * 5, hg, 5 * sizeof(float));
+    VC_HIP(hipMemcpyAsync(e->d_geom, hg, (size_t)B * 5 * sizeof(float), hipMemcpyHostToDevice, e->dstream));
+    { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->dstream)); }
     return yolo_forward(e, B, nh, nw);
 }
 
@@ -471,7 +476,7 @@ static int reid_forward(vc_engine* e, int k) {
         x = pb.conv(p + ".conv2", t, mkview(m[p + ".y"], k, 0, 0, b.cout, 0), 3, 1, 1, ACT_RELU, &sc, RES_BEFORE_ACT);
     }
     VC_TRY(pb.status);
-    VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX));
+    VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, e->stream));
     { ProfScope ps(e, VC_PROF_REID_AUX); VC_TRY(launch_avgpool_l2norm(x, e->d_feat, e->prec, e->stream)); }               // model.py:70,93
     return VC_OK;
 }
@@ -527,7 +532,10 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     e->prec = cfg->precision;
     int st = VC_OK;
     do {
-        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&e->dstream, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
+        if (hipEventCreateWithFlags(&e->ev_det[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_det[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (cfg->with_detector) yolo_define(e);
         if (cfg->with_reid) reid_define(e);
@@ -542,11 +550,14 @@ int vc_engine_destroy(vc_engine* e) {
     if (!e) return VC_OK;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->dstream) hipStreamSynchronize(e->dstream);
     for (void* p : e->allocs) hipFree(p);
     for (void* p : e->host_allocs) hipHostFree(p);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
+    if (e->dstream) hipStreamDestroy(e->dstream);
+    for (hipEvent_t ev : e->ev_det) if (ev) hipEventDestroy(ev);
     delete e;
     return VC_OK;
 }
@@ -604,6 +615,7 @@ int vc_engine_finalize(vc_engine* e) {
 int vc_engine_sync(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipStreamSynchronize(e->dstream));
     return VC_OK;
 }
 
@@ -622,22 +634,23 @@ int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* 
         VC_CHECK(h[i] > 0 && w[i] > 0, VC_ERR_ARG, "empty image %d", i);
         const size_t bytes = (size_t)h[i] * w[i] * 3;
         VC_CHECK(off + bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frames exceed the staging buffer (max_frame_h/w)");
-        VC_HIP(hipMemcpyAsync(e->d_frames + off, rgb[i], bytes, hipMemcpyHostToDevice, e->stream));
+        VC_HIP(hipMemcpyAsync(e->d_frames + off, rgb[i], bytes, hipMemcpyHostToDevice, e->dstream));
         offs[i] = off; off += bytes;
         scale_geom_host(ScaleGeom{nh, nw, h[i], w[i]}, &hg[(size_t)i * 5]);
     }
-    VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->dstream));
+    VC_HIP(hipStreamSynchronize(e->dstream));        // hg / rgb[] are caller or stack memory
     const size_t px = (size_t)nh * nw * 4 * elem_size(e->prec);
     for (int i = 0; i < n; ++i) {
         const LetterboxGeom g = letterbox_geom(h[i], w[i], nh, nw, false);
-        ProfScope ps(e, VC_PROF_DETECT_AUX);
-        VC_TRY(launch_letterbox(e->d_frames + offs[i], (char*)e->ybuf["in"].ptr + (size_t)i * px, 1, g, e->prec, e->stream));
+        ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream);
+        VC_TRY(launch_letterbox(e->d_frames + offs[i], (char*)e->ybuf["in"].ptr + (size_t)i * px, 1, g, e->prec, e->dstream));
     }
     VC_TRY(yolo_forward(e, n, nh, nw));
     const int md = e->cfg.max_det;
-    VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)n * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)n * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->dstream));
+    VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, n * sizeof(int), hipMemcpyDeviceToHost, e->dstream));
+    VC_HIP(hipStreamSynchronize(e->dstream));
     memcpy(out_det, e->h_det, (size_t)n * md * 6 * sizeof(float));
     memcpy(out_count, e->h_det_count, n * sizeof(int));
     return VC_OK;
@@ -658,6 +671,7 @@ static int read_view_f32(vc_engine* e, const View& v, float* out, size_t cap, in
     const size_t rows = (size_t)v.B * v.H * v.W;
     std::vector<uint8_t> raw(rows * v.cs * es);
     VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipStreamSynchronize(e->dstream));
     VC_HIP(hipMemcpy(raw.data(), v.ptr, raw.size(), hipMemcpyDeviceToHost));
     for (size_t r = 0; r < rows; ++r)
         for (int c = 0; c < v.C; ++c) {
@@ -685,7 +699,7 @@ int vc_detect_debug_pred(vc_engine* e, float* out, size_t cap) {
     VC_CHECK(e->d_pred_debug && e->last_B > 0, VC_ERR_STATE, "arm with out=NULL and run the detector first");
     const size_t n = (size_t)e->last_B * e->last_ntotal * (e->cfg.num_classes + 5);
     VC_CHECK(n <= cap, VC_ERR_CAPACITY, "need %zu floats", n);
-    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipStreamSynchronize(e->dstream));
     VC_HIP(hipMemcpy(out, e->d_pred_debug, n * sizeof(float), hipMemcpyDeviceToHost));
     return VC_OK;
 }

@@ -6,9 +6,34 @@
 #include <cmath>
 #include <numeric>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "engine.h"
 
 using namespace vc;
+
+namespace {
+// host-timeline instrumentation (VC_TIMING=1): where a vc_stream_run call spends its wall time
+struct Tm {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    bool on = getenv("VC_TIMING") != nullptr;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+    void report() {
+        if (!on || ++calls % 10) return;
+        fprintf(stderr, "[vc timing, us per call] wait_det %.0f marshal %.0f reid_issue %.0f build %.0f phaseA_issue %.0f sync %.0f emit %.0f phaseB %.0f\n",
+                acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, acc[4] / calls, acc[5] / calls, acc[6] / calls, acc[7] / calls);
+    }
+} g_tm;
+}  // namespace
 
 namespace {
 
@@ -47,6 +72,23 @@ int vc_stream_inject(vc_engine* e, const float* det6, const int* count, int b, i
     return VC_OK;
 }
 
+// Enqueue the detector (letterbox .. NMS, results to pinned memory) for a batch on the detector stream and return
+// immediately.  At most two submissions may be outstanding; vc_stream_run consumes them in order.
+int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w) {
+    VC_CHECK(e && frames_dev, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "engine not finalized");
+    VC_CHECK(e->pending.size() < 2, VC_ERR_STATE, "two submissions are already in flight: call vc_stream_run first");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const int slot = (int)(e->submit_seq++ & 1);
+    const int md = e->cfg.max_det;
+    VC_TRY(run_detector_dev(e, (const uint8_t*)frames_dev, b, h, w, /*swap_rb=*/true));
+    VC_HIP(hipMemcpyAsync(e->h_det2[slot], e->post.det, (size_t)b * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->dstream));
+    VC_HIP(hipMemcpyAsync(e->h_det_count2[slot], e->post.det_count, b * sizeof(int), hipMemcpyDeviceToHost, e->dstream));
+    VC_HIP(hipEventRecord(e->ev_det[slot], e->dstream));
+    e->pending.push_back(vc_engine::Pending{frames_dev, b, h, w, slot});
+    return VC_OK;
+}
+
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
     VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
@@ -54,20 +96,42 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
     VC_HIP(hipSetDevice(e->cfg.device));
     const uint8_t* frames = (const uint8_t*)frames_dev;
     const int md = e->cfg.max_det;
-    VC_TRY(run_detector_dev(e, frames, b, h, w, /*swap_rb=*/true));
-    VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)b * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, b * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    VC_HIP(hipStreamSynchronize(e->stream));
+    if (e->pending.empty()) VC_TRY(vc_stream_submit(e, frames_dev, b, h, w));
+    const vc_engine::Pending pd = e->pending.front();
+    VC_CHECK(pd.frames == frames_dev && pd.b == b && pd.h == h && pd.w == w, VC_ERR_STATE,
+             "vc_stream_run must consume submissions in the order they were made");
+    e->pending.erase(e->pending.begin());
+    g_tm.start();
+    VC_HIP(hipEventSynchronize(e->ev_det[pd.slot]));
+    g_tm.lap(0);
+    const float* h_det = e->h_det2[pd.slot];
+    const int* h_cnt = e->h_det_count2[pd.slot];
     std::vector<FrameDets> fd(b);
     for (int f = 0; f < b; ++f) {
         if (e->inject_b > 0) {
             const int fi = f % e->inject_b;
             marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], fd[f]);
         } else {
-            marshal(e->h_det + (size_t)f * md * 6, e->h_det_count[f], fd[f]);
+            marshal(h_det + (size_t)f * md * 6, h_cnt[f], fd[f]);
         }
         if (out_ndet) out_ndet[f] = (int)fd[f].conf.size();
+        out_m[f] = 0;
     }
+    g_tm.lap(1);
+    // Tracker pipeline: phase B of frame f and phase A of the next non-empty frame share one synchronisation.
+    StepCtx ctx[2];
+    int cur = 0, prev_f = -1;
+    auto flush_prev = [&](int which) -> int {             // rows of the previously stepped frame (its means have landed)
+        if (prev_f < 0) return VC_OK;
+        std::vector<int64_t> rows6;
+        emit_rows(ctx[which], e->h_mean, rows6);
+        const int m = (int)(rows6.size() / 6);
+        VC_CHECK(m <= cap_rows_per_frame, VC_ERR_CAPACITY, "frame %d needs room for %d rows", prev_f, m);
+        memcpy(out_rows6 + (size_t)prev_f * cap_rows_per_frame * 6, rows6.data(), rows6.size() * sizeof(int64_t));
+        out_m[prev_f] = m;
+        prev_f = -1;
+        return VC_OK;
+    };
     // frames are processed in groups whose crops fit one ReID launch
     int f0 = 0;
     while (f0 < b) {
@@ -76,6 +140,8 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         VC_CHECK(f1 > f0, VC_ERR_CAPACITY, "one frame has more boxes (%zu) than max_crops (%d)", fd[f0].conf.size(), e->cfg.max_crops);
         std::vector<int> row0(f1 - f0, 0);
         int k = 0;
+        // the crop list lives in pinned memory that the previous group's copy may still be reading
+        if (f0 > 0) VC_HIP(hipStreamSynchronize(e->stream));
         for (int f = f0; f < f1; ++f) {
             row0[f - f0] = k;
             FrameDets& d = fd[f];
@@ -96,28 +162,85 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
             VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             VC_TRY(run_reid_dev(e, frames, h, w, k));
         }
+        g_tm.lap(2);
         for (int f = f0; f < f1; ++f) {
             FrameDets& d = fd[f];
-            out_m[f] = 0;
             if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
             std::vector<int> ids, labs;
             std::vector<std::vector<int>> groups;
-            for (int c = 0; c < num_classes; ++c) {
+            for (int c = 0; c < num_classes; ++c) {                                  // modules/track.py:50-59
                 std::vector<int> g;
                 for (size_t i = 0; i < d.label.size(); ++i) if (d.label[i] == c) g.push_back((int)i);
                 if (g.empty()) continue;
                 ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(g));
             }
             if (ids.empty()) continue;
-            std::vector<int64_t> rows6;
-            VC_TRY(frame_track(e, frames, f, h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), (int)d.conf.size(), e->d_feat,
-                               row0[f - f0], rows6));
-            const int m = (int)(rows6.size() / 6);
-            VC_CHECK(m <= cap_rows_per_frame, VC_ERR_CAPACITY, "frame %d needs room for %d rows", f, m);
-            memcpy(out_rows6 + (size_t)f * cap_rows_per_frame * 6, rows6.data(), rows6.size() * sizeof(int64_t));
-            out_m[f] = m;
+            build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), row0[f - f0]);
+            g_tm.lap(3);
+            VC_TRY(track_phase_a(e, ctx[cur], e->d_feat));
+            g_tm.lap(4);
+            VC_HIP(hipStreamSynchronize(e->stream));          // cost rows of f are here; so are the means of the previous frame
+            g_tm.lap(5);
+            VC_TRY(flush_prev(cur ^ 1));
+            g_tm.lap(6);
+            VC_TRY(track_phase_b(e, ctx[cur], e->d_feat));
+            g_tm.lap(7);
+            prev_f = f;
+            cur ^= 1;
         }
         f0 = f1;
+    }
+    if (prev_f >= 0) {
+        VC_HIP(hipStreamSynchronize(e->stream));
+        g_tm.lap(5);
+        VC_TRY(flush_prev(cur ^ 1));
+        g_tm.lap(6);
+    }
+    g_tm.report();
+    return VC_OK;
+}
+
+// Zone filter of VideoCounting.run (/root/reference/modules/track.py:102-104 -> utilities/counting/bb_polygon.py:14-114):
+// inside[i] = any corner of boxes[i] = (x1,y1,x2,y2) lies in the polygon (ray cast to y = 1e9, exact double compares).
+// Host-only (the post-pass runs once per video on a few thousand rows); same arithmetic as counting.py.
+namespace {
+struct P2 { double x, y; };
+inline int orient(P2 p, P2 q, P2 r) {
+    const double v = (q.y - p.y) * (r.x - q.x) - (q.x - p.x) * (r.y - q.y);
+    return v == 0 ? 0 : (v > 0 ? 1 : 2);
+}
+inline bool on_segment(P2 p, P2 q, P2 r) {
+    return q.x <= std::max(p.x, r.x) && q.x >= std::min(p.x, r.x) && q.y <= std::max(p.y, r.y) && q.y >= std::min(p.y, r.y);
+}
+inline bool intersect(P2 p1, P2 q1, P2 p2, P2 q2) {
+    const int o1 = orient(p1, q1, p2), o2 = orient(p1, q1, q2), o3 = orient(p2, q2, p1), o4 = orient(p2, q2, q1);
+    if (o1 != o2 && o3 != o4) return true;
+    if (o1 == 0 && on_segment(p1, p2, q1)) return true;
+    if (o2 == 0 && on_segment(p1, q2, q1)) return true;
+    if (o3 == 0 && on_segment(p2, p1, q2)) return true;
+    return o4 == 0 && on_segment(p2, q1, q2);
+}
+bool point_in_polygon(const P2* poly, int n, P2 pt) {
+    const P2 far{pt.x, 1e9};
+    int count = 0;
+    for (int i = 0; i < n; ++i) {
+        const P2 a = poly[i], b = poly[(i + 1) % n];
+        if (intersect(a, b, pt, far)) {
+            if (orient(a, pt, b) == 0) return on_segment(a, pt, b);
+            ++count;
+        }
+    }
+    return count % 2 == 1;
+}
+}  // namespace
+
+int vc_zone_filter_host(const double* polygon_xy, int n_points, const int64_t* boxes_xyxy, int n, uint8_t* inside) {
+    VC_CHECK(polygon_xy && n_points >= 1 && (n == 0 || (boxes_xyxy && inside)), VC_ERR_ARG, "bad argument");
+    const P2* poly = (const P2*)polygon_xy;
+    for (int i = 0; i < n; ++i) {
+        const double x1 = (double)boxes_xyxy[i * 4], y1 = (double)boxes_xyxy[i * 4 + 1], x2 = (double)boxes_xyxy[i * 4 + 2], y2 = (double)boxes_xyxy[i * 4 + 3];
+        inside[i] = point_in_polygon(poly, n_points, P2{x1, y1}) || point_in_polygon(poly, n_points, P2{x2, y1}) ||
+                    point_in_polygon(poly, n_points, P2{x2, y2}) || point_in_polygon(poly, n_points, P2{x1, y2});
     }
     return VC_OK;
 }

@@ -159,6 +159,8 @@ int tracker_init_pool(vc_engine* e) {
                    2 * align16(T * 4) + 2 * align16((T + D) * 32) + align16((T + D) * 12) + 256;          // phase B (superset)
     VC_TRY(host_alloc(e, (void**)&e->h_stage, e->stage_cap));
     VC_TRY(dev_alloc(e, (void**)&e->d_stage, e->stage_cap));
+    VC_TRY(host_alloc(e, (void**)&e->h_stage2, e->stage_cap));
+    VC_TRY(dev_alloc(e, (void**)&e->d_stage2, e->stage_cap));
     VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));
     VC_TRY(dev_alloc(e, (void**)&e->d_cost, e->cost_cap * sizeof(double)));
     VC_TRY(host_alloc(e, (void**)&e->h_mean, T * 8 * sizeof(double)));
@@ -182,22 +184,26 @@ struct Stage {
     }
 };
 
-// Steps `njobs` trackers (Tracker.predict(); Tracker.update(dets)) with one batched device pass each for
-// {predict, cost} and {update, initiate, gallery, mean gather}; each phase is one H2D copy, a few launches and one
-// D2H copy.  dets[j].feat_rows index rows of d_feat.  On return (stream-ordered, NOT synchronised) e->h_mean will hold
-// the posterior means of every live track of the stepped trackers in (job, list) order; mean_offsets[j] = first row.
-int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, int njobs, const float* d_feat,
-                       std::vector<int>* mean_offsets) {
+// One tracker step for a set of trackers (all classes of one frame), split at its only data dependency on the device:
+//   phase A (enqueue)  Tracker.predict for every track, appearance+gate and IoU cost rows, cost D2H
+//   -- caller synchronises the stream --
+//   phase B (host)     matching cascade + IoU matching (exact LSAP), Track.update / mark_missed / _initiate_track, gallery
+//           (enqueue)  batched Kalman update / initiate, gallery ring writes, gather of the posterior means, means D2H
+// Each phase is ONE host->device copy of a pinned staging block, a few launches and ONE device->host copy.  Phase B of
+// frame f and phase A of frame f+1 share a synchronisation point (vc_stream_run), so a frame costs one round trip.
+int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat) {
     hipStream_t s = e->stream;
-    // ---------------- phase A: predict + cost matrices
-    int n_tracks = 0, n_dets = 0;
-    std::vector<int> det_base(njobs);
+    const int njobs = (int)c.ids.size();
+    int n_tracks = 0;
+    c.n_dets = 0;
+    c.det_base.assign(njobs, 0);
     for (int j = 0; j < njobs; ++j) {
-        VC_CHECK(tracker_ids[j] >= 0 && tracker_ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
-        n_tracks += (int)e->trackers[tracker_ids[j]]->tracks.size();
-        det_base[j] = n_dets;
-        n_dets += dets[j].k;
+        VC_CHECK(c.ids[j] >= 0 && c.ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", c.ids[j]);
+        n_tracks += (int)e->trackers[c.ids[j]]->tracks.size();
+        c.det_base[j] = c.n_dets;
+        c.n_dets += (int)c.prep[j].conf.size();
     }
+    const int n_dets = c.n_dets;
     VC_CHECK(n_dets <= e->det_cap, VC_ERR_CAPACITY, "%d detections in one step exceed capacity %d", n_dets, e->det_cap);
     Stage st{e->h_stage, e->d_stage, e->stage_cap};
     int *d_slots, *d_featrow; double *d_xyah, *d_tlwh; CostJob* d_jobs;
@@ -206,68 +212,74 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
     double* h_xyah = st.take<double>((size_t)n_dets * 4, &d_xyah);
     double* h_tlwh = st.take<double>((size_t)n_dets * 4, &d_tlwh);
     CostJob* h_jobs = st.take<CostJob>((size_t)2 * n_tracks, &d_jobs);
+    VC_CHECK(st.off <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
     {
         int q = 0;
         for (int j = 0; j < njobs; ++j)
-            for (TrackRec& t : e->trackers[tracker_ids[j]]->tracks) { h_slots[q++] = t.slot; t.age += 1; t.tsu += 1; }   // sort/track.py:112-124
+            for (TrackRec& t : e->trackers[c.ids[j]]->tracks) { h_slots[q++] = t.slot; t.age += 1; t.tsu += 1; }   // sort/track.py:112-124
     }
-    for (int j = 0; j < njobs; ++j)
-        for (int i = 0; i < dets[j].k; ++i) {
-            const int g = det_base[j] + i;
-            memcpy(h_tlwh + (size_t)g * 4, dets[j].tlwh + (size_t)i * 4, 4 * sizeof(double));
-            tlwh_to_xyah(dets[j].tlwh + (size_t)i * 4, h_xyah + (size_t)g * 4);
-            h_featrow[g] = dets[j].feat_rows ? dets[j].feat_rows[i] : dets[j].feat_off + i;
-        }
-    // cost jobs: appearance rows for confirmed tracks, IoU rows for every possible IoU candidate, each over all of its tracker's dets
-    int n_app = 0, n_iou = 0;
-    size_t out = 0;
-    std::vector<std::vector<int>> app_job(njobs), iou_job(njobs);
     for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[tracker_ids[j]];
-        if (dets[j].k == 0) continue;
-        app_job[j].assign(tk.tracks.size(), -1);
+        const Prepared& p = c.prep[j];
+        for (size_t i = 0; i < p.conf.size(); ++i) {
+            const int g = c.det_base[j] + (int)i;
+            memcpy(h_tlwh + (size_t)g * 4, &p.tlwh[i * 4], 4 * sizeof(double));
+            tlwh_to_xyah(&p.tlwh[i * 4], h_xyah + (size_t)g * 4);
+            h_featrow[g] = p.feat_rows[i];
+        }
+    }
+    // cost jobs: appearance rows for confirmed tracks, IoU rows for every possible IoU candidate, each over all of its tracker's dets
+    c.n_app = c.n_iou = 0;
+    c.out = 0;
+    c.app_job.assign(njobs, {});
+    c.iou_job.assign(njobs, {});
+    for (int j = 0; j < njobs; ++j) {
+        Tracker& tk = *e->trackers[c.ids[j]];
+        const int k = (int)c.prep[j].conf.size();
+        if (k == 0) continue;
+        c.app_job[j].assign(tk.tracks.size(), -1);
         for (size_t t = 0; t < tk.tracks.size(); ++t) {
             const TrackRec& tr = tk.tracks[t];
             if (tr.state != CONFIRMED) continue;
-            h_jobs[n_app] = CostJob{tr.slot, tr.gal_count, det_base[j], dets[j].k, (int)out, tr.tsu};
-            app_job[j][t] = n_app++;
-            out += dets[j].k;
+            h_jobs[c.n_app] = CostJob{tr.slot, tr.gal_count, c.det_base[j], k, (int)c.out, tr.tsu};
+            c.app_job[j][t] = c.n_app++;
+            c.out += k;
         }
     }
     for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[tracker_ids[j]];
-        if (dets[j].k == 0) continue;
-        iou_job[j].assign(tk.tracks.size(), -1);
+        Tracker& tk = *e->trackers[c.ids[j]];
+        const int k = (int)c.prep[j].conf.size();
+        if (k == 0) continue;
+        c.iou_job[j].assign(tk.tracks.size(), -1);
         for (size_t t = 0; t < tk.tracks.size(); ++t) {
             const TrackRec& tr = tk.tracks[t];
             if (tr.state == CONFIRMED && tr.tsu != 1) continue;       // never an IoU candidate (sort/tracker.py:118-120)
-            h_jobs[n_app + n_iou] = CostJob{tr.slot, 0, det_base[j], dets[j].k, (int)out, tr.tsu};
-            iou_job[j][t] = n_app + n_iou++;
-            out += dets[j].k;
+            h_jobs[c.n_app + c.n_iou] = CostJob{tr.slot, 0, c.det_base[j], k, (int)c.out, tr.tsu};
+            c.iou_job[j][t] = c.n_app + c.n_iou++;
+            c.out += k;
         }
     }
-    VC_CHECK(out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", out, e->cost_cap);
+    VC_CHECK(c.out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", c.out, e->cost_cap);
+    c.det_xyah.assign(h_xyah, h_xyah + (size_t)n_dets * 4);
+    c.featrow.assign(h_featrow, h_featrow + n_dets);
+    c.job_out.resize(c.n_app + c.n_iou);
+    for (int i = 0; i < c.n_app + c.n_iou; ++i) c.job_out[i] = h_jobs[i].out_off;
     if (st.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage, e->h_stage, st.off, hipMemcpyHostToDevice, s));
     { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_predict(e->pool, d_slots, n_tracks, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_appearance_cost(e->pool, d_jobs, n_app, d_feat, d_featrow, d_xyah, e->d_cost, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, d_jobs + n_app, n_iou, d_tlwh, e->d_cost, s)); }
-    if (out > 0) {
-        VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, out * sizeof(double), hipMemcpyDeviceToHost, s));
-        VC_HIP(hipStreamSynchronize(s));
-    }
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_appearance_cost(e->pool, d_jobs, c.n_app, d_feat, d_featrow, d_xyah, e->d_cost, s)); }
+    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, d_jobs + c.n_app, c.n_iou, d_tlwh, e->d_cost, s)); }
+    if (c.out > 0) VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, c.out * sizeof(double), hipMemcpyDeviceToHost, s));
+    return VC_OK;
+}
 
-    // ---------------- phase B: association + lifecycle (host), then the batched Kalman update
-    // the phase-A block is consumed (the stream was synchronised or nothing depended on it): keep what is still needed
-    std::vector<double> det_xyah(h_xyah, h_xyah + (size_t)n_dets * 4);
-    std::vector<int> featrow(h_featrow, h_featrow + n_dets);
-    std::vector<int> job_out(h_jobs ? n_app + n_iou : 0);
-    for (int i = 0; i < n_app + n_iou; ++i) job_out[i] = h_jobs[i].out_off;
-    if (out == 0 && st.off > 0) VC_HIP(hipStreamSynchronize(s));     // the staging block is about to be rewritten
+int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
+    hipStream_t s = e->stream;
+    const int njobs = (int)c.ids.size();
     std::vector<int> upd_slots, new_slots, sps;
     std::vector<double> upd_xyah, new_xyah;
     for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[tracker_ids[j]];
-        const int k = dets[j].k;
+        Tracker& tk = *e->trackers[c.ids[j]];
+        const Prepared& pr = c.prep[j];
+        const int k = (int)pr.conf.size();
         const int nt = (int)tk.tracks.size();
         std::vector<int> confirmed, unconfirmed;
         for (int t = 0; t < nt; ++t) (tk.tracks[t].state == CONFIRMED ? confirmed : unconfirmed).push_back(t);
@@ -283,7 +295,7 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
             for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
             if (lvl.empty()) continue;
             std::vector<const double*> rp;
-            for (int t : lvl) rp.push_back(e->h_cost + job_out[app_job[j][t]]);
+            for (int t : lvl) rp.push_back(e->h_cost + c.job_out[c.app_job[j][t]]);
             VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
             for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
             left = mo.un_cols;
@@ -295,7 +307,7 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
         {
             std::vector<const double*> rp;
-            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + job_out[iou_job[j][t]]);
+            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + c.job_out[c.iou_job[j][t]]);
             else rp.assign(cand.size(), nullptr);
             VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
         }
@@ -306,13 +318,13 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         // Track.update, sort/track.py:126-145
         for (auto& m : matches) {
             TrackRec& tr = tk.tracks[m.first];
-            const int g = det_base[j] + m.second;
+            const int g = c.det_base[j] + m.second;
             upd_slots.push_back(tr.slot);
-            upd_xyah.insert(upd_xyah.end(), &det_xyah[(size_t)g * 4], &det_xyah[(size_t)g * 4] + 4);
-            sps.push_back(tr.slot); sps.push_back(tr.gal_head); sps.push_back(featrow[g]);
+            upd_xyah.insert(upd_xyah.end(), &c.det_xyah[(size_t)g * 4], &c.det_xyah[(size_t)g * 4] + 4);
+            sps.push_back(tr.slot); sps.push_back(tr.gal_head); sps.push_back(c.featrow[g]);
             tr.gal_head = (tr.gal_head + 1) % tk.p.nn_budget;
             tr.gal_count = std::min(tr.gal_count + 1, tk.p.nn_budget);
-            tr.last_conf = dets[j].conf[m.second];
+            tr.last_conf = pr.conf[m.second];
             tr.hits += 1; tr.tsu = 0;
             if (tr.state == TENTATIVE && tr.hits >= tk.p.n_init) tr.state = CONFIRMED;
         }
@@ -328,12 +340,12 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
             TrackRec tr{};
             tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
             tr.slot = e->free_slots.back(); e->free_slots.pop_back();
-            const int g = det_base[j] + d;
+            const int g = c.det_base[j] + d;
             new_slots.push_back(tr.slot);
-            new_xyah.insert(new_xyah.end(), &det_xyah[(size_t)g * 4], &det_xyah[(size_t)g * 4] + 4);
-            sps.push_back(tr.slot); sps.push_back(0); sps.push_back(featrow[g]);
+            new_xyah.insert(new_xyah.end(), &c.det_xyah[(size_t)g * 4], &c.det_xyah[(size_t)g * 4] + 4);
+            sps.push_back(tr.slot); sps.push_back(0); sps.push_back(c.featrow[g]);
             tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
-            tr.last_conf = dets[j].conf[d];
+            tr.last_conf = pr.conf[d];
             tk.tracks.push_back(tr);
         }
         // drop deleted tracks, sort/tracker.py:80
@@ -344,15 +356,23 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         }
         tk.tracks.swap(alive);
     }
-    // one staging block again: update list, initiate list, gallery writes, slots whose means the caller wants back
-    Stage sb{e->h_stage, e->d_stage, e->stage_cap};
+    // second staging block: update list, initiate list, gallery writes, slots whose posterior means go back to the host
+    Stage sb{e->h_stage2, e->d_stage2, e->stage_cap};
     const int n_upd = (int)upd_slots.size(), n_new = (int)new_slots.size(), n_gal = (int)sps.size() / 3;
-    int n_out = 0;
-    if (mean_offsets) {
-        mean_offsets->assign(njobs + 1, 0);
-        for (int j = 0; j < njobs; ++j) { (*mean_offsets)[j] = n_out; n_out += (int)e->trackers[tracker_ids[j]]->tracks.size(); }
-        (*mean_offsets)[njobs] = n_out;
+    // deep_sort.py:46-58 output eligibility (confirmed, time_since_update <= 1), or every track for the state readers
+    c.emit.clear();
+    c.mean_offsets.assign(njobs + 1, 0);
+    std::vector<int> out_slots;
+    for (int j = 0; j < njobs; ++j) {
+        c.mean_offsets[j] = (int)out_slots.size();
+        for (const TrackRec& tr : e->trackers[c.ids[j]]->tracks) {
+            if (!c.all_means && (tr.state != CONFIRMED || tr.tsu > 1)) continue;
+            if (tr.state == CONFIRMED && tr.tsu <= 1) c.emit.push_back(StepCtx::Emit{(int)out_slots.size(), tr.id, j < (int)c.labels.size() ? c.labels[j] : 0});
+            out_slots.push_back(tr.slot);
+        }
     }
+    const int n_out = (int)out_slots.size();
+    c.mean_offsets[njobs] = n_out;
     int *d_upd, *d_new, *d_sps, *d_outs; double *d_uz, *d_nz;
     int* h_upd = sb.take<int>(n_upd, &d_upd);
     int* h_new = sb.take<int>(n_new, &d_new);
@@ -364,11 +384,8 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
     if (n_upd) { memcpy(h_upd, upd_slots.data(), n_upd * sizeof(int)); memcpy(h_uz, upd_xyah.data(), (size_t)n_upd * 32); }
     if (n_new) { memcpy(h_new, new_slots.data(), n_new * sizeof(int)); memcpy(h_nz, new_xyah.data(), (size_t)n_new * 32); }
     if (n_gal) memcpy(h_sp, sps.data(), sps.size() * sizeof(int));
-    if (n_out) {
-        int q = 0;
-        for (int j = 0; j < njobs; ++j) for (const TrackRec& t : e->trackers[tracker_ids[j]]->tracks) h_outs[q++] = t.slot;
-    }
-    if (sb.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage, e->h_stage, sb.off, hipMemcpyHostToDevice, s));
+    if (n_out) memcpy(h_outs, out_slots.data(), n_out * sizeof(int));
+    if (sb.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage2, e->h_stage2, sb.off, hipMemcpyHostToDevice, s));
     if (n_upd) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_update(e->pool, d_upd, d_uz, n_upd, s)); }
     if (n_new) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_initiate(e->pool, d_new, d_nz, n_new, s)); }
     if (n_gal) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gallery_write(e->pool, d_sps, n_gal, d_feat, s)); }
@@ -376,28 +393,26 @@ int tracker_step_batch(vc_engine* e, const int* tracker_ids, const DetIn* dets, 
         { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gather_means(e->pool, d_outs, n_out, e->d_mean_out, s)); }
         VC_HIP(hipMemcpyAsync(e->h_mean, e->d_mean_out, (size_t)n_out * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
-    return VC_OK;      // stream-ordered; callers synchronise before reading h_mean or stepping again
+    return VC_OK;      // stream-ordered: e->h_mean / c.emit are valid after the next synchronisation of e->stream
 }
 
-// deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id] (box = Kalman posterior, quirk Q7)
-static void emit_rows(const Tracker& tk, const double* means, int W, int H, std::vector<int64_t>& rows5) {
-    for (size_t t = 0; t < tk.tracks.size(); ++t) {
-        const TrackRec& tr = tk.tracks[t];
-        if (tr.state != CONFIRMED || tr.tsu > 1) continue;
-        const double* m = means + t * 8;
-        const double w = m[2] * m[3], h = m[3];
+// deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id,label] (box = Kalman posterior, Q7)
+void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6) {
+    for (const StepCtx::Emit& em : c.emit) {
+        const double* m = means + (size_t)em.row * 8;
+        const double w = m[2] * m[3], h = m[3];                         // sort/track.py:82-96 to_tlwh
         const double x = m[0] - w / 2, y = m[1] - h / 2;
-        rows5.push_back(std::max((int64_t)x, (int64_t)0));
-        rows5.push_back(std::max((int64_t)y, (int64_t)0));
-        rows5.push_back(std::min((int64_t)(x + w), (int64_t)W - 1));
-        rows5.push_back(std::min((int64_t)(y + h), (int64_t)H - 1));
-        rows5.push_back(tr.id);
+        rows6.push_back(std::max((int64_t)x, (int64_t)0));              // deep_sort.py:97-108 int() + clamp
+        rows6.push_back(std::max((int64_t)y, (int64_t)0));
+        rows6.push_back(std::min((int64_t)(x + w), (int64_t)c.W - 1));
+        rows6.push_back(std::min((int64_t)(y + h), (int64_t)c.H - 1));
+        rows6.push_back(em.id);
+        rows6.push_back(em.label);
     }
 }
 
 // DeepSort.update minus the embedding: confidence filter, tlwh, DeepSORT NMS -> detections in pick order
-struct Prepared { std::vector<double> tlwh, conf; std::vector<int> feat_rows; };
-static void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k, const vc_tracker_params& p, Prepared& out) {
+void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k, const vc_tracker_params& p, Prepared& out) {
     std::vector<double> tl, cf;
     std::vector<int> fr;
     for (int i = 0; i < k; ++i) {
@@ -429,31 +444,12 @@ static void crop_corners_i(const double* b, int W, int H, int* c) {  // deep_sor
     c[1] = std::max((int)(b[1] - b[3] / 2), 0); c[3] = std::min((int)(b[1] + b[3] / 2), H - 1);
 }
 
-// Shared by vc_deepsort_update / vc_videotracker_run / vc_stream_run: one frame already on the device.
-// groups: per tracker the indices (into xyxy/conf) of its boxes.  Output rows [x1,y1,x2,y2,id,label].
-int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
-                const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
-                int n, const float* d_feat_ready, int feat_row0, std::vector<int64_t>& rows6) {
-    // crops + embedding for every box (unless the caller already embedded them: d_feat_ready)
-    const float* d_feat = d_feat_ready;
-    if (!d_feat) {
-        VC_CHECK(n <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", n, e->cfg.max_crops);
-        for (int i = 0; i < n; ++i) {
-            double c[4]; int q[4];
-            xyxy_to_cxcywh(xyxy + (size_t)i * 4, c);
-            crop_corners_i(c, W, H, q);
-            VC_CHECK(q[2] > q[0] && q[3] > q[1], VC_ERR_ARG, "box %d gives an empty crop (the reference's cv2.resize raises here)", i);
-            int* h = e->h_crops + (size_t)i * 5;
-            h[0] = frame_index; h[1] = q[0]; h[2] = q[1]; h[3] = q[2]; h[4] = q[3];
-        }
-        VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)n * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
-        VC_TRY(run_reid_dev(e, d_frame_base, H, W, n));
-        d_feat = e->d_feat;
-        feat_row0 = 0;
-    }
+// Build the step context of one frame: per tracker the prepared (filtered, NMS'ed) detections.
+void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
+               const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0) {
     const int nj = (int)tracker_ids.size();
-    std::vector<Prepared> prep(nj);
-    std::vector<DetIn> din(nj);
+    c.ids = tracker_ids; c.labels = labels; c.H = H; c.W = W; c.all_means = false;
+    c.prep.assign(nj, Prepared{});
     for (int j = 0; j < nj; ++j) {
         const auto& g = groups[j];
         std::vector<double> bx(g.size() * 4), cf(g.size());
@@ -463,21 +459,33 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
             cf[i] = conf[g[i]];
             rows[i] = feat_row0 + g[i];
         }
-        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, prep[j]);
-        din[j].tlwh = prep[j].tlwh.data(); din[j].conf = prep[j].conf.data(); din[j].k = (int)prep[j].conf.size();
-        din[j].feat_rows = prep[j].feat_rows.data(); din[j].feat_off = 0;
+        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, c.prep[j]);
     }
-    std::vector<int> offs;
-    VC_TRY(tracker_step_batch(e, tracker_ids.data(), din.data(), nj, d_feat, &offs));
+}
+
+// Shared by vc_deepsort_update / vc_videotracker_run: one frame already on the device, blocking.
+// groups: per tracker the indices (into xyxy/conf) of its boxes.  Output rows [x1,y1,x2,y2,id,label].
+int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
+                const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
+                int n, std::vector<int64_t>& rows6) {
+    VC_CHECK(n <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", n, e->cfg.max_crops);
+    for (int i = 0; i < n; ++i) {
+        double c[4]; int q[4];
+        xyxy_to_cxcywh(xyxy + (size_t)i * 4, c);
+        crop_corners_i(c, W, H, q);
+        VC_CHECK(q[2] > q[0] && q[3] > q[1], VC_ERR_ARG, "box %d gives an empty crop (the reference's cv2.resize raises here)", i);
+        int* h = e->h_crops + (size_t)i * 5;
+        h[0] = frame_index; h[1] = q[0]; h[2] = q[1]; h[3] = q[2]; h[4] = q[3];
+    }
+    VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)n * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    VC_TRY(run_reid_dev(e, d_frame_base, H, W, n));
+    StepCtx c;
+    build_ctx(e, c, H, W, tracker_ids, labels, groups, xyxy, conf, 0);
+    VC_TRY(track_phase_a(e, c, e->d_feat));
     VC_HIP(hipStreamSynchronize(e->stream));
-    for (int j = 0; j < nj; ++j) {
-        std::vector<int64_t> r5;
-        emit_rows(*e->trackers[tracker_ids[j]], e->h_mean + (size_t)offs[j] * 8, W, H, r5);
-        for (size_t i = 0; i < r5.size(); i += 5) {
-            for (int c = 0; c < 5; ++c) rows6.push_back(r5[i + c]);
-            rows6.push_back(labels[j]);
-        }
-    }
+    VC_TRY(track_phase_b(e, c, e->d_feat));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    emit_rows(c, e->h_mean, rows6);
     return VC_OK;
 }
 
@@ -515,8 +523,16 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
     VC_CHECK(k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
     VC_HIP(hipSetDevice(e->cfg.device));
     if (k > 0) VC_HIP(hipMemcpyAsync(e->d_feat_in, feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    DetIn d{tlwh, conf, k, nullptr, 0};
-    VC_TRY(tracker_step_batch(e, &id, &d, 1, e->d_feat_in, nullptr));
+    StepCtx c;
+    c.ids = {id}; c.labels = {0}; c.all_means = false;
+    c.prep.assign(1, Prepared{});
+    c.prep[0].tlwh.assign(tlwh, tlwh + (size_t)k * 4);
+    c.prep[0].conf.assign(conf, conf + k);
+    c.prep[0].feat_rows.resize(k);
+    std::iota(c.prep[0].feat_rows.begin(), c.prep[0].feat_rows.end(), 0);
+    VC_TRY(track_phase_a(e, c, e->d_feat_in));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_TRY(track_phase_b(e, c, e->d_feat_in));
     VC_HIP(hipStreamSynchronize(e->stream));
     return VC_OK;
 }
@@ -558,7 +574,7 @@ int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, c
     std::vector<int> all(k);
     std::iota(all.begin(), all.end(), 0);
     std::vector<int64_t> rows6;
-    VC_TRY(frame_track(e, e->d_frames, 0, h, w, {id}, {0}, {all}, bbox_xyxy, conf, k, nullptr, 0, rows6));
+    VC_TRY(frame_track(e, e->d_frames, 0, h, w, {id}, {0}, {all}, bbox_xyxy, conf, k, rows6));
     const int m = (int)(rows6.size() / 6);
     VC_CHECK(m <= cap_rows, VC_ERR_CAPACITY, "need room for %d rows", m);
     for (int i = 0; i < m; ++i) {
@@ -602,7 +618,7 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
                 for (int c = 0; c < 4; ++c) used_xyxy.push_back(xyxy[(size_t)i * 4 + c]);
                 used_conf.push_back(scores[i]);
             }
-        VC_TRY(frame_track(e, e->d_frames, 0, h, w, ids, labs, g2, used_xyxy.data(), used_conf.data(), (int)used_conf.size(), nullptr, 0, rows6));
+        VC_TRY(frame_track(e, e->d_frames, 0, h, w, ids, labs, g2, used_xyxy.data(), used_conf.data(), (int)used_conf.size(), rows6));
     }
     const int m = (int)(rows6.size() / 6);
     VC_CHECK(m <= cap_rows, VC_ERR_CAPACITY, "need room for %d rows", m);

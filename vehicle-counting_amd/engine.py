@@ -180,6 +180,10 @@ class Engine:
                                       L.ptr(rows, C.c_int64), cap_rows, L.ptr(m, C.c_int), L.ptr(nd, C.c_int)))
         return [rows[i, : m[i]].copy() for i in range(b)], nd
 
+    def stream_submit(self, frames_dev_ptr, b, h, w):
+        """Enqueue the detector for a batch (returns immediately); the matching stream_run consumes it."""
+        L.check(L.lib().vc_stream_submit(self._h, C.c_void_p(frames_dev_ptr), b, h, w))
+
     def stream_inject(self, det6=None, counts=None):
         if det6 is None:
             L.check(L.lib().vc_stream_inject(self._h, None, None, 0, 0))

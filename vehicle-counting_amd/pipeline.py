@@ -84,8 +84,13 @@ class CountingPipeline:
         frames = source.frames
         t, h, w, _ = frames.shape
         dev = torch.from_numpy(frames).to(f"cuda:{self.engine.cfg.device}")      # tensor container only
-        for f0 in range(0, t, batch):
+        starts = list(range(0, t, batch))
+        self.engine.stream_submit(dev[0:min(batch, t)].data_ptr(), min(batch, t), h, w)
+        for n, f0 in enumerate(starts):
             b = min(batch, t - f0)
+            if n + 1 < len(starts):                     # detect the next batch while this one is tracked
+                g0 = starts[n + 1]
+                self.engine.stream_submit(dev[g0:g0 + min(batch, t - g0)].data_ptr(), min(batch, t - g0), h, w)
             rows, _ = self.engine.stream_run(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)
             for i, r in enumerate(rows):
                 for row in r:

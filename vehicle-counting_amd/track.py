@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .counting import (check_bbox_intersect_polygon, find_best_match_direction, load_zone_anno, save_tracking_to_csv)
+from .counting import find_best_match_direction, load_zone_anno, save_tracking_to_csv, zone_mask
 
 
 class DeepSort:
@@ -60,8 +60,9 @@ class VideoCounting:
         self.polygons, self.directions = load_zone_anno(zone_path)
 
     def run(self, frames, tracks, labels, boxes, output_path=None):
-        for frame_id, track_id, label_id, box in zip(frames, tracks, labels, boxes):
-            if check_bbox_intersect_polygon(self.polygons, box):
+        inside = zone_mask(self.polygons, boxes) if len(boxes) else []
+        for keep, frame_id, track_id, label_id, box in zip(inside, frames, tracks, labels, boxes):
+            if keep:                                     # check_bbox_intersect_polygon (modules/track.py:104)
                 rec = self.track_dict[label_id].setdefault(track_id, {"boxes": [], "frames": [], "color": ""})
                 rec["boxes"].append(box)
                 rec["frames"].append(frame_id)
