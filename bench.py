@@ -130,6 +130,14 @@ def main():
     eng.profile(False)
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
 
+    # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
+    # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp):
+        with open(tp) as f:
+            traffic = json.load(f)["conv_all"]["hbm_bytes_per_launch"]
+
     if rank == 0:
         out = {
             "metric": "end-to-end frames/sec (detect+NMS+ReID+track), YOLOv5s 640px",
@@ -141,7 +149,9 @@ def main():
                        "weights": "seeded synthetic (no checkpoints available)", "streams": world,
                        "counts_allgather_shape": list(all_counts.shape)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "traffic_note": "bytes per conv launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                         "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                          "kernel": "vc::conv_igemm_kernel<*> (all YOLOv5s + ReID conv launches of a step)",
                          "launches_per_step": conv["launches"] / 2, "avg_launch_us": conv["ms"] * 1e3 / max(conv["launches"], 1),
                          "algorithmic_gflop_per_step": conv["flops"] / 2 / 1e9},

@@ -72,7 +72,8 @@ struct ConvP {
     int out_cs, out_co;
     int res_cs, res_co;
     int kh, kw, sh, sw, ph, pw;
-    int K, Kp;           // kh*kw*Cin and its padding to the K tile
+    int K, Kp;           // kh*kw*Cin and the padded row length of the packed weights (multiple of conv_k_tile)
+    int Kw;              // set by launch_conv: weight row stride (= caller's Kp); Kp then becomes the K-loop extent
     int act, res_mode, out_f32, prec;
     int M;               // B*Ho*Wo
 };
