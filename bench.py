@@ -69,6 +69,7 @@ def main():
     rsd = synth_reid(1702)
     eng = E.Engine(ysd, rsd, device=local, precision="bf16", model_name="yolov5s", num_classes=NC, max_batch=B,
                    max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
+    eng.pretune()                                                               # conv autotune for every ReID size bucket
     trackers = [eng.tracker_create(**TRACK) for _ in range(NC)]
     frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank)          # one camera stream per rank
     d_frames = torch.from_numpy(frames).to(dev)                                 # resident in HBM before the timed region

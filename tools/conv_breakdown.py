@@ -5,7 +5,7 @@ import numpy as np, torch
 import vehicle_counting_amd.engine as E
 from vehicle_counting_amd.synth import synth_frames
 from vehicle_counting_amd.weights import synth_reid, synth_yolo
-B, H, W, NC = 16, 640, 640, 80
+B, H, W, NC = int(os.environ.get('VC_B', 16)), 640, 640, 80
 eng = E.Engine(synth_yolo("yolov5s", nc=NC, det_scale=4.0, obj_shift=1.0), synth_reid(), precision="bf16", num_classes=NC, max_batch=B,
                max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
 tr = [eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60) for _ in range(NC)]
@@ -17,4 +17,6 @@ lines = eng.profile_ops().strip().split("\n")
 tot = 0
 for l in lines:
     print(l); tot += float(l.split("ms=")[1].split()[0])
-print("total conv ms", tot, "launches", len(lines))
+print("total conv ms", tot, "launches", len(lines), "B", B, "conv ms per frame", tot / B)
+import vehicle_counting_amd._lib as L
+print({k: eng.profile_read(c) for k, c in (("conv", 0), ("detect_aux", 1), ("reid_aux", 2), ("track", 3))})

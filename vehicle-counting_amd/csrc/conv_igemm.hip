@@ -48,35 +48,35 @@ __device__ __forceinline__ float act_apply(float v, int act, bool precise) {
     return v;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v_cvt_pk_bf16_f32 (RNE)
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
 
-// BP x BC output tile (pixels x channels), WP x WC wavefronts, KC 16-byte chunks of K per tile row, PD = prefetch
-// distance (global loads of K tile kt+PD are issued before the MFMAs of tile kt).
+// BP x BC output tile (pixels x channels) per workgroup of WP x WC wavefronts; KC 16-byte chunks of K per tile row.
 //
-// Address generation is kept off the VALU as far as possible (the first version spent ~2000 VALU instructions per
-// wave against 144 MFMAs): both operands are fetched with raw buffer loads (SGPR descriptor + one 32-bit offset per
-// lane), padding / tile-edge / K-padding taps are turned into out-of-range offsets that the hardware answers with
-// zeros, the per-row validity of all kh*kw taps is one 64-bit mask computed once, the tap offset advances
-// incrementally, and all LDS addresses are loop invariant.
-template <int BP, int BC, int WP, int WC, int KC, int PD, bool F32>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
+// Staging: both operands go global -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA: no VGPR round trip, no ds_write).
+// One wave-instruction writes 64 lanes x 16 B = 1 KiB lane-linearly, i.e. 64/KC consecutive tile rows, so the
+// bank-conflict swizzle is applied on the SOURCE side: lane (row, c) fetches logical chunk c ^ swz(row)
+// (cdna_hip_programming.md rule 21).  Padding / tile-edge / K-padding taps become out-of-range buffer offsets that the
+// hardware answers with zeros (verified by the padded test cases); the per-row validity of all kh*kw taps is one 64-bit
+// mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
+// {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
+template <int BP, int BC, int WP, int WC, int KC, bool F32>
+__global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     constexpr int ES = F32 ? 4 : 2;           // element size
     constexpr int CH = 16 / ES;               // elements per 16-byte chunk
     constexpr int BK = KC * CH;               // K elements per tile
-    constexpr int CPT = KC / 4;               // chunks per thread per staged row
-    constexpr int XI = BP / 64;               // pixel rows staged per thread
-    constexpr int WI = (BC + 63) / 64;        // weight rows staged per thread
+    constexpr int RPI = 64 / KC;              // tile rows covered by one wave-instruction
+    constexpr int PASS = 4 * RPI;             // tile rows covered by one instruction of all four waves
+    constexpr int XI = BP / PASS;             // DMA instructions per thread for the pixel tile
+    constexpr int WI = (BC + PASS - 1) / PASS;
     constexpr int WTP = BP / WP, WTC = BC / WC;
     constexpr int PT = WTP / 16, CT = WTC / 16;
     constexpr uint32_t OOB = 0x80000000u;     // beyond every descriptor's num_records -> the load returns 0
     static_assert(WP * WC == 4, "4 waves per workgroup");
-    static_assert(BP % 64 == 0 && WTP % 16 == 0 && WTC % 16 == 0, "tile shape");
+    static_assert(BP % PASS == 0 && BC % RPI == 0 && WTP % 16 == 0 && WTC % 16 == 0, "tile shape");
     static_assert(KC == 4 || KC == 8, "K tile");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[2][(BP + BC) * KC];
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     const int n0 = (tile % tiles_c) * BC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kc0 = (tid & 3) * CPT, lrow = tid >> 2;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int prow = wave * RPI + lane / KC;                 // this thread's row inside a PASS-row slab
+    const int cpos = lane % KC;                              // physical chunk slot it fills
+    const int kc0 = KC == 4 ? (cpos ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3)) : (cpos ^ (prow & 7));   // logical chunk
     const int HoWo = p.Ho * p.Wo;
     const int ntap = p.kh * p.kw;
 
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     unsigned long long xmask[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int m = m0 + lrow + 64 * i;
+        const int m = m0 + prow + PASS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int b = mm / HoWo;
@@ -128,77 +131,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     }
     uint32_t woff[WI];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) woff[i] = (uint32_t)(((n0 + lrow + 64 * i) * p.Kw + kc0 * CH) * ES);
+    for (int i = 0; i < WI; ++i) woff[i] = (uint32_t)(((n0 + prow + PASS * i) * p.Kw + kc0 * CH) * ES);
 
-    // (tap, c) of each of this thread's chunks and the tap's byte offset (r*W + s)*in_cs*ES, advanced by BK per K step
-    int kc_c[CPT], kc_t[CPT], kc_s[CPT];
-    uint32_t kc_off[CPT];
+    // (tap, c) of this thread's chunk and the tap's byte offset (r*W + s)*in_cs*ES, advanced by BK per K step
+    int kc_c, kc_t, kc_s;
+    uint32_t kc_off;
     const uint32_t tap_x = (uint32_t)(p.in_cs * ES), tap_y = (uint32_t)((p.W - p.kw + 1) * p.in_cs * ES);
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int k = (kc0 + j) * CH;
+    {
+        const int k = kc0 * CH;
         const int tap = k / p.Cin;
         const int r = tap / p.kw;
-        kc_c[j] = k - tap * p.Cin;
-        kc_t[j] = tap;
-        kc_s[j] = tap - r * p.kw;
-        kc_off[j] = (uint32_t)((r * p.W + kc_s[j]) * p.in_cs * ES);
+        kc_c = k - tap * p.Cin;
+        kc_t = tap;
+        kc_s = tap - r * p.kw;
+        kc_off = (uint32_t)((r * p.W + kc_s) * p.in_cs * ES);
     }
     const int nk = p.Kp / BK;
 
-    // loop-invariant LDS slots
-    int xslot[XI][CPT], wslot[WI][CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) xslot[i][j] = lds_slot<KC>(lrow + 64 * i, kc0 + j);
-#pragma unroll
-        for (int i = 0; i < WI; ++i) wslot[i][j] = BP * KC + lds_slot<KC>(lrow + 64 * i, kc0 + j);
-    }
-
-    u32x4 xr[PD][XI][CPT], wr[PD][WI][CPT];
-#pragma unroll
-    for (int d = 0; d < PD; ++d) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i)
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) xr[d][i][j] = (u32x4){0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < WI; ++i)
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) wr[d][i][j] = (u32x4){0, 0, 0, 0};
-    }
-    // global -> registers for K tile `kt` into register set `set`
-#define VC_GLOAD(kt, set)                                                                                                \
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define VC_STAGE(kt, buf)                                                                                                \
     {                                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < CPT; ++j) {                                                                \
-            const uint32_t tc = kc_off[j] + (uint32_t)(kc_c[j] * ES);                                                    \
-            const int t = kc_t[j];                                                                                       \
-            _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                             \
-                const uint32_t o = ((xmask[i] >> t) & 1ull) ? xoff[i] + tc : OOB;                                        \
-                xr[set][i][j] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, (int)o, 0, 0);                               \
-            }                                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                             \
-                if (BC % 64 == 0 || lrow + 64 * i < BC)                                                                  \
-                    wr[set][i][j] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, (int)(woff[i] + (uint32_t)(((kt) * BK + j * CH) * ES)), 0, 0); \
-            }                                                                                                            \
-            int cc = kc_c[j] + BK;                                                                                       \
-            while (cc >= p.Cin) {                                                                                        \
-                cc -= p.Cin;                                                                                             \
-                ++kc_t[j];                                                                                               \
-                if (++kc_s[j] == p.kw) { kc_s[j] = 0; kc_off[j] += tap_y; } else { kc_off[j] += tap_x; }                 \
-            }                                                                                                            \
-            kc_c[j] = cc;                                                                                                \
+        const uint32_t tc = kc_off + (uint32_t)(kc_c * ES);                                                              \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                 \
+            const uint32_t o = ((xmask[i] >> kc_t) & 1ull) ? xoff[i] + tc : OOB;                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[buf][(PASS * i + uwave * RPI) * KC], 16, (int)o, 0, 0, 0); \
         }                                                                                                                \
-    }
-#define VC_LSTORE(buf, set)                                                                                              \
-    {                                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < CPT; ++j) {                                                                \
-            _Pragma("unroll") for (int i = 0; i < XI; ++i) lds[buf][xslot[i][j]] = __builtin_bit_cast(uint4, xr[set][i][j]); \
-            _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                             \
-                if (BC % 64 == 0 || lrow + 64 * i < BC) lds[buf][wslot[i][j]] = __builtin_bit_cast(uint4, wr[set][i][j]); \
-            }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                                 \
+            if (BC % PASS == 0 || PASS * i + uwave * RPI < BC)                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[buf][BP * KC + (PASS * i + uwave * RPI) * KC], 16, \
+                                                         (int)(woff[i] + (uint32_t)((kt) * BK * ES)), 0, 0, 0);         \
         }                                                                                                                \
+        int cc = kc_c + BK;                                                                                              \
+        while (cc >= p.Cin) {                                                                                            \
+            cc -= p.Cin;                                                                                                 \
+            ++kc_t;                                                                                                      \
+            if (++kc_s == p.kw) { kc_s = 0; kc_off += tap_y; } else { kc_off += tap_x; }                                 \
+        }                                                                                                                \
+        kc_c = cc;                                                                                                       \
     }
 
     f32x4 acc[CT][PT];
@@ -209,53 +178,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
 
     const int wp = wave % WP, wc = wave / WP;
     const int frow = lane & 15, fch = lane >> 4;
-    int xfrag[CPT][PT], wfrag[CPT][CT];
+    int xfrag[KC / 4][PT], wfrag[KC / 4][CT];
 #pragma unroll
-    for (int h = 0; h < CPT; ++h) {
+    for (int h = 0; h < KC / 4; ++h) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) xfrag[h][i] = lds_slot<KC>(wp * WTP + i * 16 + frow, h * 4 + fch);
 #pragma unroll
         for (int i = 0; i < CT; ++i) wfrag[h][i] = BP * KC + lds_slot<KC>(wc * WTC + i * 16 + frow, h * 4 + fch);
     }
 
-    // prologue: tiles 0 .. PD-1 in flight, tile 0 staged
-#pragma unroll
-    for (int d = 0; d < PD; ++d)
-        if (d < nk) VC_GLOAD(d, d);
-    VC_LSTORE(0, 0);
+    VC_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) VC_STAGE(kt + 1, buf ^ 1);      // DMA of the next tile runs under this tile's MFMAs
 #pragma unroll
-        for (int d = 0; d < PD; ++d) {                // register set indices are compile-time constants
-            const int kt = kt0 + d;
-            if (kt < nk) {
-                const int buf = kt & 1;
-                if (kt + PD < nk) VC_GLOAD(kt + PD, d);       // set d held tile kt, which is already in LDS
+        for (int h = 0; h < KC / 4; ++h) {
+            Chunk xa[PT], wa[CT];
 #pragma unroll
-                for (int h = 0; h < CPT; ++h) {               // one MFMA K-step (4 chunks) per half of the tile row
-                    Chunk xa[PT], wa[CT];
+            for (int i = 0; i < PT; ++i) xa[i].u = lds[buf][xfrag[h][i]];
 #pragma unroll
-                    for (int i = 0; i < PT; ++i) xa[i].u = lds[buf][xfrag[h][i]];
+            for (int i = 0; i < CT; ++i) wa[i].u = lds[buf][wfrag[h][i]];
 #pragma unroll
-                    for (int i = 0; i < CT; ++i) wa[i].u = lds[buf][wfrag[h][i]];
+            for (int a = 0; a < CT; ++a)
 #pragma unroll
-                    for (int a = 0; a < CT; ++a)
+                for (int b = 0; b < PT; ++b) {
+                    if constexpr (F32) {
 #pragma unroll
-                        for (int b = 0; b < PT; ++b) {
-                            if constexpr (F32) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a].f[j], xa[b].f[j], acc[a][b], 0, 0, 0);
-                            } else {
-                                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[a].h, xa[b].h, acc[a][b], 0, 0, 0);
-                            }
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a].f[j], xa[b].f[j], acc[a][b], 0, 0, 0);
+                    } else {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[a].h, xa[b].h, acc[a][b], 0, 0, 0);
+                    }
                 }
-                if (kt + 1 < nk) VC_LSTORE(buf ^ 1, (d + 1) % PD);
-                __syncthreads();
-            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
+#undef VC_STAGE
 
     // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]
     const int nbase = n0 + wc * WTC + fch * 4;
@@ -310,43 +271,67 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     }
 }
 
-#undef VC_GLOAD
-#undef VC_LSTORE
-
 int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights are padded to the widest K tile (KC = 8)
 
 double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * (double)p.K; }
 
-template <int BP, int BC, int WP, int WC, int KC, int PD>
-static int launch_cfg(ConvP p, hipStream_t s) {
+// ---- tile configurations -------------------------------------------------------------------------------------------
+struct ConvCfg { int bp, bc, wp, wc, kc; };
+static const ConvCfg kCfg[] = {
+    {256, 32, 4, 1, 4},  {128, 64, 2, 2, 4},  {128, 128, 2, 2, 4}, {64, 64, 2, 2, 4},   {128, 64, 2, 2, 8},
+    {128, 128, 2, 2, 8}, {64, 64, 2, 2, 8},   {256, 64, 4, 1, 4},  {256, 64, 4, 1, 8},  {256, 128, 2, 2, 4},
+    {256, 128, 2, 2, 8}, {64, 128, 1, 4, 4},  {64, 128, 1, 4, 8},  {256, 32, 4, 1, 8},
+};
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])); }
+
+template <int BP, int BC, int WP, int WC, int KC>
+static int launch_one(ConvP p, hipStream_t s) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const int bk = KC * (p.prec == PREC_F32 ? 4 : 8);
     p.Kw = p.Kp;                              // weight row stride as packed
     p.Kp = (p.K + bk - 1) / bk * bk;          // K-loop extent: only the tiles that hold real taps
-    if (p.prec == PREC_F32)
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, 1, true>), dim3(tiles), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, PD, false>), dim3(tiles), dim3(256), 0, s, p);
+    if (p.prec == PREC_F32) hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, true>), dim3(tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, false>), dim3(tiles), dim3(256), 0, s, p);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
 
-template <int BP, int BC, int WP, int WC>
-static int launch_kc(const ConvP& p, hipStream_t s) {
-    // wide K tile (half the barriers per MFMA) unless its zero padding would waste more than 1/8 of the K loop
-    const int ch = p.prec == PREC_F32 ? 4 : 8;
-    const int k8 = (p.K + 8 * ch - 1) / (8 * ch) * (8 * ch);
-    static const int force_kc = getenv("VC_CONV_KC") ? atoi(getenv("VC_CONV_KC")) : 0;      // tuning knobs (bench only)
-    static const int pd = getenv("VC_CONV_PD") ? atoi(getenv("VC_CONV_PD")) : 1;
-    const bool wide = force_kc ? force_kc == 8 : false;
-    (void)k8;
-    if (wide) return pd >= 2 ? launch_cfg<BP, BC, WP, WC, 8, 2>(p, s) : launch_cfg<BP, BC, WP, WC, 8, 1>(p, s);
-    if (pd >= 3) return launch_cfg<BP, BC, WP, WC, 4, 3>(p, s);
-    if (pd == 2) return launch_cfg<BP, BC, WP, WC, 4, 2>(p, s);
-    return launch_cfg<BP, BC, WP, WC, 4, 1>(p, s);
+static int conv_heuristic(const ConvP& p) {
+    // narrow layers get tall pixel tiles; late (small-M) layers get small tiles so the grid still covers 256 CUs
+    if (p.Cout <= 32) return 0;
+    if (p.Cout <= 64) return 1;
+    const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    return t128 >= 512 ? 2 : 3;
 }
 
+int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
+    if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
+    switch (cfg) {
+        case 0: return launch_one<256, 32, 4, 1, 4>(p, s);
+        case 1: return launch_one<128, 64, 2, 2, 4>(p, s);
+        case 2: return launch_one<128, 128, 2, 2, 4>(p, s);
+        case 3: return launch_one<64, 64, 2, 2, 4>(p, s);
+        case 4: return launch_one<128, 64, 2, 2, 8>(p, s);
+        case 5: return launch_one<128, 128, 2, 2, 8>(p, s);
+        case 6: return launch_one<64, 64, 2, 2, 8>(p, s);
+        case 7: return launch_one<256, 64, 4, 1, 4>(p, s);
+        case 8: return launch_one<256, 64, 4, 1, 8>(p, s);
+        case 9: return launch_one<256, 128, 2, 2, 4>(p, s);
+        case 10: return launch_one<256, 128, 2, 2, 8>(p, s);
+        case 11: return launch_one<64, 128, 1, 4, 4>(p, s);
+        case 12: return launch_one<64, 128, 1, 4, 8>(p, s);
+        default: return launch_one<256, 32, 4, 1, 8>(p, s);
+    }
+}
+
+int conv_check(const ConvP& p);
+
 int launch_conv(const ConvP& p, hipStream_t s) {
+    VC_TRY(conv_check(p));
+    return launch_conv_cfg(p, p.cfg, s);
+}
+
+int conv_check(const ConvP& p) {
     const int ch = p.prec == PREC_F32 ? 4 : 8;
     VC_CHECK(p.Cin % ch == 0 && p.in_cs % ch == 0 && p.in_co % ch == 0, VC_ERR_ARG,
              "conv: input channels/stride/offset (%d,%d,%d) must be multiples of %d", p.Cin, p.in_cs, p.in_co, ch);
@@ -357,12 +342,7 @@ int launch_conv(const ConvP& p, hipStream_t s) {
     VC_CHECK((size_t)p.B * p.H * p.W * p.in_cs * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: input tensor exceeds the 2 GiB buffer descriptor");
     VC_CHECK((size_t)((p.Cout + 127) / 128 * 128) * p.Kp * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: weights exceed 2 GiB");
     VC_CHECK(p.kh * p.kw <= 40, VC_ERR_ARG, "conv: at most 40 taps (validity mask is 64 bits incl. K padding)");
-    // tile choice: narrow layers get tall pixel tiles; late (small-M) layers get 64x64 so the grid still covers 256 CUs
-    if (p.Cout <= 32) return launch_kc<256, 32, 4, 1>(p, s);
-    if (p.Cout <= 64) return launch_kc<128, 64, 2, 2>(p, s);
-    const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-    if (t128 >= 512) return launch_kc<128, 128, 2, 2>(p, s);
-    return launch_kc<64, 64, 2, 2>(p, s);
+    return VC_OK;
 }
 
 }  // namespace vc

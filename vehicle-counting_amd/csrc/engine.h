@@ -120,6 +120,8 @@ struct vc_engine {
     bool profiling = false;
     vc::ProfCat prof[VC_PROF_NCAT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::pair<const void*, long>, int> tuned;   // conv autotune cache: (weights, size bucket) -> tile config
+    bool profiling_tune_off = false;
     std::string op_log;                          // per-launch lines "name M N K tile ms" while profiling
     double last_ms = 0;
 

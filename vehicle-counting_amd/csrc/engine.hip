@@ -144,6 +144,7 @@ struct PlanBuilder {
         c.act = act; c.res_mode = res_mode; c.out_f32 = out_f32 ? 1 : 0; c.prec = prec;
         if (res) { c.res = res->ptr; c.res_cs = res->cs; c.res_co = res->co; }
         c.M = c.B * c.Ho * c.Wo;
+        c.cfg = -1;
         op.C = cp.I * cp.kh * cp.kw;          // logical K for algorithmic FLOPs
         ops->push_back(op);
         out.B = in.B; out.H = c.Ho; out.W = c.Wo; out.C = cp.O;
@@ -320,6 +321,36 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     return pb.status;
 }
 
+// Pick the fastest tile configuration for a conv launch by timing every candidate once per (layer, problem-size bucket).
+// Results are identical across configurations (same K order, fp32 accumulate), so tuning never changes the numerics.
+static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
+    static const bool enabled = !(getenv("VC_AUTOTUNE") && atoi(getenv("VC_AUTOTUNE")) == 0);
+    if (!enabled || e->profiling_tune_off) return -1;
+    int bucket = 1;
+    while (bucket < c.M) bucket <<= 1;
+    const auto key = std::make_pair(c.w, ((long)bucket << 20) ^ ((long)c.H << 10) ^ c.W);
+    auto it = e->tuned.find(key);
+    if (it != e->tuned.end()) return it->second;
+    int best = -1;
+    float best_ms = 1e30f;
+    for (int cfg = 0; cfg < conv_num_cfgs(); ++cfg) {
+        if (launch_conv_cfg(c, cfg, s) != VC_OK) continue;          // warm-up (instruction cache, L2)
+        float tmin = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e->ev0, s);
+            launch_conv_cfg(c, cfg, s);
+            hipEventRecord(e->ev1, s);
+            hipEventSynchronize(e->ev1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e->ev0, e->ev1);
+            tmin = std::min(tmin, ms);
+        }
+        if (tmin < best_ms) { best_ms = tmin; best = cfg; }
+    }
+    e->tuned[key] = best;
+    return best;
+}
+
 static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStream_t s) {
     for (const Op& op : ops) {
         switch (op.kind) {
@@ -328,15 +359,17 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 const double es = elem_size(op.conv.prec);
                 const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
+                ConvP cp = op.conv;
+                cp.cfg = tuned_cfg(e, cp, s);
                 {
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
-                    VC_TRY(launch_conv(op.conv, s));
+                    VC_TRY(launch_conv(cp, s));
                 }
                 if (e->profiling && e->op_log.size() < (1u << 20)) {
                     char line[256];
                     const ConvP& c = op.conv;
-                    snprintf(line, sizeof(line), "%s M=%d N=%d K=%d k=%dx%d s=%d ms=%.4f tflops=%.1f\n", c.M > 0 ? "conv" : "?", c.M, c.Cout, c.K,
-                             c.kh, c.kw, c.sh, e->last_ms, fl / (e->last_ms * 1e-3) / 1e12);
+                    snprintf(line, sizeof(line), "%s M=%d N=%d K=%d k=%dx%d s=%d cfg=%d ms=%.4f tflops=%.1f\n", c.M > 0 ? "conv" : "?", c.M, c.Cout, c.K,
+                             c.kh, c.kw, c.sh, cp.cfg, e->last_ms, fl / (e->last_ms * 1e-3) / 1e12);
                     e->op_log += line;
                 }
                 break;
@@ -810,6 +843,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         c.kh = d->kh; c.kw = d->kw; c.sh = c.sw = d->stride; c.ph = c.pw = d->pad;
         c.K = p.K; c.Kp = p.Kp; c.act = d->act; c.res_mode = res ? d->res_mode : RES_NONE; c.out_f32 = 0; c.prec = prec;
         c.M = d->b * Ho * Wo;
+        c.cfg = getenv("VC_CONV_CFG") ? atoi(getenv("VC_CONV_CFG")) : -1;
         st = launch_conv(c, nullptr);
         if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
     }

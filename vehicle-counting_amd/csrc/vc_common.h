@@ -76,9 +76,12 @@ struct ConvP {
     int Kw;              // set by launch_conv: weight row stride (= caller's Kp); Kp then becomes the K-loop extent
     int act, res_mode, out_f32, prec;
     int M;               // B*Ho*Wo
+    int cfg;             // tile configuration index (conv_igemm.hip kCfg), -1 = heuristic
 };
 
 int launch_conv(const ConvP& p, hipStream_t s);
+int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument checks: for the autotuner
+int conv_num_cfgs();
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
 double conv_flops(const ConvP& p);
 

@@ -117,6 +117,13 @@ class Engine:
         L.check(L.lib().vc_embed_tensor(self._h, L.ptr(x, C.c_float), len(x), L.ptr(out, C.c_float)))
         return out
 
+    def pretune(self, crop_counts=(32, 64, 128, 256, 512, 1024)):
+        """Run the ReID net once per problem-size bucket so the conv autotuner (engine.hip::tuned_cfg) has picked its tile
+        configurations before any timed work; the detector's convs are tuned by the first (warm-up) batch."""
+        for k in crop_counts:
+            if k <= self.cfg.max_crops and self.cfg.with_reid:
+                self.embed_tensor(np.zeros((k, 3, 50, 50), np.float32))
+
     # ---------------------------------------------------------------- tracker
     def tracker_create(self, max_dist=0.2, min_confidence=0.3, nms_max_overlap=1.0, max_iou_distance=0.7, max_age=70,
                        n_init=3, nn_budget=100):
