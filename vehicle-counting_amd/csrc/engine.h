@@ -108,10 +108,11 @@ struct vc_engine {
     std::vector<int> free_slots;
     std::vector<std::unique_ptr<vc::Tracker>> trackers;
     // per-step scratch: one pinned staging block mirrored on the device, cost matrices, posterior means
-    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0;     // phase A block
-    char* h_stage2 = nullptr; char* d_stage2 = nullptr;                          // phase B block
-    double* h_cost = nullptr; double* d_cost = nullptr;
-    double* h_mean = nullptr; double* d_mean_out = nullptr;
+    // pinned + device-mapped (hd_* = device alias): phase A block, phase B block, cost rows, posterior means
+    char* h_stage = nullptr; char* hd_stage = nullptr; size_t stage_cap = 0;
+    char* h_stage2 = nullptr; char* hd_stage2 = nullptr;
+    double* h_cost = nullptr; double* hd_cost = nullptr;
+    double* h_mean = nullptr; double* hd_mean = nullptr;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
     size_t cost_cap = 0;
     int det_cap = 0;
@@ -155,7 +156,7 @@ struct StepCtx {
     // phase A products
     int n_dets = 0, n_app = 0, n_iou = 0;
     size_t out = 0;
-    std::vector<int> det_base, job_out, featrow;
+    std::vector<int> det_base, featrow;
     std::vector<std::vector<int>> app_job, iou_job;
     std::vector<double> det_xyah;
     // phase B products

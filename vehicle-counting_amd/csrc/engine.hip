@@ -32,7 +32,7 @@ int dev_alloc(vc_engine* e, void** p, size_t bytes) {
 }
 int host_alloc(vc_engine* e, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    VC_HIP(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    VC_HIP(hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocPortable));
     e->host_allocs.push_back(*p);
     return VC_OK;
 }

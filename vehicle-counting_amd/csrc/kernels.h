@@ -88,6 +88,12 @@ struct CostJob {
     int out_off;     // offset into the output cost array
     int tsu;         // time since update (IoU rows with tsu > 1 are filled with 1e5)
 };
+// fused per-frame tracker kernels (one launch per phase; descriptors and results may live in host-mapped pinned memory)
+struct TrackJobA { int slot, gal_count, det_off, det_n, app_off, iou_off, tsu, pad; };          // app_off / iou_off < 0: no such row
+struct TrackOpB { int slot, kind, gal_pos, feat_row, out_row, pad0, pad1, pad2; double z[4]; }; // kind 0 none, 1 update, 2 initiate
+int launch_track_phase_a(const TrackPool& tp, const TrackJobA* jobs, int njobs, const float* feat, const int* det_feat_row,
+                         const double* det_xyah, const double* det_tlwh, double* out, hipStream_t s);
+int launch_track_phase_b(const TrackPool& tp, const TrackOpB* ops, int nops, const float* feat, double* mean_out, hipStream_t s);
 // appearance cost (min cosine distance over the gallery) with Mahalanobis gating folded in:
 //   out[out_off + i] = gate(slot, det i) > 9.4877 ? 1e5 : min_s (1 - <g_s/|g_s|, f_i/|f_i|>)
 // feature of detection g (global index det_off + i) is feat[det_feat_row[g]]

@@ -23,12 +23,7 @@ namespace vc {
 #define VC_CHI2_95_4 9.4877
 #define VC_GATED 1e5
 
-__global__ __launch_bounds__(64) void kalman_initiate_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double* m = tp.mean + (size_t)slots[i] * 8;
-    double* P = tp.cov + (size_t)slots[i] * 64;
-    const double* z = xyah + (size_t)i * 4;
+__device__ __forceinline__ void kalman_initiate_dev(double* m, double* P, const double* z) {
     const double h = z[3];
     for (int k = 0; k < 4; ++k) { m[k] = z[k]; m[4 + k] = 0.0; }
     const double sp = (2 * VC_W_POS) * h, sv = (10 * VC_W_VEL) * h;
@@ -37,11 +32,13 @@ __global__ __launch_bounds__(64) void kalman_initiate_kernel(TrackPool tp, const
         for (int c = 0; c < 8; ++c) P[r * 8 + c] = r == c ? sd[r] * sd[r] : 0.0;
 }
 
-__global__ __launch_bounds__(64) void kalman_predict_kernel(TrackPool tp, const int* slots, int n) {
+__global__ __launch_bounds__(64) void kalman_initiate_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double* m = tp.mean + (size_t)slots[i] * 8;
-    double* P = tp.cov + (size_t)slots[i] * 64;
+    kalman_initiate_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64, xyah + (size_t)i * 4);
+}
+
+__device__ __forceinline__ void kalman_predict_dev(double* m, double* P) {
     const double h = m[3];
     const double sp = VC_W_POS * h, sv = VC_W_VEL * h;
     const double sd[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
@@ -57,6 +54,12 @@ __global__ __launch_bounds__(64) void kalman_predict_kernel(TrackPool tp, const 
             P[r * 8 + c] = v;
         }
     for (int k = 0; k < 4; ++k) m[k] = m[k] + m[k + 4];
+}
+
+__global__ __launch_bounds__(64) void kalman_predict_kernel(TrackPool tp, const int* slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    kalman_predict_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64);
 }
 
 // S = H P H^T + R (4x4), projected mean = mean[:4]
@@ -82,12 +85,7 @@ __device__ __forceinline__ void chol4(const double S[16], double L[16]) {
     }
 }
 
-__global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double* m = tp.mean + (size_t)slots[i] * 8;
-    double* P = tp.cov + (size_t)slots[i] * 64;
-    const double* z = xyah + (size_t)i * 4;
+__device__ __forceinline__ void kalman_update_dev(double* m, double* P, const double* z) {
     double S[16], L[16], K[32];
     project4(m, P, S);
     chol4(S, L);
@@ -130,6 +128,12 @@ __global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const i
     for (int r = 0; r < 8; ++r) m[r] = nm[r];
 }
 
+__global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    kalman_update_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64, xyah + (size_t)i * 4);
+}
+
 __device__ __forceinline__ double maha4(const double* m, const double L[16], const double* z) {
     double y[4], acc = 0.0;
     for (int a = 0; a < 4; ++a) {
@@ -142,10 +146,9 @@ __device__ __forceinline__ double maha4(const double* m, const double L[16], con
 }
 
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
-__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* __restrict__ feat,
-                                                              const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
-                                                              double* __restrict__ out) {
-    const CostJob jb = jobs[blockIdx.x];
+__device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const CostJob& jb, const float* __restrict__ feat,
+                                                   const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
+                                                   double* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* m = tp.mean + (size_t)jb.slot * 8;
     const double* P = tp.cov + (size_t)jb.slot * 64;
@@ -177,6 +180,12 @@ __global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, cons
     }
 }
 
+__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* __restrict__ feat,
+                                                              const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
+                                                              double* __restrict__ out) {
+    appearance_row_dev(tp, jobs[blockIdx.x], feat, det_feat_row, det_xyah, out);
+}
+
 __device__ __forceinline__ double iou_tlwh(const double* b, const double* c);
 __device__ __forceinline__ void mean_to_tlwh(const double* m, double t[4]) {
     t[2] = m[2] * m[3];
@@ -201,6 +210,60 @@ __global__ __launch_bounds__(128) void gallery_write_kernel(TrackPool tp, const 
     float* dst = tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM;
     const float* src = feat + (size_t)e[2] * VC_FEAT_DIM;
     ((float4*)dst)[threadIdx.x] = ((const float4*)src)[threadIdx.x];
+}
+
+// ---- fused per-frame kernels (tracker.hip: track_phase_a / track_phase_b) ------------------------------------------
+// Phase A, one workgroup per live track of the stepped trackers: Kalman predict in place, then (confirmed tracks) the
+// appearance + gate row and (IoU candidates) the IoU row against the track's tracker's detections.  Inputs are read from
+// and results written to host-mapped pinned memory, so a phase is ONE kernel launch and no copy operations.
+__global__ __launch_bounds__(256) void track_phase_a_kernel(TrackPool tp, const TrackJobA* __restrict__ jobs, const float* __restrict__ feat,
+                                                            const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
+                                                            const double* __restrict__ det_tlwh, double* __restrict__ out) {
+    const TrackJobA jb = jobs[blockIdx.x];
+    if (threadIdx.x == 0) kalman_predict_dev(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64);
+    __syncthreads();
+    if (jb.app_off >= 0) {
+        const CostJob cj{jb.slot, jb.gal_count, jb.det_off, jb.det_n, jb.app_off, jb.tsu};
+        appearance_row_dev(tp, cj, feat, det_feat_row, det_xyah, out);
+    }
+    if (jb.iou_off >= 0) {
+        double b[4];
+        mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
+        for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x)
+            out[jb.iou_off + d] = jb.tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, det_tlwh + (size_t)(jb.det_off + d) * 4);
+    }
+}
+
+// Phase B, one workgroup per track operation: Kalman update (kind 1) or initiate (kind 2) or nothing (kind 0), the
+// gallery ring write of the matched / initial feature, and the posterior mean of output-eligible tracks to the host.
+__global__ __launch_bounds__(128) void track_phase_b_kernel(TrackPool tp, const TrackOpB* __restrict__ ops, const float* __restrict__ feat,
+                                                            double* __restrict__ mean_out) {
+    const TrackOpB op = ops[blockIdx.x];
+    double* m = tp.mean + (size_t)op.slot * 8;
+    if (threadIdx.x == 0) {
+        if (op.kind == 1) kalman_update_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+        else if (op.kind == 2) kalman_initiate_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+    }
+    if (op.feat_row >= 0) {
+        float* dst = tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM;
+        ((float4*)dst)[threadIdx.x] = ((const float4*)(feat + (size_t)op.feat_row * VC_FEAT_DIM))[threadIdx.x];
+    }
+    __syncthreads();
+    if (op.out_row >= 0 && threadIdx.x < 8) mean_out[(size_t)op.out_row * 8 + threadIdx.x] = m[threadIdx.x];
+}
+
+int launch_track_phase_a(const TrackPool& tp, const TrackJobA* jobs, int njobs, const float* feat, const int* det_feat_row,
+                         const double* det_xyah, const double* det_tlwh, double* out, hipStream_t s) {
+    if (njobs <= 0) return VC_OK;
+    hipLaunchKernelGGL(track_phase_a_kernel, dim3(njobs), dim3(256), 0, s, tp, jobs, feat, det_feat_row, det_xyah, det_tlwh, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+int launch_track_phase_b(const TrackPool& tp, const TrackOpB* ops, int nops, const float* feat, double* mean_out, hipStream_t s) {
+    if (nops <= 0) return VC_OK;
+    hipLaunchKernelGGL(track_phase_b_kernel, dim3(nops), dim3(128), 0, s, tp, ops, feat, mean_out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
 }
 
 __device__ __forceinline__ double iou_tlwh(const double* b, const double* c) {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <map>
 #include <numeric>
 
 #include "engine.h"
@@ -157,14 +158,16 @@ int tracker_init_pool(vc_engine* e) {
     // one pinned staging block per phase, mirrored on the device: a phase costs ONE host->device copy
     e->stage_cap = align16((T + D) * 4) + 2 * align16(D * 32) + align16(2 * T * sizeof(CostJob)) +      // phase A
                    2 * align16(T * 4) + 2 * align16((T + D) * 32) + align16((T + D) * 12) + 256;          // phase B (superset)
+    e->stage_cap = std::max(e->stage_cap, (T + D) * sizeof(TrackOpB) + 256);
+    // pinned + device-mapped: the per-frame kernels read their descriptors from and write their results to host memory
     VC_TRY(host_alloc(e, (void**)&e->h_stage, e->stage_cap));
-    VC_TRY(dev_alloc(e, (void**)&e->d_stage, e->stage_cap));
     VC_TRY(host_alloc(e, (void**)&e->h_stage2, e->stage_cap));
-    VC_TRY(dev_alloc(e, (void**)&e->d_stage2, e->stage_cap));
     VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));
-    VC_TRY(dev_alloc(e, (void**)&e->d_cost, e->cost_cap * sizeof(double)));
     VC_TRY(host_alloc(e, (void**)&e->h_mean, T * 8 * sizeof(double)));
-    VC_TRY(dev_alloc(e, (void**)&e->d_mean_out, T * 8 * sizeof(double)));
+    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_stage, e->h_stage, 0));
+    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_stage2, e->h_stage2, 0));
+    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_cost, e->h_cost, 0));
+    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_mean, e->h_mean, 0));
     VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, D * VC_FEAT_DIM * sizeof(float)));
     return VC_OK;
 }
@@ -205,19 +208,15 @@ int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat) {
     }
     const int n_dets = c.n_dets;
     VC_CHECK(n_dets <= e->det_cap, VC_ERR_CAPACITY, "%d detections in one step exceed capacity %d", n_dets, e->det_cap);
-    Stage st{e->h_stage, e->d_stage, e->stage_cap};
-    int *d_slots, *d_featrow; double *d_xyah, *d_tlwh; CostJob* d_jobs;
-    int* h_slots = st.take<int>(n_tracks, &d_slots);
+    // descriptors + detections go into the pinned, device-mapped staging block: the kernel reads them over the host link
+    // (a few hundred bytes) and writes the cost rows straight into pinned memory -- no copy operations in the phase
+    Stage st{e->h_stage, e->hd_stage, e->stage_cap};
+    int* d_featrow; double *d_xyah, *d_tlwh; TrackJobA* d_jobs;
     int* h_featrow = st.take<int>(n_dets, &d_featrow);
     double* h_xyah = st.take<double>((size_t)n_dets * 4, &d_xyah);
     double* h_tlwh = st.take<double>((size_t)n_dets * 4, &d_tlwh);
-    CostJob* h_jobs = st.take<CostJob>((size_t)2 * n_tracks, &d_jobs);
+    TrackJobA* h_jobs = st.take<TrackJobA>(n_tracks, &d_jobs);
     VC_CHECK(st.off <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
-    {
-        int q = 0;
-        for (int j = 0; j < njobs; ++j)
-            for (TrackRec& t : e->trackers[c.ids[j]]->tracks) { h_slots[q++] = t.slot; t.age += 1; t.tsu += 1; }   // sort/track.py:112-124
-    }
     for (int j = 0; j < njobs; ++j) {
         const Prepared& p = c.prep[j];
         for (size_t i = 0; i < p.conf.size(); ++i) {
@@ -227,55 +226,45 @@ int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat) {
             h_featrow[g] = p.feat_rows[i];
         }
     }
-    // cost jobs: appearance rows for confirmed tracks, IoU rows for every possible IoU candidate, each over all of its tracker's dets
-    c.n_app = c.n_iou = 0;
+    // one job per live track: Kalman predict + (confirmed) appearance row + (IoU candidate) IoU row over its tracker's dets
     c.out = 0;
     c.app_job.assign(njobs, {});
     c.iou_job.assign(njobs, {});
+    int q = 0;
     for (int j = 0; j < njobs; ++j) {
         Tracker& tk = *e->trackers[c.ids[j]];
         const int k = (int)c.prep[j].conf.size();
-        if (k == 0) continue;
         c.app_job[j].assign(tk.tracks.size(), -1);
-        for (size_t t = 0; t < tk.tracks.size(); ++t) {
-            const TrackRec& tr = tk.tracks[t];
-            if (tr.state != CONFIRMED) continue;
-            h_jobs[c.n_app] = CostJob{tr.slot, tr.gal_count, c.det_base[j], k, (int)c.out, tr.tsu};
-            c.app_job[j][t] = c.n_app++;
-            c.out += k;
-        }
-    }
-    for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[c.ids[j]];
-        const int k = (int)c.prep[j].conf.size();
-        if (k == 0) continue;
         c.iou_job[j].assign(tk.tracks.size(), -1);
         for (size_t t = 0; t < tk.tracks.size(); ++t) {
-            const TrackRec& tr = tk.tracks[t];
-            if (tr.state == CONFIRMED && tr.tsu != 1) continue;       // never an IoU candidate (sort/tracker.py:118-120)
-            h_jobs[c.n_app + c.n_iou] = CostJob{tr.slot, 0, c.det_base[j], k, (int)c.out, tr.tsu};
-            c.iou_job[j][t] = c.n_app + c.n_iou++;
-            c.out += k;
+            TrackRec& tr = tk.tracks[t];
+            tr.age += 1; tr.tsu += 1;                                      // sort/track.py:112-124
+            TrackJobA jb{tr.slot, tr.gal_count, c.det_base[j], k, -1, -1, tr.tsu, 0};
+            if (k > 0 && tr.state == CONFIRMED) { jb.app_off = (int)c.out; c.app_job[j][t] = jb.app_off; c.out += k; }
+            if (k > 0 && !(tr.state == CONFIRMED && tr.tsu != 1)) {         // IoU candidates only (sort/tracker.py:118-120)
+                jb.iou_off = (int)c.out; c.iou_job[j][t] = jb.iou_off; c.out += k;
+            }
+            h_jobs[q++] = jb;
         }
     }
     VC_CHECK(c.out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", c.out, e->cost_cap);
     c.det_xyah.assign(h_xyah, h_xyah + (size_t)n_dets * 4);
     c.featrow.assign(h_featrow, h_featrow + n_dets);
-    c.job_out.resize(c.n_app + c.n_iou);
-    for (int i = 0; i < c.n_app + c.n_iou; ++i) c.job_out[i] = h_jobs[i].out_off;
-    if (st.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage, e->h_stage, st.off, hipMemcpyHostToDevice, s));
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_predict(e->pool, d_slots, n_tracks, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_appearance_cost(e->pool, d_jobs, c.n_app, d_feat, d_featrow, d_xyah, e->d_cost, s)); }
-    { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_iou_cost(e->pool, d_jobs + c.n_app, c.n_iou, d_tlwh, e->d_cost, s)); }
-    if (c.out > 0) VC_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, c.out * sizeof(double), hipMemcpyDeviceToHost, s));
+    { ProfScope ps(e, VC_PROF_TRACK);
+      VC_TRY(launch_track_phase_a(e->pool, d_jobs, n_tracks, d_feat, d_featrow, d_xyah, d_tlwh, e->hd_cost, s)); }
     return VC_OK;
 }
 
 int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
     hipStream_t s = e->stream;
     const int njobs = (int)c.ids.size();
-    std::vector<int> upd_slots, new_slots, sps;
-    std::vector<double> upd_xyah, new_xyah;
+    std::vector<TrackOpB> ops;                       // one per updated / initiated / output-only track
+    auto add_op = [&](int slot, int kind, const double* z, int gal_pos, int feat_row) {
+        TrackOpB op{};
+        op.slot = slot; op.kind = kind; op.gal_pos = gal_pos; op.feat_row = feat_row; op.out_row = -1;
+        if (z) memcpy(op.z, z, 4 * sizeof(double));
+        ops.push_back(op);
+    };
     for (int j = 0; j < njobs; ++j) {
         Tracker& tk = *e->trackers[c.ids[j]];
         const Prepared& pr = c.prep[j];
@@ -295,7 +284,7 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
             for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
             if (lvl.empty()) continue;
             std::vector<const double*> rp;
-            for (int t : lvl) rp.push_back(e->h_cost + c.job_out[c.app_job[j][t]]);
+            for (int t : lvl) rp.push_back(e->h_cost + c.app_job[j][t]);
             VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
             for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
             left = mo.un_cols;
@@ -307,7 +296,7 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
         for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
         {
             std::vector<const double*> rp;
-            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + c.job_out[c.iou_job[j][t]]);
+            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + c.iou_job[j][t]);
             else rp.assign(cand.size(), nullptr);
             VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
         }
@@ -319,9 +308,7 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
         for (auto& m : matches) {
             TrackRec& tr = tk.tracks[m.first];
             const int g = c.det_base[j] + m.second;
-            upd_slots.push_back(tr.slot);
-            upd_xyah.insert(upd_xyah.end(), &c.det_xyah[(size_t)g * 4], &c.det_xyah[(size_t)g * 4] + 4);
-            sps.push_back(tr.slot); sps.push_back(tr.gal_head); sps.push_back(c.featrow[g]);
+            add_op(tr.slot, 1, &c.det_xyah[(size_t)g * 4], tr.gal_head, c.featrow[g]);
             tr.gal_head = (tr.gal_head + 1) % tk.p.nn_budget;
             tr.gal_count = std::min(tr.gal_count + 1, tk.p.nn_budget);
             tr.last_conf = pr.conf[m.second];
@@ -341,9 +328,7 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
             tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
             tr.slot = e->free_slots.back(); e->free_slots.pop_back();
             const int g = c.det_base[j] + d;
-            new_slots.push_back(tr.slot);
-            new_xyah.insert(new_xyah.end(), &c.det_xyah[(size_t)g * 4], &c.det_xyah[(size_t)g * 4] + 4);
-            sps.push_back(tr.slot); sps.push_back(0); sps.push_back(c.featrow[g]);
+            add_op(tr.slot, 2, &c.det_xyah[(size_t)g * 4], 0, c.featrow[g]);
             tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
             tr.last_conf = pr.conf[d];
             tk.tracks.push_back(tr);
@@ -356,42 +341,30 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
         }
         tk.tracks.swap(alive);
     }
-    // second staging block: update list, initiate list, gallery writes, slots whose posterior means go back to the host
-    Stage sb{e->h_stage2, e->d_stage2, e->stage_cap};
-    const int n_upd = (int)upd_slots.size(), n_new = (int)new_slots.size(), n_gal = (int)sps.size() / 3;
-    // deep_sort.py:46-58 output eligibility (confirmed, time_since_update <= 1), or every track for the state readers
+    // deep_sort.py:46-58 output eligibility (confirmed, time_since_update <= 1): those tracks' posterior means go back
     c.emit.clear();
     c.mean_offsets.assign(njobs + 1, 0);
-    std::vector<int> out_slots;
+    std::map<int, int> op_of_slot;
+    for (size_t i = 0; i < ops.size(); ++i) op_of_slot[ops[i].slot] = (int)i;
+    int n_out = 0;
     for (int j = 0; j < njobs; ++j) {
-        c.mean_offsets[j] = (int)out_slots.size();
+        c.mean_offsets[j] = n_out;
         for (const TrackRec& tr : e->trackers[c.ids[j]]->tracks) {
             if (!c.all_means && (tr.state != CONFIRMED || tr.tsu > 1)) continue;
-            if (tr.state == CONFIRMED && tr.tsu <= 1) c.emit.push_back(StepCtx::Emit{(int)out_slots.size(), tr.id, j < (int)c.labels.size() ? c.labels[j] : 0});
-            out_slots.push_back(tr.slot);
+            if (tr.state == CONFIRMED && tr.tsu <= 1) c.emit.push_back(StepCtx::Emit{n_out, tr.id, j < (int)c.labels.size() ? c.labels[j] : 0});
+            auto it = op_of_slot.find(tr.slot);
+            if (it == op_of_slot.end()) { add_op(tr.slot, 0, nullptr, 0, -1); ops.back().out_row = n_out; }
+            else ops[it->second].out_row = n_out;
+            ++n_out;
         }
     }
-    const int n_out = (int)out_slots.size();
     c.mean_offsets[njobs] = n_out;
-    int *d_upd, *d_new, *d_sps, *d_outs; double *d_uz, *d_nz;
-    int* h_upd = sb.take<int>(n_upd, &d_upd);
-    int* h_new = sb.take<int>(n_new, &d_new);
-    double* h_uz = sb.take<double>((size_t)n_upd * 4, &d_uz);
-    double* h_nz = sb.take<double>((size_t)n_new * 4, &d_nz);
-    int* h_sp = sb.take<int>((size_t)n_gal * 3, &d_sps);
-    int* h_outs = sb.take<int>(n_out, &d_outs);
-    VC_CHECK(sb.off <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
-    if (n_upd) { memcpy(h_upd, upd_slots.data(), n_upd * sizeof(int)); memcpy(h_uz, upd_xyah.data(), (size_t)n_upd * 32); }
-    if (n_new) { memcpy(h_new, new_slots.data(), n_new * sizeof(int)); memcpy(h_nz, new_xyah.data(), (size_t)n_new * 32); }
-    if (n_gal) memcpy(h_sp, sps.data(), sps.size() * sizeof(int));
-    if (n_out) memcpy(h_outs, out_slots.data(), n_out * sizeof(int));
-    if (sb.off > 0) VC_HIP(hipMemcpyAsync(e->d_stage2, e->h_stage2, sb.off, hipMemcpyHostToDevice, s));
-    if (n_upd) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_update(e->pool, d_upd, d_uz, n_upd, s)); }
-    if (n_new) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_kalman_initiate(e->pool, d_new, d_nz, n_new, s)); }
-    if (n_gal) { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gallery_write(e->pool, d_sps, n_gal, d_feat, s)); }
-    if (n_out) {
-        { ProfScope ps(e, VC_PROF_TRACK); VC_TRY(launch_gather_means(e->pool, d_outs, n_out, e->d_mean_out, s)); }
-        VC_HIP(hipMemcpyAsync(e->h_mean, e->d_mean_out, (size_t)n_out * 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    const int nops = (int)ops.size();
+    VC_CHECK((size_t)nops * sizeof(TrackOpB) <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
+    if (nops) {
+        memcpy(e->h_stage2, ops.data(), (size_t)nops * sizeof(TrackOpB));
+        ProfScope ps(e, VC_PROF_TRACK);
+        VC_TRY(launch_track_phase_b(e->pool, (const TrackOpB*)e->hd_stage2, nops, d_feat, e->hd_mean, s));
     }
     return VC_OK;      // stream-ordered: e->h_mean / c.emit are valid after the next synchronisation of e->stream
 }
