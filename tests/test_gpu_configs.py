@@ -1,0 +1,118 @@
+"""GPU: the other BASELINE.json configurations and edge cases as parity-test cases (not bench lines):
+1280x720 frames (letterbox resize, rectangular tensor, quirk Q8), yolov5m channel counts, mixed image sizes in one
+call, frames without detections (quirk Q1), capacity / argument errors."""
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from oracle import yolov5 as oy  # noqa: E402
+from vehicle_counting_amd._lib import VcError  # noqa: E402
+from vehicle_counting_amd.detect import ImageDetect  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+
+NC = 8
+
+
+def nchw(x):
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
+def check_dets(dets, ref, atol_px=5e-2):
+    assert len(dets) == len(ref)
+    for d, r in zip(dets, ref):
+        assert len(d) == len(r), (len(d), len(r))
+        if len(r):
+            np.testing.assert_array_equal(d[:, 5], r[:, 5])
+            np.testing.assert_allclose(d[:, :4], r[:, :4], rtol=0, atol=atol_px)
+            np.testing.assert_allclose(d[:, 4], r[:, 4], rtol=0, atol=2e-4)
+
+
+def test_720p_frames_fp32():
+    """demo-like 1280x720 video: AutoShape gives a 384x640 tensor through the fixed-point bilinear resize (scale 0.5)."""
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=8.0, obj_shift=1.0)
+    frames = synth_frames(2, 720, 1280, n_obj=6, seed=9)
+    imgs = [f[:, :, ::-1] for f in frames]
+    eng = E.Engine(sd, None, precision="f32", num_classes=NC, max_batch=2, max_frame_hw=(720, 1280))
+    dets = eng.detect(imgs)
+    x, s0, s1 = oy.preprocess(imgs, 640)
+    assert s1 == [384, 640]
+    np.testing.assert_array_equal(nchw(eng.debug_layer(-1, batch=2)), x)
+    ref = oy.autoshape_detect(sd, imgs, "yolov5s", NC)
+    assert sum(len(r) for r in ref) > 5
+    check_dets(dets, ref, atol_px=1e-1)          # source-pixel coordinates are 2x the tensor's here
+    eng.close()
+
+
+def test_yolov5m_graph_fp32():
+    """yolov5m (0.67 / 0.75 multiples: 48..768 channels, 2-4-6-2 bottlenecks, 82 convs) at AutoShape size 320."""
+    sd = synth_yolo("yolov5m", nc=NC, seed=7, det_scale=4.0, obj_shift=0.5)
+    frames = synth_frames(1, 180, 320, n_obj=4, seed=2)
+    imgs = [frames[0][:, :, ::-1]]
+    eng = E.Engine(sd, None, precision="f32", model_name="yolov5m", num_classes=NC, img_size=320, max_batch=1, max_frame_hw=(180, 320))
+    eng.debug_pred(arm=True)
+    dets = eng.detect(imgs)
+    x, s0, s1 = oy.preprocess(imgs, 320)
+    pred, ys, raw = oy.forward(sd, x, "yolov5m", NC, return_layers=True)
+    for layer in (0, 4, 9, 17, 20, 23):
+        got, ref = nchw(eng.debug_layer(layer)), ys[layer].numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-6, layer
+    np.testing.assert_allclose(eng.debug_pred()[:1][..., 4:], pred.numpy()[..., 4:], rtol=0, atol=2e-4)
+    ref = [np.concatenate((oy.scale_coords(s1, d[:, :4], s0[0]), d[:, 4:]), 1) if len(d) else d
+           for d in oy.non_max_suppression(pred.numpy(), 0.25, 0.45, None, 300)]
+    check_dets(dets, ref)
+    eng.close()
+
+
+def test_mixed_sizes_one_call_fp32():
+    """vc_detect with images of different sizes: common AutoShape tensor, per-image letterbox and scale_coords."""
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0)
+    a = synth_frames(1, 360, 640, n_obj=5, seed=4)[0][:, :, ::-1]
+    b = synth_frames(1, 300, 400, n_obj=3, seed=5)[0][:, :, ::-1]
+    eng = E.Engine(sd, None, precision="f32", num_classes=NC, max_batch=2, max_frame_hw=(360, 640))
+    dets = eng.detect([a, b])
+    ref = oy.autoshape_detect(sd, [a, b], "yolov5s", NC)
+    check_dets(dets, ref, atol_px=1e-1)
+    eng.close()
+
+
+def test_no_detections_and_q1():
+    """A detector that finds nothing: ImageDetect.run gives zero-length arrays, the stream path steps no tracker (Q1)."""
+    import torch
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=1.0, obj_shift=-6.0)
+    eng = E.Engine(sd, synth_reid(1), precision="bf16", num_classes=NC, max_batch=2, max_frame_hw=(360, 640), max_crops=64, max_tracks=64)
+    frames = synth_frames(2, 360, 640, n_obj=3, seed=1)
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    det = ImageDetect(types.SimpleNamespace(weight=None, mapping=None), cfg, engine=eng, class_names=[str(i) for i in range(NC)])
+    out = det.run({"imgs": [frames[0][:, :, ::-1]]})
+    assert len(out["boxes"][0]) == 0 and len(out["labels"][0]) == 0 and len(out["scores"][0]) == 0
+    tids = [eng.tracker_create() for _ in range(NC)]
+    rows, nd = eng.stream_run(tids, torch.from_numpy(frames).cuda().data_ptr(), 2, 360, 640)
+    assert nd.tolist() == [0, 0] and all(len(r) == 0 for r in rows)
+    assert all(len(eng.tracker_state(t, with_cov=False)["ids"]) == 0 for t in tids)
+    eng.close()
+
+
+def test_error_behaviour():
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702)
+    eng = E.Engine(sd, synth_reid(1), precision="bf16", num_classes=NC, max_batch=1, max_frame_hw=(360, 640), max_crops=8, max_tracks=16, nn_budget_cap=10)
+    img = synth_frames(1, 360, 640, n_obj=2, seed=1)[0]
+    with pytest.raises(VcError):                                   # more images than max_batch
+        eng.detect([img, img])
+    with pytest.raises(VcError):                                   # frame larger than the staging buffer
+        eng.detect([np.zeros((720, 1280, 3), np.uint8)])
+    with pytest.raises(VcError):                                   # degenerate box -> empty crop (cv2.resize raises in the reference, Q4)
+        eng.embed(img, np.array([[100.5, 100.5, 0.2, 0.2]]))
+    with pytest.raises(VcError):                                   # budget above the engine cap
+        eng.tracker_create(nn_budget=50)
+    with pytest.raises(VcError):                                   # too many crops for one launch
+        eng.embed(img, np.tile(np.array([[100.0, 100.0, 40.0, 40.0]]), (9, 1)))
+    tid = eng.tracker_create(nn_budget=10)
+    with pytest.raises(VcError):                                   # DeepSort.update is only ever called with >= 1 box
+        eng.deepsort_update(tid, np.zeros((0, 4)), np.zeros(0), img)
+    eng.close()
