@@ -67,7 +67,9 @@ struct vc_engine {
     int prec = 0;
     hipStream_t stream = nullptr;    // ReID + tracker
     hipStream_t dstream = nullptr;   // detector (runs ahead of the tracker on the next batch)
+    hipStream_t rstream = nullptr;   // ReID of the next batch (stream path), concurrent with detector and tracker
     hipEvent_t ev_det[2] = {nullptr, nullptr};
+    hipEvent_t ev_reid[2] = {nullptr, nullptr};
     bool finalized = false;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
@@ -91,7 +93,18 @@ struct vc_engine {
     int* h_det_count2[2] = {nullptr, nullptr};
     float* h_geom = nullptr;                     // pinned [2][max_batch][5]
     unsigned geom_seq = 0, submit_seq = 0;
-    struct Pending { const void* frames; int b, h, w, slot; };
+    float* d_feat2[2] = {nullptr, nullptr};      // stream path: features of the batch being tracked / being embedded
+    int* d_crops2[2] = {nullptr, nullptr};
+    int* h_crops2[2] = {nullptr, nullptr};
+    unsigned reid_seq = 0;
+    struct FrameDets { std::vector<double> xyxy, conf; std::vector<int> label; };
+    struct Pending {
+        const void* frames; int b, h, w, slot;
+        int stage = 0;                   // 0: detector enqueued, 1: ReID enqueued as well
+        int fslot = 0;                   // feature / crop buffer of this batch
+        std::vector<FrameDets> fd;       // per frame, as VideoTracker.run sees them
+        std::vector<int> row0;           // first feature row of each frame
+    };
     std::vector<Pending> pending;
 
     // ---- ReID ---------------------------------------------------------------------------------------
@@ -138,6 +151,7 @@ int dev_alloc(vc_engine* e, void** p, size_t bytes);
 int host_alloc(vc_engine* e, void** p, size_t bytes);
 int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w, bool swap_rb);   // frames same size, on device
 int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k);                      // crops in e->d_crops -> e->d_feat
+int run_reid_on(vc_engine* e, const uint8_t* d_frames, int H, int W, int k, const int* d_crops, float* feat_out, hipStream_t rs);
 int prof_launch(vc_engine* e, int cat, double flops, double bytes, int status);
 struct ProfScope {
     vc_engine* e; int cat; double flops, bytes;

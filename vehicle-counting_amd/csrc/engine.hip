@@ -487,13 +487,18 @@ static int reid_alloc(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&e->d_crops, K * 5 * sizeof(int)));
     VC_TRY(host_alloc(e, (void**)&e->h_crops, K * 5 * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&e->d_feat, K * VC_FEAT_DIM * sizeof(float)));
+    for (int q = 0; q < 2; ++q) {                      // stream path: ReID of batch i+1 runs while batch i is tracked
+        VC_TRY(dev_alloc(e, (void**)&e->d_feat2[q], K * VC_FEAT_DIM * sizeof(float)));
+        VC_TRY(dev_alloc(e, (void**)&e->d_crops2[q], K * 5 * sizeof(int)));
+        VC_TRY(host_alloc(e, (void**)&e->h_crops2[q], K * 5 * sizeof(int)));
+    }
     VC_TRY(host_alloc(e, (void**)&e->h_feat, K * VC_FEAT_DIM * sizeof(float)));
     VC_TRY(dev_alloc(e, (void**)&e->d_reid_in_nchw, K * 3 * 50 * 50 * sizeof(float)));
     return VC_OK;
 }
 
 // forward from the pre-filled "in" buffer (k x 50 x 50 x cpad) to e->d_feat
-static int reid_forward(vc_engine* e, int k) {
+static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     std::vector<Op> ops;
     PlanBuilder pb{e, &e->reid, &ops, e->prec};
     auto& m = e->rbuf;
@@ -509,18 +514,24 @@ static int reid_forward(vc_engine* e, int k) {
         x = pb.conv(p + ".conv2", t, mkview(m[p + ".y"], k, 0, 0, b.cout, 0), 3, 1, 1, ACT_RELU, &sc, RES_BEFORE_ACT);
     }
     VC_TRY(pb.status);
-    VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, e->stream));
-    { ProfScope ps(e, VC_PROF_REID_AUX); VC_TRY(launch_avgpool_l2norm(x, e->d_feat, e->prec, e->stream)); }               // model.py:70,93
+    VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, rs));
+    { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs); VC_TRY(launch_avgpool_l2norm(x, feat_out, e->prec, rs)); }               // model.py:70,93
     return VC_OK;
 }
 
-int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k) {
+int run_reid_on(vc_engine* e, const uint8_t* d_frames, int H, int W, int k, const int* d_crops, float* feat_out, hipStream_t rs) {
     VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
     VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
     if (k <= 0) return VC_OK;
-    { ProfScope ps(e, VC_PROF_REID_AUX);
-      VC_TRY(launch_crop_resize(d_frames, H, W, e->d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, e->stream)); }
-    return reid_forward(e, k);
+    { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs);
+      VC_TRY(launch_crop_resize(d_frames, H, W, d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, rs)); }
+    return reid_forward(e, k, rs, feat_out);
+}
+
+// blocking-API flavour (vc_embed, vc_deepsort_update, vc_videotracker_run): tracker stream, shared crop / feature buffers
+int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k) {
+    VC_HIP(hipStreamSynchronize(e->rstream));          // the activation buffers are shared with the stream path's ReID
+    return run_reid_on(e, d_frames, H, W, k, e->d_crops, e->d_feat, e->stream);
 }
 
 }  // namespace vc
@@ -565,8 +576,15 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     e->prec = cfg->precision;
     int st = VC_OK;
     do {
-        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&e->dstream, hipStreamNonBlocking) != hipSuccess) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
+        // the tracker's kernels are tiny and latency-critical (the host waits on them every frame): highest priority,
+        // so they are not queued behind the conv waves of the detector / ReID streams they run beside
+        int plo = 0, phi = 0;
+        hipDeviceGetStreamPriorityRange(&plo, &phi);             // numerically lower = higher priority
+        if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, phi) != hipSuccess ||
+            hipStreamCreateWithPriority(&e->dstream, hipStreamNonBlocking, plo) != hipSuccess ||
+            hipStreamCreateWithPriority(&e->rstream, hipStreamNonBlocking, plo) != hipSuccess) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
+        if (hipEventCreateWithFlags(&e->ev_reid[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_reid[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&e->ev_det[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_det[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
@@ -584,13 +602,16 @@ int vc_engine_destroy(vc_engine* e) {
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->dstream) hipStreamSynchronize(e->dstream);
+    if (e->rstream) hipStreamSynchronize(e->rstream);
     for (void* p : e->allocs) hipFree(p);
     for (void* p : e->host_allocs) hipHostFree(p);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->dstream) hipStreamDestroy(e->dstream);
+    if (e->rstream) hipStreamDestroy(e->rstream);
     for (hipEvent_t ev : e->ev_det) if (ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_reid) if (ev) hipEventDestroy(ev);
     delete e;
     return VC_OK;
 }
@@ -649,6 +670,7 @@ int vc_engine_sync(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_HIP(hipStreamSynchronize(e->stream));
     VC_HIP(hipStreamSynchronize(e->dstream));
+    VC_HIP(hipStreamSynchronize(e->rstream));
     return VC_OK;
 }
 
@@ -776,8 +798,9 @@ int vc_embed_tensor(vc_engine* e, const float* x, int k, float* out_feat) {
     VC_CHECK(k >= 1 && k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_HIP(hipMemcpyAsync(e->d_reid_in_nchw, x, (size_t)k * 3 * 2500 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    VC_HIP(hipStreamSynchronize(e->rstream));
     VC_TRY(launch_nchw_to_nhwc_pad(e->d_reid_in_nchw, k, 3, 50, 50, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, e->stream));
-    VC_TRY(reid_forward(e, k));
+    VC_TRY(reid_forward(e, k, e->stream, e->d_feat));
     VC_HIP(hipMemcpyAsync(e->h_feat, e->d_feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     VC_HIP(hipStreamSynchronize(e->stream));
     memcpy(out_feat, e->h_feat, (size_t)k * VC_FEAT_DIM * sizeof(float));

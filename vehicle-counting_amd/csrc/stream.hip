@@ -40,10 +40,7 @@ namespace {
 // DataFrame.to_json(double_precision=10) -> json.loads (quirk Q9), same rounding as oracle/yolov5.py::marshal_like_reference
 inline double round10(double v) { return std::nearbyint(v * 1e10) / 1e10; }
 
-struct FrameDets {
-    std::vector<double> xyxy, conf;      // as VideoTracker.run sees them (xywh -> xyxy round trip included)
-    std::vector<int> label;
-};
+typedef vc_engine::FrameDets FrameDets;     // boxes as VideoTracker.run sees them (xywh -> xyxy round trip included)
 
 void marshal(const float* det6, int n, FrameDets& out) {
     out.xyxy.clear(); out.conf.clear(); out.label.clear();
@@ -85,35 +82,98 @@ int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w) 
     VC_HIP(hipMemcpyAsync(e->h_det2[slot], e->post.det, (size_t)b * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->dstream));
     VC_HIP(hipMemcpyAsync(e->h_det_count2[slot], e->post.det_count, b * sizeof(int), hipMemcpyDeviceToHost, e->dstream));
     VC_HIP(hipEventRecord(e->ev_det[slot], e->dstream));
-    e->pending.push_back(vc_engine::Pending{frames_dev, b, h, w, slot});
+    vc_engine::Pending pd{};
+    pd.frames = frames_dev; pd.b = b; pd.h = h; pd.w = w; pd.slot = slot;
+    e->pending.push_back(std::move(pd));
     return VC_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Second pipeline stage of a submission whose detector has finished: marshal the detections like networks/yolo.py:72-97,
+// cut the crops of every box of the batch (deep_sort.py:89-95,119-129) and enqueue the ReID net on its own stream.
+int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
+    const int md = e->cfg.max_det, b = pd.b, h = pd.h, w = pd.w;
+    const float* h_det = e->h_det2[pd.slot];
+    const int* h_cnt = e->h_det_count2[pd.slot];
+    pd.fd.assign(b, FrameDets{});
+    pd.row0.assign(b, 0);
+    for (int f = 0; f < b; ++f) {
+        if (e->inject_b > 0) {
+            const int fi = f % e->inject_b;
+            marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], pd.fd[f]);
+        } else {
+            marshal(h_det + (size_t)f * md * 6, h_cnt[f], pd.fd[f]);
+        }
+    }
+    pd.fslot = (int)(e->reid_seq++ & 1);
+    int* hc = e->h_crops2[pd.fslot];
+    int k = 0;
+    for (int f = 0; f < b; ++f) {
+        pd.row0[f] = k;
+        FrameDets& d = pd.fd[f];
+        VC_CHECK(k + (int)d.conf.size() <= e->cfg.max_crops, VC_ERR_CAPACITY,
+                 "the batch has more boxes than max_crops (%d): raise vc_engine_config.max_crops", e->cfg.max_crops);
+        for (size_t i = 0; i < d.conf.size(); ++i) {
+            const double* bx = &d.xyxy[i * 4];
+            const double bw = bx[2] - bx[0], bh = bx[3] - bx[1];                 // deep_sort.py:78-87
+            const double cx = bx[0] + bw / 2, cy = bx[1] + bh / 2;
+            int* c = hc + (size_t)k * 5;
+            c[0] = f;
+            c[1] = std::max((int)(cx - bw / 2), 0); c[3] = std::min((int)(cx + bw / 2), w - 1);    // deep_sort.py:89-95
+            c[2] = std::max((int)(cy - bh / 2), 0); c[4] = std::min((int)(cy + bh / 2), h - 1);
+            VC_CHECK(c[3] > c[1] && c[4] > c[2], VC_ERR_ARG,
+                     "frame %d box %zu gives an empty crop (the reference's cv2.resize raises here)", f, i);
+            ++k;
+        }
+    }
+    if (k > 0) {
+        VC_HIP(hipMemcpyAsync(e->d_crops2[pd.fslot], hc, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->rstream));
+        VC_TRY(run_reid_on(e, (const uint8_t*)pd.frames, h, w, k, e->d_crops2[pd.fslot], e->d_feat2[pd.fslot], e->rstream));
+    }
+    VC_HIP(hipEventRecord(e->ev_reid[pd.fslot], e->rstream));
+    pd.stage = 1;
+    return VC_OK;
+}
+
+// If the detector of the next submission has finished, start its ReID now (it then overlaps the tracking in progress).
+int try_issue_next(vc_engine* e) {
+    if (e->pending.empty() || e->pending[0].stage != 0) return VC_OK;
+    if (hipEventQuery(e->ev_det[e->pending[0].slot]) != hipSuccess) return VC_OK;
+    return issue_reid(e, e->pending[0]);
+}
+
+}  // namespace
+
+extern "C" {
 
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
     VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
     VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
     VC_HIP(hipSetDevice(e->cfg.device));
-    const uint8_t* frames = (const uint8_t*)frames_dev;
-    const int md = e->cfg.max_det;
     if (e->pending.empty()) VC_TRY(vc_stream_submit(e, frames_dev, b, h, w));
-    const vc_engine::Pending pd = e->pending.front();
-    VC_CHECK(pd.frames == frames_dev && pd.b == b && pd.h == h && pd.w == w, VC_ERR_STATE,
-             "vc_stream_run must consume submissions in the order they were made");
-    e->pending.erase(e->pending.begin());
+    {
+        const vc_engine::Pending& fr = e->pending.front();
+        VC_CHECK(fr.frames == frames_dev && fr.b == b && fr.h == h && fr.w == w, VC_ERR_STATE,
+                 "vc_stream_run must consume submissions in the order they were made");
+    }
     g_tm.start();
-    VC_HIP(hipEventSynchronize(e->ev_det[pd.slot]));
+    if (e->pending.front().stage == 0) {
+        VC_HIP(hipEventSynchronize(e->ev_det[e->pending.front().slot]));
+        VC_TRY(issue_reid(e, e->pending.front()));
+    }
+    vc_engine::Pending pd = std::move(e->pending.front());
+    e->pending.erase(e->pending.begin());
     g_tm.lap(0);
-    const float* h_det = e->h_det2[pd.slot];
-    const int* h_cnt = e->h_det_count2[pd.slot];
-    std::vector<FrameDets> fd(b);
+    VC_TRY(try_issue_next(e));
+    // the tracker stream waits (on the GPU) for this batch's features
+    VC_HIP(hipStreamWaitEvent(e->stream, e->ev_reid[pd.fslot], 0));
+    const float* d_feat = e->d_feat2[pd.fslot];
+    std::vector<FrameDets>& fd = pd.fd;
     for (int f = 0; f < b; ++f) {
-        if (e->inject_b > 0) {
-            const int fi = f % e->inject_b;
-            marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], fd[f]);
-        } else {
-            marshal(h_det + (size_t)f * md * 6, h_cnt[f], fd[f]);
-        }
         if (out_ndet) out_ndet[f] = (int)fd[f].conf.size();
         out_m[f] = 0;
     }
@@ -132,63 +192,32 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         prev_f = -1;
         return VC_OK;
     };
-    // frames are processed in groups whose crops fit one ReID launch
-    int f0 = 0;
-    while (f0 < b) {
-        int f1 = f0, total = 0;
-        while (f1 < b && total + (int)fd[f1].conf.size() <= e->cfg.max_crops) { total += (int)fd[f1].conf.size(); ++f1; }
-        VC_CHECK(f1 > f0, VC_ERR_CAPACITY, "one frame has more boxes (%zu) than max_crops (%d)", fd[f0].conf.size(), e->cfg.max_crops);
-        std::vector<int> row0(f1 - f0, 0);
-        int k = 0;
-        // the crop list lives in pinned memory that the previous group's copy may still be reading
-        if (f0 > 0) VC_HIP(hipStreamSynchronize(e->stream));
-        for (int f = f0; f < f1; ++f) {
-            row0[f - f0] = k;
-            FrameDets& d = fd[f];
-            for (size_t i = 0; i < d.conf.size(); ++i) {
-                const double* bx = &d.xyxy[i * 4];
-                const double bw = bx[2] - bx[0], bh = bx[3] - bx[1];                 // deep_sort.py:78-87
-                const double cx = bx[0] + bw / 2, cy = bx[1] + bh / 2;
-                int* c = e->h_crops + (size_t)k * 5;
-                c[0] = f;
-                c[1] = std::max((int)(cx - bw / 2), 0); c[3] = std::min((int)(cx + bw / 2), w - 1);    // deep_sort.py:89-95
-                c[2] = std::max((int)(cy - bh / 2), 0); c[4] = std::min((int)(cy + bh / 2), h - 1);
-                VC_CHECK(c[3] > c[1] && c[4] > c[2], VC_ERR_ARG,
-                         "frame %d box %zu gives an empty crop (the reference's cv2.resize raises here)", f, i);
-                ++k;
-            }
+    g_tm.lap(2);
+    for (int f = 0; f < b; ++f) {
+        FrameDets& d = fd[f];
+        if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
+        std::vector<int> ids, labs;
+        std::vector<std::vector<int>> groups;
+        for (int c = 0; c < num_classes; ++c) {                                  // modules/track.py:50-59
+            std::vector<int> g;
+            for (size_t i = 0; i < d.label.size(); ++i) if (d.label[i] == c) g.push_back((int)i);
+            if (g.empty()) continue;
+            ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(g));
         }
-        if (k > 0) {
-            VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
-            VC_TRY(run_reid_dev(e, frames, h, w, k));
-        }
-        g_tm.lap(2);
-        for (int f = f0; f < f1; ++f) {
-            FrameDets& d = fd[f];
-            if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
-            std::vector<int> ids, labs;
-            std::vector<std::vector<int>> groups;
-            for (int c = 0; c < num_classes; ++c) {                                  // modules/track.py:50-59
-                std::vector<int> g;
-                for (size_t i = 0; i < d.label.size(); ++i) if (d.label[i] == c) g.push_back((int)i);
-                if (g.empty()) continue;
-                ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(g));
-            }
-            if (ids.empty()) continue;
-            build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), row0[f - f0]);
-            g_tm.lap(3);
-            VC_TRY(track_phase_a(e, ctx[cur], e->d_feat));
-            g_tm.lap(4);
-            VC_HIP(hipStreamSynchronize(e->stream));          // cost rows of f are here; so are the means of the previous frame
-            g_tm.lap(5);
-            VC_TRY(flush_prev(cur ^ 1));
-            g_tm.lap(6);
-            VC_TRY(track_phase_b(e, ctx[cur], e->d_feat));
-            g_tm.lap(7);
-            prev_f = f;
-            cur ^= 1;
-        }
-        f0 = f1;
+        if (ids.empty()) continue;
+        build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), pd.row0[f]);
+        g_tm.lap(3);
+        VC_TRY(track_phase_a(e, ctx[cur], d_feat));
+        g_tm.lap(4);
+        VC_HIP(hipStreamSynchronize(e->stream));          // cost rows of f are here; so are the means of the previous frame
+        g_tm.lap(5);
+        VC_TRY(flush_prev(cur ^ 1));
+        g_tm.lap(6);
+        VC_TRY(track_phase_b(e, ctx[cur], d_feat));
+        VC_TRY(try_issue_next(e));
+        g_tm.lap(7);
+        prev_f = f;
+        cur ^= 1;
     }
     if (prev_f >= 0) {
         VC_HIP(hipStreamSynchronize(e->stream));
@@ -196,6 +225,7 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         VC_TRY(flush_prev(cur ^ 1));
         g_tm.lap(6);
     }
+    VC_TRY(try_issue_next(e));
     g_tm.report();
     return VC_OK;
 }

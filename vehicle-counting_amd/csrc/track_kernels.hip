@@ -145,39 +145,73 @@ __device__ __forceinline__ double maha4(const double* m, const double L[16], con
     return acc;
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
+// cost[d] = min_s (1 - <g_s, f_d/|f_d|>) with the gallery rows g_s stored already normalised (store_gallery_row):
+// a (S x 512) x (512 x D) product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, an exact fmaf chain), one 16-sample
+// tile per wave against 16 detections at a time; |f_d|^2 falls out of the same operand loads.  The Mahalanobis gate of
+// linear_assignment.py:148-192 is folded in (lane d of wave 0).
 __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const CostJob& jb, const float* __restrict__ feat,
                                                    const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
                                                    double* __restrict__ out) {
+    __shared__ float smax[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int S = jb.gal_count, D = jb.det_n;
     const double* m = tp.mean + (size_t)jb.slot * 8;
-    const double* P = tp.cov + (size_t)jb.slot * 64;
-    double S[16], L[16];
-    project4(m, P, S);
-    chol4(S, L);
+    double Sg[16], L[16];
+    project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
+    chol4(Sg, L);
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
-    for (int d = wave; d < jb.det_n; d += 4) {
-        const float* f = feat + (size_t)det_feat_row[jb.det_off + d] * VC_FEAT_DIM + lane * 8;
-        const float4 f0 = *(const float4*)f, f1 = *(const float4*)(f + 4);
-        float fn = f0.x * f0.x + f0.y * f0.y + f0.z * f0.z + f0.w * f0.w + f1.x * f1.x + f1.y * f1.y + f1.z * f1.z + f1.w * f1.w;
+    for (int d0 = 0; d0 < D; d0 += 16) {
+        const int dcl = min(d0 + col, D - 1);
+        const float* fptr = feat + (size_t)det_feat_row[jb.det_off + dcl] * VC_FEAT_DIM + kq * 4;
+        float best = -INFINITY, ss = 0.f;
+        for (int st = wave; st * 16 < S; st += 4) {
+            const float* gptr = gal + (size_t)min(st * 16 + col, S - 1) * VC_FEAT_DIM + kq * 4;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            float s2 = 0.f;
+#pragma unroll 4
+            for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
+                const float4 a = *(const float4*)(gptr + k0), b = *(const float4*)(fptr + k0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                s2 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            }
+            ss = s2;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) fn += __shfl_xor(fn, o);
-        const float finv = 1.0f / sqrtf(fn);
-        float best = -INFINITY;
-        for (int s = 0; s < jb.gal_count; ++s) {
-            const float* g = gal + (size_t)s * VC_FEAT_DIM + lane * 8;
-            const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
-            float dot = g0.x * f0.x + g0.y * f0.y + g0.z * f0.z + g0.w * f0.w + g1.x * f1.x + g1.y * f1.y + g1.z * f1.z + g1.w * f1.w;
-            float gn = g0.x * g0.x + g0.y * g0.y + g0.z * g0.z + g0.w * g0.w + g1.x * g1.x + g1.y * g1.y + g1.z * g1.z + g1.w * g1.w;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o); gn += __shfl_xor(gn, o); }
-            best = fmaxf(best, dot * finv * (1.0f / sqrtf(gn)));
+            for (int r = 0; r < 4; ++r)                       // acc[r] = <g_{st*16 + kq*4 + r}, f_{d0 + col}>
+                if (st * 16 + kq * 4 + r < S) best = fmaxf(best, acc[r]);
         }
-        if (lane == 0) {
-            const double g2 = maha4(m, L, det_xyah + (size_t)(jb.det_off + d) * 4);
-            out[jb.out_off + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - best);
+        best = fmaxf(best, __shfl_xor(best, 16));
+        best = fmaxf(best, __shfl_xor(best, 32));
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (lane < 16) smax[wave][lane] = best;
+        __syncthreads();
+        if (wave == 0 && lane < 16 && d0 + lane < D) {
+            const float bmax = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+            const float cosv = bmax * (1.0f / sqrtf(ss));
+            const double g2 = maha4(m, L, det_xyah + (size_t)(jb.det_off + d0 + lane) * 4);
+            out[jb.out_off + d0 + lane] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
         }
+        __syncthreads();
     }
+}
+
+// gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector)
+__device__ __forceinline__ void store_gallery_row(float* dst, const float* src, int t /* 0..127 */, float* red /* [2] */) {
+    const float4 v = ((const float4*)src)[t];
+    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((t & 63) == 0) red[t >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1]);
+    ((float4*)dst)[t] = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
 }
 
 __global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* __restrict__ feat,
@@ -206,10 +240,9 @@ __global__ __launch_bounds__(64) void iou_cost_kernel(TrackPool tp, const CostJo
 }
 
 __global__ __launch_bounds__(128) void gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
+    __shared__ float red[2];
     const int* e = sps + (size_t)blockIdx.x * 3;
-    float* dst = tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM;
-    const float* src = feat + (size_t)e[2] * VC_FEAT_DIM;
-    ((float4*)dst)[threadIdx.x] = ((const float4*)src)[threadIdx.x];
+    store_gallery_row(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x, red);
 }
 
 // ---- fused per-frame kernels (tracker.hip: track_phase_a / track_phase_b) ------------------------------------------
@@ -244,10 +277,10 @@ __global__ __launch_bounds__(128) void track_phase_b_kernel(TrackPool tp, const 
         if (op.kind == 1) kalman_update_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
         else if (op.kind == 2) kalman_initiate_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
     }
-    if (op.feat_row >= 0) {
-        float* dst = tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM;
-        ((float4*)dst)[threadIdx.x] = ((const float4*)(feat + (size_t)op.feat_row * VC_FEAT_DIM))[threadIdx.x];
-    }
+    __shared__ float red[2];
+    if (op.feat_row >= 0)              // block-uniform
+        store_gallery_row(tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM,
+                          feat + (size_t)op.feat_row * VC_FEAT_DIM, threadIdx.x, red);
     __syncthreads();
     if (op.out_row >= 0 && threadIdx.x < 8) mean_out[(size_t)op.out_row * 8 + threadIdx.x] = m[threadIdx.x];
 }

@@ -709,12 +709,22 @@ int vc_cosine_cost_host(const float* gallery, const int* gal_count, int t, int s
         std::iota(rows.begin(), rows.end(), 0);
         for (int i = 0; i < t; ++i) jobs[i] = CostJob{i, gal_count[i], 0, d, i * d, 1};
         hipMemcpy(tp.mean, mean.data(), mean.size() * 8, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov.data(), cov.size() * 8, hipMemcpyHostToDevice);
-        hipMemcpy(tp.gallery, gallery, (size_t)t * s_cap * VC_FEAT_DIM * 4, hipMemcpyHostToDevice);
         hipMemcpy(dfeat, feat, (size_t)d * VC_FEAT_DIM * 4, hipMemcpyHostToDevice);
+        {   // samples enter the device gallery the way the tracker stores them (normalised rows)
+            float* draw = nullptr; int* dsps = nullptr;
+            std::vector<int> sps;
+            for (int i = 0; i < t; ++i) for (int q = 0; q < gal_count[i]; ++q) { sps.push_back(i); sps.push_back(q); sps.push_back(i * s_cap + q); }
+            if (hipMalloc((void**)&draw, (size_t)t * s_cap * VC_FEAT_DIM * 4) == hipSuccess && hipMalloc((void**)&dsps, sps.size() * 4 + 16) == hipSuccess) {
+                al.push_back(draw); al.push_back(dsps);
+                hipMemcpy(draw, gallery, (size_t)t * s_cap * VC_FEAT_DIM * 4, hipMemcpyHostToDevice);
+                hipMemcpy(dsps, sps.data(), sps.size() * 4, hipMemcpyHostToDevice);
+                st = launch_gallery_write(tp, dsps, (int)sps.size() / 3, draw, nullptr);
+            } else { set_error("alloc"); st = VC_ERR_HIP; }
+        }
         hipMemcpy(dz, z.data(), z.size() * 8, hipMemcpyHostToDevice);
         hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(CostJob), hipMemcpyHostToDevice);
         hipMemcpy(drow, rows.data(), rows.size() * 4, hipMemcpyHostToDevice);
-        st = launch_appearance_cost(tp, dj, t, dfeat, drow, dz, dout, nullptr);
+        if (st == VC_OK) st = launch_appearance_cost(tp, dj, t, dfeat, drow, dz, dout, nullptr);
     }
     VC_HOST_FINISH(st);
     if (st == VC_OK) hipMemcpy(out, dout, (size_t)t * d * 8, hipMemcpyDeviceToHost);
