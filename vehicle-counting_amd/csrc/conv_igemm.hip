@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
         const int m = m0 + wp * WTP + b * 16 + frow;
         if (m >= p.M) continue;
         const size_t orow = (size_t)m * p.out_cs + p.out_co, rrow = (size_t)m * p.res_cs + p.res_co;
+        const size_t orow2 = (size_t)m * p.out2_cs + p.out2_co;
 #pragma unroll
         for (int a = 0; a < CT; ++a) {
             const int n = nbase + a * 16;
@@ -251,15 +252,16 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
                 if (p.res_mode == RES_AFTER_ACT) t += rv[j];
                 v[j] = t;
             }
+            const bool second = p.split > 0 && n >= p.split;            // lane-uniform per 4-channel group
             if (F32 || p.out_f32) {
-                float* o = (float*)p.out + orow + n;
+                float* o = second ? (float*)p.out2 + orow2 + (n - p.split) : (float*)p.out + orow + n;
                 if (nvalid == 4) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (j < nvalid) o[j] = v[j];
                 }
             } else {
-                uint16_t* o = (uint16_t*)p.out + orow + n;
+                uint16_t* o = second ? (uint16_t*)p.out2 + orow2 + (n - p.split) : (uint16_t*)p.out + orow + n;
                 if (nvalid == 4) {
                     *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 } else {
@@ -336,6 +338,8 @@ int conv_check(const ConvP& p) {
     VC_CHECK(p.Cin % ch == 0 && p.in_cs % ch == 0 && p.in_co % ch == 0, VC_ERR_ARG,
              "conv: input channels/stride/offset (%d,%d,%d) must be multiples of %d", p.Cin, p.in_cs, p.in_co, ch);
     VC_CHECK(p.out_cs % 4 == 0 && p.out_co % 4 == 0, VC_ERR_ARG, "conv: output stride/offset must be multiples of 4");
+    VC_CHECK(p.split == 0 || (p.split % 4 == 0 && p.out2 && p.out2_cs % 4 == 0 && p.out2_co % 4 == 0 && p.res_mode == RES_NONE), VC_ERR_ARG,
+             "conv: bad split destination");
     VC_CHECK(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_co % 4 == 0), VC_ERR_ARG, "conv: residual alignment");
     VC_CHECK(p.Kp % conv_k_tile(p.prec) == 0 && p.Kp >= p.K, VC_ERR_ARG, "conv: bad K padding %d/%d", p.K, p.Kp);
     VC_CHECK(p.M > 0 && p.Cout > 0, VC_ERR_ARG, "conv: empty problem");

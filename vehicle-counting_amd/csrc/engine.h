@@ -14,6 +14,8 @@ struct ConvParam {
     int O = 0, I = 0, kh = 0, kw = 0;
     bool set = false;
     bool pair_stem = false;          // YOLO stem in bf16: two 4-channel pixels form one 16-byte chunk
+    int fuse_a = -1, fuse_b = -1;    // >= 0: internal parameter = rows of params[fuse_a] then params[fuse_b] (same input, 1x1)
+    bool hidden = false;             // internal (fused) parameters are not enumerated to the caller
     std::vector<float> w, b;         // host copies (OIHW, BN folded) until finalize()
     void* d_w = nullptr;             // packed [Cout_pad][Kp]
     float* d_b = nullptr;            // [Cout_pad]

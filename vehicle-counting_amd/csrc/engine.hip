@@ -159,9 +159,11 @@ static const float kAnchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 
 static void yolo_c3_params(Net& n, int idx, int cin, int cout, int reps) {
     const std::string p = "model." + std::to_string(idx);
     const int h = cout / 2;
-    n.add(p + ".cv1.conv", h, cin, 1, 1);
-    n.add(p + ".cv2.conv", h, cin, 1, 1);
+    const int a = n.add(p + ".cv1.conv", h, cin, 1, 1);
+    const int b = n.add(p + ".cv2.conv", h, cin, 1, 1);
     n.add(p + ".cv3.conv", cout, 2 * h, 1, 1);
+    const int f = n.add(p + ".cv12", 2 * h, cin, 1, 1);        // cv1 and cv2 read the same input: one launch, two destinations
+    n.params[f].fuse_a = a; n.params[f].fuse_b = b; n.params[f].hidden = true;
     for (int j = 0; j < reps; ++j) {
         n.add(p + ".m." + std::to_string(j) + ".cv1.conv", h, h, 1, 1);
         n.add(p + ".m." + std::to_string(j) + ".cv2.conv", h, h, 3, 3);
@@ -260,14 +262,19 @@ static View yolo_c3(PlanBuilder& pb, vc_engine* e, int idx, View x, View out, in
     const int h = cout / 2;
     auto& m = e->ybuf;
     View cat = mkview(m[bn + ".cat"], x.B, x.H, x.W, 2 * h, 0);
-    View y = pb.conv(p + ".cv1.conv", x, mkview(m[bn + ".a"], x.B, x.H, x.W, h, 0), 1, 1, 0, ACT_SILU);
+    View y = pb.conv(p + ".cv12", x, mkview(m[bn + ".a"], x.B, x.H, x.W, h, 0), 1, 1, 0, ACT_SILU);
+    {   // channels [h, 2h) of the fused launch are C3.cv2 -> second half of the concat buffer
+        ConvP& c = pb.ops->back().conv;
+        View second = mkview(cat, x.B, x.H, x.W, h, h);
+        c.out2 = second.ptr; c.out2_cs = second.cs; c.out2_co = second.co; c.split = h;
+    }
+    y.C = h;
     for (int j = 0; j < reps; ++j) {
         View t = pb.conv(p + ".m." + std::to_string(j) + ".cv1.conv", y, mkview(m[bn + ".t"], x.B, x.H, x.W, h, 0), 1, 1, 0, ACT_SILU);
         View dst = j == reps - 1 ? mkview(cat, x.B, x.H, x.W, h, 0) : mkview(m[bn + ((j % 2 == 0) ? ".b" : ".a")], x.B, x.H, x.W, h, 0);
         y = pb.conv(p + ".m." + std::to_string(j) + ".cv2.conv", t, dst, 3, 1, 1, ACT_SILU, shortcut ? &y : nullptr,
                     shortcut ? RES_AFTER_ACT : RES_NONE);
     }
-    pb.conv(p + ".cv2.conv", x, mkview(cat, x.B, x.H, x.W, h, h), 1, 1, 0, ACT_SILU);
     return pb.conv(p + ".cv3.conv", cat, out, 1, 1, 0, ACT_SILU);
 }
 
@@ -622,15 +629,23 @@ int vc_engine_param_count(const vc_engine* e, int net, int* n) {
     VC_CHECK(e && n, VC_ERR_ARG, "null argument");
     const Net* nn = pick_net(const_cast<vc_engine*>(e), net);
     VC_CHECK(nn, VC_ERR_ARG, "bad net id %d", net);
-    *n = (int)nn->params.size();
+    int cnt = 0;
+    for (const auto& p : nn->params) cnt += p.hidden ? 0 : 1;
+    *n = cnt;
     return VC_OK;
 }
 
 int vc_engine_param_info(const vc_engine* e, int net, int index, char* name, int name_cap, int dims[4]) {
     VC_CHECK(e && name && dims, VC_ERR_ARG, "null argument");
     const Net* nn = pick_net(const_cast<vc_engine*>(e), net);
-    VC_CHECK(nn && index >= 0 && index < (int)nn->params.size(), VC_ERR_ARG, "bad net/index");
-    const ConvParam& p = nn->params[index];
+    VC_CHECK(nn && index >= 0, VC_ERR_ARG, "bad net/index");
+    int real = -1;
+    for (size_t i = 0, k = 0; i < nn->params.size(); ++i) {
+        if (nn->params[i].hidden) continue;
+        if ((int)k++ == index) { real = (int)i; break; }
+    }
+    VC_CHECK(real >= 0, VC_ERR_ARG, "parameter index %d out of range", index);
+    const ConvParam& p = nn->params[real];
     snprintf(name, name_cap, "%s", p.name.c_str());
     dims[0] = p.O; dims[1] = p.I; dims[2] = p.kh; dims[3] = p.kw;
     return VC_OK;
@@ -644,6 +659,7 @@ int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w,
     auto it = nn->index.find(name);
     VC_CHECK(it != nn->index.end(), VC_ERR_NOTFOUND, "no parameter named '%s'", name);
     ConvParam& p = nn->params[it->second];
+    VC_CHECK(!p.hidden, VC_ERR_NOTFOUND, "no parameter named '%s'", name);
     p.w.assign(w, w + (size_t)p.O * p.I * p.kh * p.kw);
     p.b.assign(bias, bias + p.O);
     p.set = true;
@@ -654,7 +670,22 @@ int vc_engine_finalize(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_CHECK(!e->finalized, VC_ERR_STATE, "engine already finalized");
     VC_HIP(hipSetDevice(e->cfg.device));
-    for (auto& p : e->yolo.params) VC_TRY(pack_and_upload(e, p, e->prec));
+    for (auto& p : e->yolo.params) {
+        if (p.fuse_a < 0) continue;
+        const ConvParam &a = e->yolo.params[p.fuse_a], &b = e->yolo.params[p.fuse_b];
+        VC_CHECK(a.set && b.set, VC_ERR_STATE, "parameters '%s' / '%s' were never set", a.name.c_str(), b.name.c_str());
+        p.w = a.w; p.w.insert(p.w.end(), b.w.begin(), b.w.end());
+        p.b = a.b; p.b.insert(p.b.end(), b.b.begin(), b.b.end());
+        p.set = true;
+    }
+    {
+        std::vector<char> part(e->yolo.params.size(), 0);
+        for (auto& p : e->yolo.params) if (p.fuse_a >= 0) { part[p.fuse_a] = 1; part[p.fuse_b] = 1; }
+        for (size_t i = 0; i < e->yolo.params.size(); ++i) {
+            if (part[i]) { VC_CHECK(e->yolo.params[i].set, VC_ERR_STATE, "parameter '%s' was never set", e->yolo.params[i].name.c_str()); continue; }
+            VC_TRY(pack_and_upload(e, e->yolo.params[i], e->prec));
+        }
+    }
     for (auto& p : e->reid.params) VC_TRY(pack_and_upload(e, p, e->prec));
     e->d_frames_bytes = (size_t)e->cfg.max_batch * e->cfg.max_frame_h * e->cfg.max_frame_w * 3;     // staging for host frames
     VC_TRY(dev_alloc(e, (void**)&e->d_frames, e->d_frames_bytes));
