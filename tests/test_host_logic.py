@@ -110,3 +110,27 @@ def test_synthetic_inputs_are_deterministic():
     assert t[0][0].shape == (3, 4) and t[0][1].dtype == np.int64
     s1, s2 = synth_yolo("yolov5s", 8, 3), synth_yolo("yolov5s", 8, 3)
     assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+
+
+def test_fold_yolo_state_dict_roundtrip():
+    """An un-fused checkpoint dict folds to exactly the tensors the engine asks for (names + shapes of yolo_conv_table)."""
+    from vehicle_counting_amd.weights import fold_yolo_state_dict
+    rng = np.random.default_rng(0)
+    sd = {}
+    for name, ci, co, k in yolo_conv_table("yolov5s", 8):
+        if name.startswith("model.24."):
+            sd[name + ".weight"] = rng.standard_normal((co, ci, 1, 1)).astype(np.float32)
+            sd[name + ".bias"] = rng.standard_normal(co).astype(np.float32)
+        else:
+            sd[name + ".weight"] = rng.standard_normal((co, ci, k, k)).astype(np.float32)
+            bn = name[:-4] + "bn"
+            sd[bn + ".weight"], sd[bn + ".bias"] = rng.uniform(0.5, 1.5, co).astype(np.float32), rng.standard_normal(co).astype(np.float32)
+            sd[bn + ".running_mean"], sd[bn + ".running_var"] = rng.standard_normal(co).astype(np.float32), rng.uniform(0.5, 1.5, co).astype(np.float32)
+            sd[bn + ".num_batches_tracked"] = np.asarray(1)
+    f = fold_yolo_state_dict(sd)
+    for name, ci, co, k in yolo_conv_table("yolov5s", 8):
+        assert f[name + ".weight"].shape == (co, ci, k, k) and f[name + ".bias"].shape == (co,)
+    w, b = fold_bn(sd["model.3.conv.weight"], None, sd["model.3.bn.weight"], sd["model.3.bn.bias"], sd["model.3.bn.running_mean"],
+                   sd["model.3.bn.running_var"], 1e-3)
+    np.testing.assert_array_equal(f["model.3.conv.weight"], w)
+    np.testing.assert_array_equal(f["model.24.m.1.bias"], sd["model.24.m.1.bias"])

@@ -136,8 +136,8 @@ struct vc_engine {
     bool profiling = false;
     vc::ProfCat prof[VC_PROF_NCAT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::map<std::pair<const void*, long>, int> tuned;   // conv autotune cache: (weights, size bucket) -> tile config
-    bool profiling_tune_off = false;
+    std::map<std::string, int> tuned;            // conv autotune cache: shape signature -> tile config (engine.hip::tune_key)
+    bool tuned_dirty = false;
     std::string op_log;                          // per-launch lines "name M N K tile ms" while profiling
     double last_ms = 0;
 

@@ -156,3 +156,25 @@ def fold_reid(sd):
         if down or ci != co:
             out[name + ".downsample"] = f(name + ".downsample.0", name + ".downsample.1")
     return out
+
+
+def fold_yolo_state_dict(sd, eps=YOLO_BN_EPS):
+    """Un-fused ultralytics/yolov5 v6.0 state_dict (`...conv.weight` + `...bn.{weight,bias,running_mean,running_var}`)
+    -> the fused {name+'.weight', name+'.bias'} dict the engine consumes (what `model.fuse()` does at hub load time).
+    Entries that are already fused (conv has a bias, no bn) and the Detect head (`model.24.m.i.*`) pass through."""
+    out = {}
+    for k in sd:
+        if not k.endswith(".weight") or np.asarray(sd[k]).ndim != 4:
+            continue
+        name = k[: -len(".weight")]
+        w = np.asarray(sd[k], np.float32)
+        bn = name[: -len("conv")] + "bn" if name.endswith(".conv") else None
+        if bn is not None and bn + ".running_var" in sd:
+            out[name + ".weight"], out[name + ".bias"] = fold_bn(w, sd.get(name + ".bias"), np.asarray(sd[bn + ".weight"], np.float32),
+                                                                 np.asarray(sd[bn + ".bias"], np.float32),
+                                                                 np.asarray(sd[bn + ".running_mean"], np.float32),
+                                                                 np.asarray(sd[bn + ".running_var"], np.float32), eps)
+        else:
+            out[name + ".weight"] = w
+            out[name + ".bias"] = np.asarray(sd.get(name + ".bias", np.zeros(w.shape[0])), np.float32)
+    return out
