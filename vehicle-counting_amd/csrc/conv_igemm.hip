@@ -15,6 +15,7 @@
 //
 // bf16 path : v_mfma_f32_16x16x32_bf16, fp32 accumulate, one RNE rounding on store.
 // fp32 path : v_mfma_f32_16x16x4_f32 (exact fmaf chain) -- the tight-parity mode (SURVEY.md 8d ladder).
+#include <algorithm>
 #include <cstdlib>
 
 #include "vc_common.h"
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     static_assert(KC == 4 || KC == 8, "K tile");
 
     __shared__ __attribute__((aligned(16))) uint4 lds[2][(BP + BC) * KC];
+    if (p.ablate == 6) return;                                 // launch floor (diagnostics)
 
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
     // range of tiles so the channel tiles that share one pixel tile hit the same private L2.
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.w), 0, (int)((size_t)((p.Cout + 127) / 128 * 128) * p.Kw * ES), 0x00020000);
 
-    // per staged pixel row: byte offset of its (iy0, ix0) corner and the validity mask of the kh*kw taps
+    // per staged pixel row: byte offset of its (iy0, ix0) corner and the validity mask of the kh*kw taps.
+    // (The prologue/epilogue are VALU-issue bound -- ~6 waves per SIMD each run them -- so no integer divisions by run-time
+    // values here: quotients come from an exact float reciprocal with a +-1 fix-up, the mask from row/column ranges.)
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
     uint32_t xoff[XI];
     unsigned long long xmask[XI];
 #pragma unroll
@@ -115,18 +120,24 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
         const int m = m0 + prow + PASS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int b = mm / HoWo;
+        int b = (int)((float)mm * inv_howo);                     // mm < 2^24: the float product is within 1 of the quotient
+        b -= (b * HoWo > mm) ? 1 : 0;
+        b += ((b + 1) * HoWo <= mm) ? 1 : 0;
         const int rem = mm - b * HoWo;
-        const int oy = rem / p.Wo;
+        int oy = (int)((float)rem * inv_wo);
+        oy -= (oy * p.Wo > rem) ? 1 : 0;
+        oy += ((oy + 1) * p.Wo <= rem) ? 1 : 0;
         const int ox = rem - oy * p.Wo;
         const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
         xoff[i] = (uint32_t)((((b * p.H + iy0) * p.W + ix0) * p.in_cs + p.in_co) * ES);
+        // valid taps: r in [r_lo, r_hi), s in [s_lo, s_hi)
+        const int r_lo = max(0, -iy0), r_hi = min(p.kh, p.H - iy0);
+        const int s_lo = max(0, -ix0), s_hi = min(p.kw, p.W - ix0);
         unsigned long long mk = 0;
-        if (ok)
-            for (int t = 0; t < ntap; ++t) {
-                const int r = t / p.kw, s = t - r * p.kw;
-                if ((unsigned)(iy0 + r) < (unsigned)p.H && (unsigned)(ix0 + s) < (unsigned)p.W) mk |= 1ull << t;
-            }
+        if (ok && s_hi > s_lo) {
+            const unsigned long long rowbits = ((1ull << (s_hi - s_lo)) - 1ull) << s_lo;
+            for (int r = r_lo; r < r_hi; ++r) mk |= rowbits << (r * p.kw);
+        }
         xmask[i] = mk;
     }
     uint32_t woff[WI];
@@ -187,14 +198,16 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
         for (int i = 0; i < CT; ++i) wfrag[h][i] = BP * KC + lds_slot<KC>(wc * WTC + i * 16 + frow, h * 4 + fch);
     }
 
+    if (p.ablate == 5) { if (xmask[0] == 0x123456789ull) ((float*)p.out)[0] = 1.f; return; }     // prologue only
     VC_STAGE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < (p.ablate == 3 ? 0 : nk); ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) VC_STAGE(kt + 1, buf ^ 1);      // DMA of the next tile runs under this tile's MFMAs
+        if (kt + 1 < nk && p.ablate != 1) VC_STAGE(kt + 1, buf ^ 1);      // DMA of the next tile runs under this tile's MFMAs
 #pragma unroll
         for (int h = 0; h < KC / 4; ++h) {
+            if (p.ablate == 2) break;
             Chunk xa[PT], wa[CT];
 #pragma unroll
             for (int i = 0; i < PT; ++i) xa[i].u = lds[buf][xfrag[h][i]];
@@ -219,27 +232,37 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
 #undef VC_STAGE
 
     // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]
+    if (p.ablate == 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }           // no epilogue
     const int nbase = n0 + wc * WTC + fch * 4;
+    float4 bias[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // 32-bit element offsets + buffer stores (SGPR descriptors): no 64-bit address arithmetic per tile
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res_mode != RES_NONE ? p.res : p.bias), 0, 0x7ffffff0, 0x00020000);
+    const bool wide_out = F32 || p.out_f32;
+    const int OES = wide_out ? 4 : 2;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
         const int m = m0 + wp * WTP + b * 16 + frow;
         if (m >= p.M) continue;
-        const size_t orow = (size_t)m * p.out_cs + p.out_co, rrow = (size_t)m * p.res_cs + p.res_co;
-        const size_t orow2 = (size_t)m * p.out2_cs + p.out2_co;
+        const int orow = m * p.out_cs + p.out_co, rrow = m * p.res_cs + p.res_co, orow2 = m * p.out2_cs + p.out2_co;
 #pragma unroll
         for (int a = 0; a < CT; ++a) {
             const int n = nbase + a * 16;
             if (n >= p.Cout) continue;
-            const float4 bv = *(const float4*)(p.bias + n);
-            float v[4] = {acc[a][b][0] + bv.x, acc[a][b][1] + bv.y, acc[a][b][2] + bv.z, acc[a][b][3] + bv.w};
+            float v[4] = {acc[a][b][0] + bias[a].x, acc[a][b][1] + bias[a].y, acc[a][b][2] + bias[a].z, acc[a][b][3] + bias[a].w};
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             const int nvalid = p.Cout - n >= 4 ? 4 : p.Cout - n;
             if (p.res_mode != RES_NONE) {
                 if constexpr (F32) {
-                    const float4 t = *(const float4*)((const float*)p.res + rrow + n);
-                    rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrd, (rrow + n) * 4, 0, 0);
+                    rv[0] = __uint_as_float(t.x); rv[1] = __uint_as_float(t.y); rv[2] = __uint_as_float(t.z); rv[3] = __uint_as_float(t.w);
                 } else {
-                    const uint2 t = *(const uint2*)((const uint16_t*)p.res + rrow + n);
+                    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (rrow + n) * 2, 0, 0);
                     rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
                     rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
                 }
@@ -252,22 +275,26 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
                 if (p.res_mode == RES_AFTER_ACT) t += rv[j];
                 v[j] = t;
             }
-            const bool second = p.split > 0 && n >= p.split;            // lane-uniform per 4-channel group
-            if (F32 || p.out_f32) {
-                float* o = second ? (float*)p.out2 + orow2 + (n - p.split) : (float*)p.out + orow + n;
-                if (nvalid == 4) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < nvalid) o[j] = v[j];
-                }
-            } else {
-                uint16_t* o = second ? (uint16_t*)p.out2 + orow2 + (n - p.split) : (uint16_t*)p.out + orow + n;
-                if (nvalid == 4) {
-                    *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            const bool second = p.split > 0 && n >= p.split;            // uniform per 4-channel group
+            const int eoff = (second ? orow2 + (n - p.split) : orow + n) * OES;
+            if (nvalid == 4) {
+                if (wide_out) {
+                    const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(t, osrd2, eoff, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(t, osrd, eoff, 0, 0);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < nvalid) o[j] = f32_to_bf16(v[j]);
+                    const u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    if (second) __builtin_amdgcn_raw_buffer_store_b64(t, osrd2, eoff, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(t, osrd, eoff, 0, 0);
                 }
+            } else {                                                      // ragged channel tail (e.g. Detect's 255 outputs)
+                char* ob = (char*)(second ? p.out2 : p.out) + eoff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nvalid) {
+                        if (wide_out) ((float*)ob)[j] = v[j];
+                        else ((uint16_t*)ob)[j] = f32_to_bf16(v[j]);
+                    }
             }
         }
     }
@@ -346,6 +373,8 @@ int conv_check(const ConvP& p) {
     VC_CHECK((size_t)p.B * p.H * p.W * p.in_cs * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: input tensor exceeds the 2 GiB buffer descriptor");
     VC_CHECK((size_t)((p.Cout + 127) / 128 * 128) * p.Kp * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: weights exceed 2 GiB");
     VC_CHECK(p.kh * p.kw <= 40, VC_ERR_ARG, "conv: at most 40 taps (validity mask is 64 bits incl. K padding)");
+    VC_CHECK(p.M < (1 << 24), VC_ERR_CAPACITY, "conv: more than 2^24 output pixels in one launch");
+    VC_CHECK((size_t)p.M * std::max(p.out_cs, std::max(p.res_cs, p.out2_cs)) * 4 < (1ull << 31), VC_ERR_CAPACITY, "conv: output tensor exceeds 2 GiB");
     return VC_OK;
 }
 

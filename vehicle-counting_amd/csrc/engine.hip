@@ -945,6 +945,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         c.K = p.K; c.Kp = p.Kp; c.act = d->act; c.res_mode = res ? d->res_mode : RES_NONE; c.out_f32 = 0; c.prec = prec;
         c.M = d->b * Ho * Wo;
         c.cfg = getenv("VC_CONV_CFG") ? atoi(getenv("VC_CONV_CFG")) : -1;
+        c.ablate = getenv("VC_CONV_ABLATE") ? atoi(getenv("VC_CONV_ABLATE")) : 0;
         st = launch_conv(c, nullptr);
         if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
     }

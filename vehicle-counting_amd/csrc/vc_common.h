@@ -81,6 +81,7 @@ struct ConvP {
     // one launch, e.g. C3.cv1 + C3.cv2); split is a multiple of 4, 0 = single destination
     void* out2;
     int split, out2_cs, out2_co;
+    int ablate;          // diagnostics only (VC_CONV_ABLATE): 1 = skip the staging DMA after the first tile, 2 = skip the MFMAs
 };
 
 int launch_conv(const ConvP& p, hipStream_t s);
