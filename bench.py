@@ -29,7 +29,7 @@ from vehicle_counting_amd.synth import synth_frames  # noqa: E402
 from vehicle_counting_amd.track import VideoCounting  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
 
-B = 16                 # frames per step
+B = int(os.environ.get("VC_BENCH_B", 16))   # frames per step
 H = W = 640
 NC = 80
 N_OBJ = 12

@@ -29,3 +29,10 @@ for i in range(20):
     eng._drain = eng.stream_run(tr, ptr(i), B, H, W)
 t1 = time.perf_counter()
 print("serial submit+sync+run per step ms", (t1 - t0) / 20 * 1e3)
+# tracker round trips without a concurrent detector: submit, wait for everything, then run with VC_TIMING on
+if os.environ.get("VC_TIMING"):
+    print("--- serial (no detector running during the tracker loop) ---")
+    for i in range(20):
+        eng.stream_submit(ptr(i), B, H, W)
+        eng.sync(); torch.cuda.synchronize(); time.sleep(0.002)
+        eng.stream_run(tr, ptr(i), B, H, W)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvcount_hip.so")
+LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(_HERE, "libvcount_hip.so")   # override: A/B runs of two builds on one box
 
 VC_OK = 0
 PREC_BF16, PREC_F32 = 0, 1

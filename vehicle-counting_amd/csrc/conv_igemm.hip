@@ -25,8 +25,9 @@ namespace vc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 union Chunk {
-    uint4 u;
+    u32x4v u;
     bf16x8 h;
     float f[4];
 };
@@ -64,7 +65,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v
 // hardware answers with zeros (verified by the padded test cases); the per-row validity of all kh*kw taps is one 64-bit
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
-template <int BP, int BC, int WP, int WC, int KC, bool F32>
+template <int BP, int BC, int WP, int WC, int KC, int NS, bool F32>
 __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     constexpr int ES = F32 ? 4 : 2;           // element size
     constexpr int CH = 16 / ES;               // elements per 16-byte chunk
@@ -78,10 +79,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     constexpr uint32_t OOB = 0x80000000u;     // beyond every descriptor's num_records -> the load returns 0
     static_assert(WP * WC == 4, "4 waves per workgroup");
     static_assert(BP % PASS == 0 && BC % RPI == 0 && WTP % 16 == 0 && WTC % 16 == 0, "tile shape");
+    constexpr int ROWS = BP + WI * PASS;       // rows of one stage: every wave issues the same XI + WI DMA instructions per tile
+    constexpr int PER = XI + WI;
     static_assert(KC == 4 || KC == 8, "K tile");
+    static_assert(NS >= 2 && (NS - 2) * PER <= 63, "ring depth: the counted s_waitcnt must fit vmcnt");
 
-    __shared__ __attribute__((aligned(16))) uint4 lds[2][(BP + BC) * KC];
+    __shared__ __attribute__((aligned(16))) uint4 lds[NS][ROWS * KC];
     if (p.ablate == 6) return;                                 // launch floor (diagnostics)
+#define VC_TS(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    VC_TS(0);
 
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each XCD a contiguous
     // range of tiles so the channel tiles that share one pixel tile hit the same private L2.
@@ -168,9 +174,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[buf][(PASS * i + uwave * RPI) * KC], 16, (int)o, 0, 0, 0); \
         }                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                                 \
-            if (BC % PASS == 0 || PASS * i + uwave * RPI < BC)                                                           \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[buf][BP * KC + (PASS * i + uwave * RPI) * KC], 16, \
-                                                         (int)(woff[i] + (uint32_t)((kt) * BK * ES)), 0, 0, 0);         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[buf][BP * KC + (PASS * i + uwave * RPI) * KC], 16,     \
+                                                     (int)(woff[i] + (uint32_t)((kt) * BK * ES)), 0, 0, 0);             \
         }                                                                                                                \
         int cc = kc_c + BK;                                                                                              \
         while (cc >= p.Cin) {                                                                                            \
@@ -193,26 +198,45 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
     for (int h = 0; h < KC / 4; ++h) {
 #pragma unroll
-        for (int i = 0; i < PT; ++i) xfrag[h][i] = lds_slot<KC>(wp * WTP + i * 16 + frow, h * 4 + fch);
+        for (int i = 0; i < PT; ++i) xfrag[h][i] = 16 * lds_slot<KC>(wp * WTP + i * 16 + frow, h * 4 + fch);          // byte offsets in a stage
 #pragma unroll
-        for (int i = 0; i < CT; ++i) wfrag[h][i] = BP * KC + lds_slot<KC>(wc * WTC + i * 16 + frow, h * 4 + fch);
+        for (int i = 0; i < CT; ++i) wfrag[h][i] = 16 * (BP * KC + lds_slot<KC>(wc * WTC + i * 16 + frow, h * 4 + fch));
     }
 
     if (p.ablate == 5) { if (xmask[0] == 0x123456789ull) ((float*)p.out)[0] = 1.f; return; }     // prologue only
-    VC_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // NS-stage ring: tiles kt+1 .. kt+NS-1 are in flight while tile kt is multiplied.  LDS-DMA loads return in order, so
+    // "tile kt+1 has landed" is vmcnt <= (NS-2) * PER.  Tiles past the K extent are still issued (range-checked buffer
+    // loads into ring slots nobody reads) so the count stays uniform.
+    //
+    // The fragment reads are inline asm and the barrier is the raw s_barrier: hipcc counts an LDS-DMA as a pending LDS
+    // write and puts `s_waitcnt vmcnt(0)` in front of every ds_read (and inside __syncthreads) it can see, which drains
+    // the tile that was just issued and serialises DMA and MFMA.  The waits that are needed are written out below.
+    VC_TS(1);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0][0];
+    constexpr uint32_t STAGE_BYTES = ROWS * KC * 16;
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) VC_STAGE(st, st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    VC_TS(2);
+    int sbuf = NS - 1;
+    uint32_t boff = lds_base;
     for (int kt = 0; kt < (p.ablate == 3 ? 0 : nk); ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk && p.ablate != 1) VC_STAGE(kt + 1, buf ^ 1);      // DMA of the next tile runs under this tile's MFMAs
+        VC_STAGE(kt + NS - 1, sbuf);                    // into the slot consumed last iteration (all waves passed its barrier)
+        sbuf = sbuf + 1 == NS ? 0 : sbuf + 1;
 #pragma unroll
         for (int h = 0; h < KC / 4; ++h) {
-            if (p.ablate == 2) break;
+            u32x4v xr[PT], wr[CT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[i]) : "v"(boff + xfrag[h][i]) : "memory");
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wr[i]) : "v"(boff + wfrag[h][i]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             Chunk xa[PT], wa[CT];
 #pragma unroll
-            for (int i = 0; i < PT; ++i) xa[i].u = lds[buf][xfrag[h][i]];
+            for (int i = 0; i < PT; ++i) { asm volatile("" : "+v"(xr[i])); xa[i].u = xr[i]; }      // the MFMAs below depend on the wait above
 #pragma unroll
-            for (int i = 0; i < CT; ++i) wa[i].u = lds[buf][wfrag[h][i]];
+            for (int i = 0; i < CT; ++i) { asm volatile("" : "+v"(wr[i])); wa[i].u = wr[i]; }
 #pragma unroll
             for (int a = 0; a < CT; ++a)
 #pragma unroll
@@ -226,9 +250,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
                     }
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        boff = boff + STAGE_BYTES == lds_base + NS * STAGE_BYTES ? lds_base : boff + STAGE_BYTES;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
+        __builtin_amdgcn_s_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the tiles issued past the K extent before the LDS is released
+    VC_TS(3);
 #undef VC_STAGE
 
     // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]
@@ -298,6 +325,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
             }
         }
     }
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VC_TS(4); }
+#undef VC_TS
 }
 
 int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights are padded to the widest K tile (KC = 8)
@@ -305,22 +334,32 @@ int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights a
 double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * (double)p.K; }
 
 // ---- tile configurations -------------------------------------------------------------------------------------------
-struct ConvCfg { int bp, bc, wp, wc, kc; };
-static const ConvCfg kCfg[] = {
-    {256, 32, 4, 1, 4},  {128, 64, 2, 2, 4},  {128, 128, 2, 2, 4}, {64, 64, 2, 2, 4},   {128, 64, 2, 2, 8},
-    {128, 128, 2, 2, 8}, {64, 64, 2, 2, 8},   {256, 64, 4, 1, 4},  {256, 64, 4, 1, 8},  {256, 128, 2, 2, 4},
-    {256, 128, 2, 2, 8}, {64, 128, 1, 4, 4},  {64, 128, 1, 4, 8},  {256, 32, 4, 1, 8},
-};
+// One list drives both the table the autotuner walks and the dispatch switch.  Rings deeper than 2 exist for bf16 only;
+// the fp32 parity path maps them to the 2-stage instantiation of the same tile.
+#define VC_CONV_CFGS(X)                                                                                          \
+    X(0, 256, 32, 4, 1, 4, 2)   X(1, 128, 64, 2, 2, 4, 2)   X(2, 128, 128, 2, 2, 4, 2)  X(3, 64, 64, 2, 2, 4, 2)      \
+    X(4, 128, 64, 2, 2, 8, 2)   X(5, 128, 128, 2, 2, 8, 2)  X(6, 64, 64, 2, 2, 8, 2)    X(7, 256, 64, 4, 1, 4, 2)     \
+    X(8, 256, 64, 4, 1, 8, 2)   X(9, 256, 128, 2, 2, 4, 2)  X(10, 256, 128, 2, 2, 8, 2) X(11, 64, 128, 1, 4, 4, 2)    \
+    X(12, 64, 128, 1, 4, 8, 2)  X(13, 256, 32, 4, 1, 8, 2)                                                          \
+    X(14, 64, 64, 2, 2, 4, 4)   X(15, 64, 64, 2, 2, 8, 3)   X(16, 64, 64, 2, 2, 8, 4)   X(17, 128, 64, 2, 2, 4, 4)    \
+    X(18, 128, 64, 2, 2, 8, 3)  X(19, 128, 128, 2, 2, 4, 4) X(20, 128, 128, 2, 2, 8, 3) X(21, 64, 128, 1, 4, 4, 4)    \
+    X(22, 64, 128, 1, 4, 8, 3)  X(23, 256, 32, 4, 1, 4, 4)  X(24, 256, 64, 4, 1, 4, 4)  X(25, 256, 64, 4, 1, 8, 3)    \
+    X(26, 256, 128, 2, 2, 4, 4) X(27, 256, 128, 2, 2, 8, 3)
+struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
+#define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
+static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
+#undef VC_X
 int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])); }
 
-template <int BP, int BC, int WP, int WC, int KC>
+template <int BP, int BC, int WP, int WC, int KC, int NS>
 static int launch_one(ConvP p, hipStream_t s) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const int bk = KC * (p.prec == PREC_F32 ? 4 : 8);
     p.Kw = p.Kp;                              // weight row stride as packed
     p.Kp = (p.K + bk - 1) / bk * bk;          // K-loop extent: only the tiles that hold real taps
-    if (p.prec == PREC_F32) hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, true>), dim3(tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, false>), dim3(tiles), dim3(256), 0, s, p);
+    static const int dyn_lds = getenv("VC_CONV_DYN_LDS") ? atoi(getenv("VC_CONV_DYN_LDS")) : 0;   // diagnostics: caps workgroups per CU
+    if (p.prec == PREC_F32) hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>), dim3(tiles), dim3(256), dyn_lds, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>), dim3(tiles), dim3(256), dyn_lds, s, p);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
@@ -336,21 +375,11 @@ static int conv_heuristic(const ConvP& p) {
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
     switch (cfg) {
-        case 0: return launch_one<256, 32, 4, 1, 4>(p, s);
-        case 1: return launch_one<128, 64, 2, 2, 4>(p, s);
-        case 2: return launch_one<128, 128, 2, 2, 4>(p, s);
-        case 3: return launch_one<64, 64, 2, 2, 4>(p, s);
-        case 4: return launch_one<128, 64, 2, 2, 8>(p, s);
-        case 5: return launch_one<128, 128, 2, 2, 8>(p, s);
-        case 6: return launch_one<64, 64, 2, 2, 8>(p, s);
-        case 7: return launch_one<256, 64, 4, 1, 4>(p, s);
-        case 8: return launch_one<256, 64, 4, 1, 8>(p, s);
-        case 9: return launch_one<256, 128, 2, 2, 4>(p, s);
-        case 10: return launch_one<256, 128, 2, 2, 8>(p, s);
-        case 11: return launch_one<64, 128, 1, 4, 4>(p, s);
-        case 12: return launch_one<64, 128, 1, 4, 8>(p, s);
-        default: return launch_one<256, 32, 4, 1, 8>(p, s);
+#define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
+        VC_CONV_CFGS(VC_X)
+#undef VC_X
     }
+    return VC_ERR_ARG;
 }
 
 int conv_check(const ConvP& p);

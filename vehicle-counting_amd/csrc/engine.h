@@ -1,5 +1,6 @@
 // Engine internals shared between engine.hip (networks), tracker.hip (DeepSORT) and stream.hip (fused path).
 #pragma once
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -129,6 +130,12 @@ struct vc_engine {
     double* h_cost = nullptr; double* hd_cost = nullptr;
     double* h_mean = nullptr; double* hd_mean = nullptr;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
+    std::vector<int> slot_chain;                 // scratch of track_launch: slot -> chain index, -1 outside a call
+    unsigned* d_track_counter = nullptr;         // workgroups of the running tracker kernel that have finished
+    unsigned* h_track_flag = nullptr; unsigned* hd_track_flag = nullptr;   // pinned completion word (sequence number)
+    unsigned track_seq = 0;
+    bool track_inflight = false;
+    std::vector<vc::TrackChainRec> chain_scratch;
     size_t cost_cap = 0;
     int det_cap = 0;
 
@@ -175,13 +182,19 @@ struct StepCtx {
     std::vector<int> det_base, featrow;
     std::vector<std::vector<int>> app_job, iou_job;
     std::vector<double> det_xyah;
+    int n_jobs = 0;                        // cost jobs staged in e->h_stage (+ their device aliases)
+    const TrackJobA* h_jobs = nullptr; const TrackJobA* d_jobs = nullptr;
+    const int* d_featrow = nullptr; const double* d_xyah = nullptr; const double* d_tlwh = nullptr;
     // phase B products
+    std::vector<TrackOpB> ops;             // pending device operations (carried by the next track_launch)
     struct Emit { int row; int64_t id; int label; };
     std::vector<Emit> emit;
     std::vector<int> mean_offsets;
 };
-int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat);
-int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat);
+int track_prepare_a(vc_engine* e, StepCtx& c);
+int track_host_b(vc_engine* e, StepCtx& c);
+int track_launch(vc_engine* e, const StepCtx* cb, const float* feat_b, const StepCtx* ca, const float* feat_a);
+int track_wait(vc_engine* e);
 void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6);
 void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
                const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0);

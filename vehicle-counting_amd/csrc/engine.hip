@@ -946,8 +946,30 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         c.M = d->b * Ho * Wo;
         c.cfg = getenv("VC_CONV_CFG") ? atoi(getenv("VC_CONV_CFG")) : -1;
         c.ablate = getenv("VC_CONV_ABLATE") ? atoi(getenv("VC_CONV_ABLATE")) : 0;
+        long long* dbg = nullptr;
+        const size_t dbg_n = (size_t)1 << 16;
+        if (getenv("VC_CONV_DBG") && hipMalloc((void**)&dbg, dbg_n * 64) == hipSuccess) { hipMemset(dbg, 0, dbg_n * 64); c.dbg = dbg; }
         st = launch_conv(c, nullptr);
         if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("conv kernel failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
+        if (dbg) {       // per-workgroup phase times (100 MHz timestamps), averaged
+            std::vector<long long> h(dbg_n * 8);
+            hipMemcpy(h.data(), dbg, dbg_n * 64, hipMemcpyDeviceToHost);
+            double acc[4] = {0, 0, 0, 0}; long n = 0; long long lo = INT64_MAX, hi = 0;
+            for (size_t b = 0; b < dbg_n; ++b) {
+                const long long* t = &h[b * 8];
+                if (!t[0] || !t[4]) continue;
+                for (int i = 0; i < 4; ++i) acc[i] += (double)(t[i + 1] - t[i]);
+                lo = std::min(lo, t[0]); hi = std::max(hi, t[4]); ++n;
+            }
+            std::vector<double> st, du;
+            for (size_t b = 0; b < dbg_n; ++b) { const long long* t = &h[b * 8]; if (t[0] && t[4]) { st.push_back((double)(t[0] - lo) / 100); du.push_back((double)(t[4] - t[0]) / 100); } }
+            std::sort(st.begin(), st.end()); std::sort(du.begin(), du.end());
+            if (n) fprintf(stderr, "[vc conv dbg] start offsets us p10/p50/p90/max %.1f %.1f %.1f %.1f ; lifetimes us p10/p50/p90/max %.1f %.1f %.1f %.1f\n",
+                           st[n / 10], st[n / 2], st[n * 9 / 10], st[n - 1], du[n / 10], du[n / 2], du[n * 9 / 10], du[n - 1]);
+            if (n) fprintf(stderr, "[vc conv dbg] %ld workgroups, us per workgroup: prologue %.2f first-tile %.2f k-loop %.2f epilogue %.2f ; first start -> last end %.2f us\n",
+                           n, acc[0] / n / 100, acc[1] / n / 100, acc[2] / n / 100, acc[3] / n / 100, (double)(hi - lo) / 100);
+            hipFree(dbg);
+        }
     }
     if (st == VC_OK) {
         std::vector<uint8_t> buf(npix_out * cout_s * es);

@@ -91,9 +91,10 @@ struct CostJob {
 // fused per-frame tracker kernels (one launch per phase; descriptors and results may live in host-mapped pinned memory)
 struct TrackJobA { int slot, gal_count, det_off, det_n, app_off, iou_off, tsu, pad; };          // app_off / iou_off < 0: no such row
 struct TrackOpB { int slot, kind, gal_pos, feat_row, out_row, pad0, pad1, pad2; double z[4]; }; // kind 0 none, 1 update, 2 initiate
-int launch_track_phase_a(const TrackPool& tp, const TrackJobA* jobs, int njobs, const float* feat, const int* det_feat_row,
-                         const double* det_xyah, const double* det_tlwh, double* out, hipStream_t s);
-int launch_track_phase_b(const TrackPool& tp, const TrackOpB* ops, int nops, const float* feat, double* mean_out, hipStream_t s);
+struct TrackChainRec { TrackOpB op; TrackJobA job; };   // per touched slot: op.kind < 0 = no operation, job.slot < 0 = no cost job (96 B)
+int launch_track_step(const TrackPool& tp, const TrackChainRec* recs, int nchains, const float* feat_ops, const float* feat_jobs,
+                      double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh, double* out,
+                      unsigned* counter, unsigned* done_flag, unsigned seq, hipStream_t s);
 // appearance cost (min cosine distance over the gallery) with Mahalanobis gating folded in:
 //   out[out_off + i] = gate(slot, det i) > 9.4877 ? 1e5 : min_s (1 - <g_s/|g_s|, f_i/|f_i|>)
 // feature of detection g (global index det_off + i) is feat[det_feat_row[g]]

@@ -30,7 +30,8 @@ struct Tm {
     void report() {
         if (!on || ++calls % 10) return;
         fprintf(stderr, "[vc timing, us per call] wait_det %.0f marshal %.0f reid_issue %.0f build %.0f phaseA_issue %.0f sync %.0f emit %.0f phaseB %.0f\n",
-                acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, acc[4] / calls, acc[5] / calls, acc[6] / calls, acc[7] / calls);
+                acc[0] / 10, acc[1] / 10, acc[2] / 10, acc[3] / 10, acc[4] / 10, acc[5] / 10, acc[6] / 10, acc[7] / 10);
+        for (double& a : acc) a = 0;                   // windowed: the last 10 calls
     }
 } g_tm;
 }  // namespace
@@ -178,7 +179,7 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         out_m[f] = 0;
     }
     g_tm.lap(1);
-    // Tracker pipeline: phase B of frame f and phase A of the next non-empty frame share one synchronisation.
+    // Tracker pipeline: the operations of frame f and the cost jobs of the next non-empty frame are one launch.
     StepCtx ctx[2];
     int cur = 0, prev_f = -1;
     auto flush_prev = [&](int which) -> int {             // rows of the previously stepped frame (its means have landed)
@@ -207,20 +208,23 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         if (ids.empty()) continue;
         build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), pd.row0[f]);
         g_tm.lap(3);
-        VC_TRY(track_phase_a(e, ctx[cur], d_feat));
+        VC_TRY(track_prepare_a(e, ctx[cur]));
+        // one launch: the pending operations of the previous frame + the cost jobs of this one
+        VC_TRY(track_launch(e, prev_f >= 0 ? &ctx[cur ^ 1] : nullptr, d_feat, &ctx[cur], d_feat));
         g_tm.lap(4);
-        VC_HIP(hipStreamSynchronize(e->stream));          // cost rows of f are here; so are the means of the previous frame
+        VC_TRY(try_issue_next(e));
+        VC_TRY(track_wait(e));                            // cost rows of f are here; so are the means of the previous frame
         g_tm.lap(5);
         VC_TRY(flush_prev(cur ^ 1));
         g_tm.lap(6);
-        VC_TRY(track_phase_b(e, ctx[cur], d_feat));
-        VC_TRY(try_issue_next(e));
+        VC_TRY(track_host_b(e, ctx[cur]));
         g_tm.lap(7);
         prev_f = f;
         cur ^= 1;
     }
     if (prev_f >= 0) {
-        VC_HIP(hipStreamSynchronize(e->stream));
+        VC_TRY(track_launch(e, &ctx[cur ^ 1], d_feat, nullptr, nullptr));
+        VC_TRY(track_wait(e));
         g_tm.lap(5);
         VC_TRY(flush_prev(cur ^ 1));
         g_tm.lap(6);

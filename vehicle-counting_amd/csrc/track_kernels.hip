@@ -147,15 +147,36 @@ __device__ __forceinline__ double maha4(const double* m, const double L[16], con
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// store to host-mapped pinned memory: system-scope write-through, complete once the wave's vmcnt drains
+__device__ __forceinline__ void host_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Descriptor loads (pinned host memory, or device memory in the KAT entry points): system-scope vector loads, so that
+// every workgroup fetches a whole record / detection chunk in one round trip to pinned memory and stages it in LDS.
+__device__ __forceinline__ unsigned long long sys_load_u64(const void* p) {
+    return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned sys_load_u32(const void* p) {
+    return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sys_load_f64(const double* p) { return __longlong_as_double((long long)sys_load_u64(p)); }
+
+// LDS scratch of one tracker workgroup
+struct TrackShared {
+    float smax[4][16];
+    float red[2];
+    int featrow[16];                 // feature rows / xyah of the 16 detections being scored
+    double xyah[16][4];
+    unsigned long long rec[12];      // the chain record being executed
+};
+
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
 // cost[d] = min_s (1 - <g_s, f_d/|f_d|>) with the gallery rows g_s stored already normalised (store_gallery_row):
 // a (S x 512) x (512 x D) product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, an exact fmaf chain), one 16-sample
 // tile per wave against 16 detections at a time; |f_d|^2 falls out of the same operand loads.  The Mahalanobis gate of
 // linear_assignment.py:148-192 is folded in (lane d of wave 0).
-__device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const CostJob& jb, const float* __restrict__ feat,
-                                                   const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
-                                                   double* __restrict__ out) {
-    __shared__ float smax[4][16];
+__device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const CostJob& jb, const float* feat, const int* det_feat_row,
+                                                   const double* det_xyah, double* out, TrackShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int S = jb.gal_count, D = jb.det_n;
@@ -165,14 +186,20 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
     chol4(Sg, L);
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
-        const int dcl = min(d0 + col, D - 1);
-        const float* fptr = feat + (size_t)det_feat_row[jb.det_off + dcl] * VC_FEAT_DIM + kq * 4;
+        // the chunk's descriptors -> LDS (one round trip to pinned memory for all 16 detections)
+        if (threadIdx.x < 16) sh.featrow[threadIdx.x] = (int)sys_load_u32(det_feat_row + jb.det_off + min(d0 + (int)threadIdx.x, D - 1));
+        else if (threadIdx.x < 80) {
+            const int t = threadIdx.x - 16, d = min(d0 + (t >> 2), D - 1);
+            sh.xyah[t >> 2][t & 3] = sys_load_f64(det_xyah + (size_t)(jb.det_off + d) * 4 + (t & 3));
+        }
+        __syncthreads();
+        const float* fptr = feat + (size_t)sh.featrow[col] * VC_FEAT_DIM + kq * 4;
         float best = -INFINITY, ss = 0.f;
         for (int st = wave; st * 16 < S; st += 4) {
             const float* gptr = gal + (size_t)min(st * 16 + col, S - 1) * VC_FEAT_DIM + kq * 4;
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
             float s2 = 0.f;
-#pragma unroll 4
+#pragma unroll 8
             for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
                 const float4 a = *(const float4*)(gptr + k0), b = *(const float4*)(fptr + k0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
@@ -190,34 +217,35 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
         best = fmaxf(best, __shfl_xor(best, 32));
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
-        if (lane < 16) smax[wave][lane] = best;
+        if (lane < 16) sh.smax[wave][lane] = best;
         __syncthreads();
         if (wave == 0 && lane < 16 && d0 + lane < D) {
-            const float bmax = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+            const float bmax = fmaxf(fmaxf(sh.smax[0][lane], sh.smax[1][lane]), fmaxf(sh.smax[2][lane], sh.smax[3][lane]));
             const float cosv = bmax * (1.0f / sqrtf(ss));
-            const double g2 = maha4(m, L, det_xyah + (size_t)(jb.det_off + d0 + lane) * 4);
-            out[jb.out_off + d0 + lane] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+            const double g2 = maha4(m, L, sh.xyah[lane]);
+            host_store(out + jb.out_off + d0 + lane, g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv));
         }
         __syncthreads();
     }
 }
 
 // gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector)
-__device__ __forceinline__ void store_gallery_row(float* dst, const float* src, int t /* 0..127 */, float* red /* [2] */) {
-    const float4 v = ((const float4*)src)[t];
+__device__ __forceinline__ void store_gallery_row(float* dst, const float* src, int t /* threads 0..127 work */, float* red /* [2] */) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < 128) v = ((const float4*)src)[t];
     float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if ((t & 63) == 0) red[t >> 6] = ss;
+    if (t < 128 && (t & 63) == 0) red[t >> 6] = ss;
     __syncthreads();
     const float nrm = sqrtf(red[0] + red[1]);
-    ((float4*)dst)[t] = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+    if (t < 128) ((float4*)dst)[t] = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
 }
 
-__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* __restrict__ feat,
-                                                              const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
-                                                              double* __restrict__ out) {
-    appearance_row_dev(tp, jobs[blockIdx.x], feat, det_feat_row, det_xyah, out);
+__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* feat, const int* det_feat_row,
+                                                              const double* det_xyah, double* out) {
+    __shared__ TrackShared sh;
+    appearance_row_dev(tp, jobs[blockIdx.x], feat, det_feat_row, det_xyah, out, sh);
 }
 
 __device__ __forceinline__ double iou_tlwh(const double* b, const double* c);
@@ -245,56 +273,84 @@ __global__ __launch_bounds__(128) void gallery_write_kernel(TrackPool tp, const 
     store_gallery_row(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x, red);
 }
 
-// ---- fused per-frame kernels (tracker.hip: track_phase_a / track_phase_b) ------------------------------------------
-// Phase A, one workgroup per live track of the stepped trackers: Kalman predict in place, then (confirmed tracks) the
-// appearance + gate row and (IoU candidates) the IoU row against the track's tracker's detections.  Inputs are read from
-// and results written to host-mapped pinned memory, so a phase is ONE kernel launch and no copy operations.
-__global__ __launch_bounds__(256) void track_phase_a_kernel(TrackPool tp, const TrackJobA* __restrict__ jobs, const float* __restrict__ feat,
-                                                            const int* __restrict__ det_feat_row, const double* __restrict__ det_xyah,
-                                                            const double* __restrict__ det_tlwh, double* __restrict__ out) {
-    const TrackJobA jb = jobs[blockIdx.x];
-    if (threadIdx.x == 0) kalman_predict_dev(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64);
+// ---- per-frame tracker work (tracker.hip: track_launch) -------------------------------------------------------------
+// A "chain" is everything one track slot needs between two host matching steps: first the slot's pending operation of
+// frame f -- Kalman update (kind 1) / initiate (kind 2) / nothing (kind 0), the gallery ring write of the matched feature
+// and the posterior mean of output-eligible tracks to the host -- then the slot's cost job of frame f+1: Kalman predict in
+// place, (confirmed tracks) the appearance + gate row and (IoU candidates) the IoU row against its tracker's detections.
+// A slot belongs to exactly one chain per step, so chains never wait for each other.  Records, detections and results
+// live in host-mapped pinned memory: no copy operations.
+__device__ __forceinline__ void run_chain(const TrackPool& tp, const TrackChainRec* rec_ptr, const float* feat_ops, const float* feat_jobs,
+                                          double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh,
+                                          double* out, TrackShared& sh) {
+    if (threadIdx.x < 12) sh.rec[threadIdx.x] = sys_load_u64((const unsigned long long*)rec_ptr + threadIdx.x);
     __syncthreads();
-    if (jb.app_off >= 0) {
-        const CostJob cj{jb.slot, jb.gal_count, jb.det_off, jb.det_n, jb.app_off, jb.tsu};
-        appearance_row_dev(tp, cj, feat, det_feat_row, det_xyah, out);
+    const TrackChainRec& rec = *(const TrackChainRec*)sh.rec;
+    const TrackOpB op = rec.op;
+    const TrackJobA jb = rec.job;
+    __syncthreads();                       // sh.rec is free again
+    if (op.kind >= 0) {
+        double* m = tp.mean + (size_t)op.slot * 8;
+        if (threadIdx.x == 0) {
+            if (op.kind == 1) kalman_update_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+            else if (op.kind == 2) kalman_initiate_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+        }
+        if (op.feat_row >= 0)              // block-uniform
+            store_gallery_row(tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM,
+                              feat_ops + (size_t)op.feat_row * VC_FEAT_DIM, threadIdx.x, sh.red);
+        __syncthreads();
+        if (op.out_row >= 0 && threadIdx.x < 8) host_store(mean_out + (size_t)op.out_row * 8 + threadIdx.x, m[threadIdx.x]);
+        __syncthreads();
     }
-    if (jb.iou_off >= 0) {
-        double b[4];
-        mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
-        for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x)
-            out[jb.iou_off + d] = jb.tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, det_tlwh + (size_t)(jb.det_off + d) * 4);
+    if (jb.slot >= 0) {
+        if (threadIdx.x == 0) kalman_predict_dev(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64);
+        __syncthreads();
+        if (jb.app_off >= 0) {
+            const CostJob cj{jb.slot, jb.gal_count, jb.det_off, jb.det_n, jb.app_off, jb.tsu};
+            appearance_row_dev(tp, cj, feat_jobs, det_feat_row, det_xyah, out, sh);
+        }
+        if (jb.iou_off >= 0) {
+            double b[4];
+            mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
+            for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x) {
+                double c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = sys_load_f64(det_tlwh + (size_t)(jb.det_off + d) * 4 + k);
+                host_store(out + jb.iou_off + d, jb.tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, c));
+            }
+        }
     }
 }
 
-// Phase B, one workgroup per track operation: Kalman update (kind 1) or initiate (kind 2) or nothing (kind 0), the
-// gallery ring write of the matched / initial feature, and the posterior mean of output-eligible tracks to the host.
-__global__ __launch_bounds__(128) void track_phase_b_kernel(TrackPool tp, const TrackOpB* __restrict__ ops, const float* __restrict__ feat,
-                                                            double* __restrict__ mean_out) {
-    const TrackOpB op = ops[blockIdx.x];
-    double* m = tp.mean + (size_t)op.slot * 8;
+// One launch per step (the blocking entry points and the profiling mode): one workgroup per chain; the last workgroup to
+// finish publishes `seq` to a pinned word, which the host polls instead of paying a stream synchronisation.
+__global__ __launch_bounds__(256) void track_step_kernel(TrackPool tp, const TrackChainRec* recs, const float* feat_ops,
+                                                         const float* feat_jobs, double* mean_out, const int* det_feat_row,
+                                                         const double* det_xyah, const double* det_tlwh, double* out,
+                                                         unsigned* counter, unsigned* done_flag, unsigned seq) {
+    __shared__ TrackShared sh;
+    run_chain(tp, recs + blockIdx.x, feat_ops, feat_jobs, mean_out, det_feat_row, det_xyah, det_tlwh, out, sh);
+    // completion: results went to pinned memory as system-scope write-through stores (host_store), so a workgroup only
+    // has to wait for its own stores to be acknowledged
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (op.kind == 1) kalman_update_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
-        else if (op.kind == 2) kalman_initiate_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+        // relaxed on purpose: an agent/system RELEASE here is a write-back of the XCD's whole L2 (full of the detector's
+        // dirty output lines) per workgroup; the results are already write-through and acknowledged (vmcnt(0) above)
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    __shared__ float red[2];
-    if (op.feat_row >= 0)              // block-uniform
-        store_gallery_row(tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM,
-                          feat + (size_t)op.feat_row * VC_FEAT_DIM, threadIdx.x, red);
-    __syncthreads();
-    if (op.out_row >= 0 && threadIdx.x < 8) mean_out[(size_t)op.out_row * 8 + threadIdx.x] = m[threadIdx.x];
 }
 
-int launch_track_phase_a(const TrackPool& tp, const TrackJobA* jobs, int njobs, const float* feat, const int* det_feat_row,
-                         const double* det_xyah, const double* det_tlwh, double* out, hipStream_t s) {
-    if (njobs <= 0) return VC_OK;
-    hipLaunchKernelGGL(track_phase_a_kernel, dim3(njobs), dim3(256), 0, s, tp, jobs, feat, det_feat_row, det_xyah, det_tlwh, out);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-int launch_track_phase_b(const TrackPool& tp, const TrackOpB* ops, int nops, const float* feat, double* mean_out, hipStream_t s) {
-    if (nops <= 0) return VC_OK;
-    hipLaunchKernelGGL(track_phase_b_kernel, dim3(nops), dim3(128), 0, s, tp, ops, feat, mean_out);
+int launch_track_step(const TrackPool& tp, const TrackChainRec* recs, int nchains, const float* feat_ops, const float* feat_jobs,
+                      double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh, double* out,
+                      unsigned* counter, unsigned* done_flag, unsigned seq, hipStream_t s) {
+    if (nchains <= 0) return VC_OK;
+    hipLaunchKernelGGL(track_step_kernel, dim3(nchains), dim3(256), 0, s, tp, recs, feat_ops, feat_jobs, mean_out, det_feat_row,
+                       det_xyah, det_tlwh, out, counter, done_flag, seq);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

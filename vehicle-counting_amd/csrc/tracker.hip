@@ -11,6 +11,8 @@
 //   deep_sort.py:25-59            DeepSort.update; modules/track.py:30-70 VideoTracker.run
 //   scipy.optimize.linear_sum_assignment (third-party; Crouse's shortest augmenting path, restated in lap_solve)
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -158,7 +160,13 @@ int tracker_init_pool(vc_engine* e) {
     // one pinned staging block per phase, mirrored on the device: a phase costs ONE host->device copy
     e->stage_cap = align16((T + D) * 4) + 2 * align16(D * 32) + align16(2 * T * sizeof(CostJob)) +      // phase A
                    2 * align16(T * 4) + 2 * align16((T + D) * 32) + align16((T + D) * 12) + 256;          // phase B (superset)
-    e->stage_cap = std::max(e->stage_cap, (T + D) * sizeof(TrackOpB) + 256);
+    e->stage_cap = std::max(e->stage_cap, (T + D) * sizeof(TrackChainRec) + 256);
+    e->slot_chain.assign(T, -1);
+    VC_TRY(dev_alloc(e, (void**)&e->d_track_counter, 64));
+    VC_HIP(hipMemset(e->d_track_counter, 0, 64));
+    VC_TRY(host_alloc(e, (void**)&e->h_track_flag, 64));
+    memset(e->h_track_flag, 0, 64);
+    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_track_flag, e->h_track_flag, 0));
     // pinned + device-mapped: the per-frame kernels read their descriptors from and write their results to host memory
     VC_TRY(host_alloc(e, (void**)&e->h_stage, e->stage_cap));
     VC_TRY(host_alloc(e, (void**)&e->h_stage2, e->stage_cap));
@@ -171,6 +179,14 @@ int tracker_init_pool(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, D * VC_FEAT_DIM * sizeof(float)));
     return VC_OK;
 }
+
+static int slot_alloc(vc_engine* e) {
+    if (e->free_slots.empty()) return -1;
+    const int slot = e->free_slots.back();
+    e->free_slots.pop_back();
+    return slot;
+}
+static void slot_free(vc_engine* e, int slot) { e->free_slots.push_back(slot); }
 
 static void tlwh_to_xyah(const double* t, double* o) {      // sort/detection.py:42-50
     o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
@@ -188,14 +204,15 @@ struct Stage {
 };
 
 // One tracker step for a set of trackers (all classes of one frame), split at its only data dependency on the device:
-//   phase A (enqueue)  Tracker.predict for every track, appearance+gate and IoU cost rows, cost D2H
-//   -- caller synchronises the stream --
-//   phase B (host)     matching cascade + IoU matching (exact LSAP), Track.update / mark_missed / _initiate_track, gallery
-//           (enqueue)  batched Kalman update / initiate, gallery ring writes, gather of the posterior means, means D2H
-// Each phase is ONE host->device copy of a pinned staging block, a few launches and ONE device->host copy.  Phase B of
-// frame f and phase A of frame f+1 share a synchronisation point (vc_stream_run), so a frame costs one round trip.
-int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat) {
-    hipStream_t s = e->stream;
+//   track_prepare_a  (host)    Tracker.predict bookkeeping, one cost job per live track (predict + appearance/gate + IoU rows)
+//   track_launch     (device)  the pending operations of the PREVIOUS frame and the cost jobs of this one, one kernel
+//   track_wait       (host)    poll the completion word; the cost rows (and the previous frame's posterior means) are in
+//                              pinned memory
+//   track_host_b     (host)    matching cascade + IoU matching (exact LSAP), Track.update / mark_missed / _initiate_track:
+//                              the Kalman update / initiate / gallery writes become the pending operations of this frame
+// so a frame costs ONE launch and ONE round trip (vc_stream_run); the blocking entry points flush the pending
+// operations with a second launch.
+int track_prepare_a(vc_engine* e, StepCtx& c) {
     const int njobs = (int)c.ids.size();
     int n_tracks = 0;
     c.n_dets = 0;
@@ -250,15 +267,77 @@ int track_phase_a(vc_engine* e, StepCtx& c, const float* d_feat) {
     VC_CHECK(c.out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", c.out, e->cost_cap);
     c.det_xyah.assign(h_xyah, h_xyah + (size_t)n_dets * 4);
     c.featrow.assign(h_featrow, h_featrow + n_dets);
-    { ProfScope ps(e, VC_PROF_TRACK);
-      VC_TRY(launch_track_phase_a(e->pool, d_jobs, n_tracks, d_feat, d_featrow, d_xyah, d_tlwh, e->hd_cost, s)); }
+    c.n_jobs = n_tracks;
+    c.h_jobs = h_jobs; c.d_jobs = d_jobs; c.d_featrow = d_featrow; c.d_xyah = d_xyah; c.d_tlwh = d_tlwh;
     return VC_OK;
 }
 
-int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
-    hipStream_t s = e->stream;
+// Chain records of one step: the pending operations of `cb` (may be null) merged with the cost jobs of `ca` (may be
+// null), one record per touched slot, written to the second pinned staging block.
+static int build_chain_recs(vc_engine* e, const StepCtx* cb, const StepCtx* ca, const TrackChainRec** d_recs, int* n_out) {
+    const int nops = cb ? (int)cb->ops.size() : 0, njobs = ca ? ca->n_jobs : 0;
+    std::vector<TrackChainRec>& tmp = e->chain_scratch;
+    tmp.clear();
+    TrackChainRec blank{};
+    blank.op.kind = -1; blank.op.slot = -1; blank.op.feat_row = -1; blank.op.out_row = -1;
+    blank.job.slot = -1; blank.job.app_off = -1; blank.job.iou_off = -1;
+    for (int i = 0; i < nops; ++i) {
+        e->slot_chain[cb->ops[i].slot] = (int)tmp.size();
+        tmp.push_back(blank);
+        tmp.back().op = cb->ops[i];
+    }
+    for (int q = 0; q < njobs; ++q) {
+        const int slot = ca->h_jobs[q].slot, at = e->slot_chain[slot];
+        if (at >= 0) tmp[at].job = ca->h_jobs[q];
+        else { tmp.push_back(blank); tmp.back().job = ca->h_jobs[q]; }
+    }
+    for (int i = 0; i < nops; ++i) e->slot_chain[cb->ops[i].slot] = -1;
+    const int n = (int)tmp.size();
+    VC_CHECK((size_t)n * sizeof(TrackChainRec) <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
+    TrackChainRec* h = (TrackChainRec*)e->h_stage2;
+    if (n) memcpy(h, tmp.data(), (size_t)n * sizeof(TrackChainRec));
+    *d_recs = (const TrackChainRec*)e->hd_stage2;
+    *n_out = n;
+    return VC_OK;
+}
+
+// Launch the pending operations of `cb` (may be null) and the cost jobs of `ca` (may be null) as one kernel, one
+// workgroup per touched slot.
+int track_launch(vc_engine* e, const StepCtx* cb, const float* feat_b, const StepCtx* ca, const float* feat_a) {
+    const TrackChainRec* d_recs; int nch;
+    VC_TRY(build_chain_recs(e, cb, ca, &d_recs, &nch));
+    if (nch == 0) { e->track_inflight = false; return VC_OK; }
+    e->track_seq += 1;
+    ProfScope ps(e, VC_PROF_TRACK);
+    VC_TRY(launch_track_step(e->pool, d_recs, nch, feat_b, feat_a, e->hd_mean, ca ? ca->d_featrow : nullptr, ca ? ca->d_xyah : nullptr,
+                             ca ? ca->d_tlwh : nullptr, e->hd_cost, e->d_track_counter, e->hd_track_flag, e->track_seq, e->stream));
+    e->track_inflight = true;
+    return VC_OK;
+}
+
+// Wait for the last track_launch: poll the completion word the kernel publishes to pinned memory (a stream
+// synchronisation costs several times the kernel itself); fall back to the stream if it does not arrive.
+int track_wait(vc_engine* e) {
+    if (!e->track_inflight) return VC_OK;
+    e->track_inflight = false;
+    if (!e->profiling) {
+        volatile unsigned* flag = (volatile unsigned*)e->h_track_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin) {
+            if (*flag == e->track_seq) { std::atomic_thread_fence(std::memory_order_acquire); return VC_OK; }
+            __builtin_ia32_pause();
+            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_CHECK(*(volatile unsigned*)e->h_track_flag == e->track_seq, VC_ERR_HIP, "tracker kernel did not publish its completion word");
+    return VC_OK;
+}
+
+int track_host_b(vc_engine* e, StepCtx& c) {
     const int njobs = (int)c.ids.size();
-    std::vector<TrackOpB> ops;                       // one per updated / initiated / output-only track
+    std::vector<TrackOpB>& ops = c.ops;              // one per updated / initiated / output-only track
+    ops.clear();
     auto add_op = [&](int slot, int kind, const double* z, int gal_pos, int feat_row) {
         TrackOpB op{};
         op.slot = slot; op.kind = kind; op.gal_pos = gal_pos; op.feat_row = feat_row; op.out_row = -1;
@@ -323,10 +402,11 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
         }
         // _initiate_track, sort/tracker.py:133-139
         for (int d : un_dets) {
-            VC_CHECK(!e->free_slots.empty(), VC_ERR_CAPACITY, "track pool exhausted (max_tracks = %d)", e->cfg.max_tracks);
+            const int new_slot = slot_alloc(e);
+            VC_CHECK(new_slot >= 0, VC_ERR_CAPACITY, "track pool exhausted (max_tracks = %d)", e->cfg.max_tracks);
             TrackRec tr{};
             tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
-            tr.slot = e->free_slots.back(); e->free_slots.pop_back();
+            tr.slot = new_slot;
             const int g = c.det_base[j] + d;
             add_op(tr.slot, 2, &c.det_xyah[(size_t)g * 4], 0, c.featrow[g]);
             tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
@@ -336,7 +416,7 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
         // drop deleted tracks, sort/tracker.py:80
         std::vector<TrackRec> alive;
         for (TrackRec& tr : tk.tracks) {
-            if (tr.state == DELETED) e->free_slots.push_back(tr.slot);
+            if (tr.state == DELETED) slot_free(e, tr.slot);
             else alive.push_back(tr);
         }
         tk.tracks.swap(alive);
@@ -344,29 +424,35 @@ int track_phase_b(vc_engine* e, StepCtx& c, const float* d_feat) {
     // deep_sort.py:46-58 output eligibility (confirmed, time_since_update <= 1): those tracks' posterior means go back
     c.emit.clear();
     c.mean_offsets.assign(njobs + 1, 0);
-    std::map<int, int> op_of_slot;
-    for (size_t i = 0; i < ops.size(); ++i) op_of_slot[ops[i].slot] = (int)i;
+    std::vector<int>& op_of_slot = e->slot_chain;    // scratch, -1 outside a call
+    const size_t n_real_ops = ops.size();
+    for (size_t i = 0; i < n_real_ops; ++i) op_of_slot[ops[i].slot] = (int)i;
     int n_out = 0;
     for (int j = 0; j < njobs; ++j) {
         c.mean_offsets[j] = n_out;
         for (const TrackRec& tr : e->trackers[c.ids[j]]->tracks) {
             if (!c.all_means && (tr.state != CONFIRMED || tr.tsu > 1)) continue;
             if (tr.state == CONFIRMED && tr.tsu <= 1) c.emit.push_back(StepCtx::Emit{n_out, tr.id, j < (int)c.labels.size() ? c.labels[j] : 0});
-            auto it = op_of_slot.find(tr.slot);
-            if (it == op_of_slot.end()) { add_op(tr.slot, 0, nullptr, 0, -1); ops.back().out_row = n_out; }
-            else ops[it->second].out_row = n_out;
+            const int at = op_of_slot[tr.slot];
+            if (at < 0) { add_op(tr.slot, 0, nullptr, 0, -1); ops.back().out_row = n_out; }
+            else ops[at].out_row = n_out;
             ++n_out;
         }
     }
+    for (size_t i = 0; i < n_real_ops; ++i) op_of_slot[ops[i].slot] = -1;
     c.mean_offsets[njobs] = n_out;
-    const int nops = (int)ops.size();
-    VC_CHECK((size_t)nops * sizeof(TrackOpB) <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
-    if (nops) {
-        memcpy(e->h_stage2, ops.data(), (size_t)nops * sizeof(TrackOpB));
-        ProfScope ps(e, VC_PROF_TRACK);
-        VC_TRY(launch_track_phase_b(e->pool, (const TrackOpB*)e->hd_stage2, nops, d_feat, e->hd_mean, s));
-    }
-    return VC_OK;      // stream-ordered: e->h_mean / c.emit are valid after the next synchronisation of e->stream
+    return VC_OK;      // c.ops are pending: e->h_mean / c.emit are valid after the launch that carries them has completed
+}
+
+// Blocking form used by the per-frame entry points: cost jobs, host matching, then the operations in a second launch.
+int track_step_blocking(vc_engine* e, StepCtx& c, const float* d_feat) {
+    VC_TRY(track_prepare_a(e, c));
+    VC_TRY(track_launch(e, nullptr, nullptr, &c, d_feat));
+    VC_TRY(track_wait(e));
+    VC_TRY(track_host_b(e, c));
+    VC_TRY(track_launch(e, &c, d_feat, nullptr, nullptr));
+    VC_TRY(track_wait(e));
+    return VC_OK;
 }
 
 // deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id,label] (box = Kalman posterior, Q7)
@@ -454,10 +540,7 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
     VC_TRY(run_reid_dev(e, d_frame_base, H, W, n));
     StepCtx c;
     build_ctx(e, c, H, W, tracker_ids, labels, groups, xyxy, conf, 0);
-    VC_TRY(track_phase_a(e, c, e->d_feat));
-    VC_HIP(hipStreamSynchronize(e->stream));
-    VC_TRY(track_phase_b(e, c, e->d_feat));
-    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_TRY(track_step_blocking(e, c, e->d_feat));
     emit_rows(c, e->h_mean, rows6);
     return VC_OK;
 }
@@ -484,7 +567,7 @@ int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
 int vc_tracker_reset(vc_engine* e, int id) {
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     Tracker& tk = *e->trackers[id];
-    for (const TrackRec& t : tk.tracks) e->free_slots.push_back(t.slot);
+    for (const TrackRec& t : tk.tracks) slot_free(e, t.slot);
     tk.tracks.clear();
     tk.next_id = 1;
     return VC_OK;
@@ -503,10 +586,7 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
     c.prep[0].conf.assign(conf, conf + k);
     c.prep[0].feat_rows.resize(k);
     std::iota(c.prep[0].feat_rows.begin(), c.prep[0].feat_rows.end(), 0);
-    VC_TRY(track_phase_a(e, c, e->d_feat_in));
-    VC_HIP(hipStreamSynchronize(e->stream));
-    VC_TRY(track_phase_b(e, c, e->d_feat_in));
-    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_TRY(track_step_blocking(e, c, e->d_feat_in));
     return VC_OK;
 }
 

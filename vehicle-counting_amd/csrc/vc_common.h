@@ -81,6 +81,7 @@ struct ConvP {
     // one launch, e.g. C3.cv1 + C3.cv2); split is a multiple of 4, 0 = single destination
     void* out2;
     int split, out2_cs, out2_co;
+    long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
     int ablate;          // diagnostics only (VC_CONV_ABLATE): 1 = skip the staging DMA after the first tile, 2 = skip the MFMAs
 };
 
