@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of B = 16 synthetic 640x640 frames of ONE camera stream per GPU
+A step = one pass of the hot path over one batch of B = 64 synthetic 640x640 frames of ONE camera stream per GPU
 (BASELINE.json configs[1]: YOLOv5s 640x640, bf16 convs): letterbox -> YOLOv5s conv stack -> decode -> NMS -> crops ->
 ReID CNN -> per-class DeepSORT step, frames already resident in HBM.  Each rank owns its own camera stream (weak
 scaling); the only collective is the all-gather of the per-camera count tensors at the end.
@@ -29,7 +29,7 @@ from vehicle_counting_amd.synth import synth_frames  # noqa: E402
 from vehicle_counting_amd.track import VideoCounting  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
 
-B = int(os.environ.get("VC_BENCH_B", 16))   # frames per step
+B = int(os.environ.get("VC_BENCH_B", 64))   # frames per step (one batch of the camera stream)
 H = W = 640
 NC = 80
 N_OBJ = 12
@@ -69,11 +69,11 @@ def main():
     rsd = synth_reid(1702)
     eng = E.Engine(ysd, rsd, device=local, precision="bf16", model_name="yolov5s", num_classes=NC, max_batch=B,
                    max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
-    eng.pretune()                                                               # conv autotune for every ReID size bucket
+    eng.pretune((32, 64, 128, 256, 512, 1024, 2048, 4096))                      # conv autotune for every ReID size bucket
     trackers = [eng.tracker_create(**TRACK) for _ in range(NC)]
     frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank)          # one camera stream per rank
     d_frames = torch.from_numpy(frames).to(dev)                                 # resident in HBM before the timed region
-    obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
+    rec = []                                  # (first frame number of the batch, packed rows, frame index per row) per timed step
     ndet_total = [0, 0]
 
     def batch_ptr(i):
@@ -83,13 +83,10 @@ def main():
     def step(i, record, prefetch=True):
         if prefetch:
             eng.stream_submit(batch_ptr(i + 1), B, H, W)      # detector of the NEXT batch runs on its own stream while this one is tracked
-        rows, nd = eng.stream_run(trackers, batch_ptr(i), B, H, W)
+        rows, fidx, nd = eng.stream_run_packed(trackers, batch_ptr(i), B, H, W)
         if record:
             ndet_total[0] += int(nd.sum()); ndet_total[1] += B
-            for k, r in enumerate(rows):
-                for row in r:
-                    obj["frames"].append(i * B + k + 1); obj["tracks"].append(int(row[4]))
-                    obj["labels"].append(int(row[5])); obj["boxes"].append(row[:4].copy())
+            rec.append((i * B + 1, rows, fidx))
 
     def sync_all():
         eng.sync()
@@ -105,14 +102,25 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i, True)
     # end of run: per-camera counts (VideoCounting) merged with the one collective of the design
+    t_post = time.perf_counter()
+    tt = [time.perf_counter()]
     counter = VideoCounting([str(c) for c in range(NC)], ZONE)
-    td = counter.run(obj["frames"], obj["tracks"], obj["labels"], obj["boxes"])
+    all_rows = np.concatenate([r for _, r, _ in rec]) if rec else np.zeros((0, 6), np.int64)
+    all_frames = np.concatenate([f0 + fi for f0, _, fi in rec]) if rec else np.zeros(0, np.int64)
+    tt.append(time.perf_counter())
+    td = counter.run(all_frames.tolist(), all_rows[:, 4].tolist(), all_rows[:, 5].tolist(), np.ascontiguousarray(all_rows[:, :4]))
+    tt.append(time.perf_counter())
     rows = csv_records(td)
+    tt.append(time.perf_counter())
     dirs = list(counter.directions.keys())
     local_counts = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)[None]
     all_counts = parallel.allgather_counts(local_counts, device=dev if world > 1 else None)
+    tt.append(time.perf_counter())
     sync_all()
     dt = time.perf_counter() - t0
+    post_ms = (time.perf_counter() - t_post) * 1e3
+    tt.append(time.perf_counter())
+    if os.environ.get('VC_BENCH_DBG'): print('post-pass ms: setup %.1f run %.1f csv %.1f count+gather %.1f final sync %.1f' % tuple((b - a) * 1e3 for a, b in zip(tt[:-1], tt[1:])), file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -148,7 +156,8 @@ def main():
             "config": {"workload": "YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])",
                        "frames_per_step": B, "frame_hw": [H, W], "num_classes": NC, "det_per_frame": ndet_total[0] / max(ndet_total[1], 1),
                        "weights": "seeded synthetic (no checkpoints available)", "streams": world,
-                       "counts_allgather_shape": list(all_counts.shape)},
+                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(len(all_rows)),
+                       "counting_postpass_ms_total": post_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes per conv launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",

@@ -1,0 +1,33 @@
+"""Aggregate frames/s of S independent camera streams on ONE GPU (one Engine + one host thread per stream)."""
+import os, sys, time, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.synth import synth_frames
+from vehicle_counting_amd.weights import synth_reid, synth_yolo
+S = int(os.environ.get("VC_STREAMS", 2)); B = int(os.environ.get("VC_B", 16)); H = W = 640; NC = 80; CLIP = 128; STEPS = 40; WARM = 5
+ysd, rsd = synth_yolo("yolov5s", nc=NC, det_scale=4.0, obj_shift=1.0), synth_reid()
+engs, trs, frs = [], [], []
+for s in range(S):
+    eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
+    eng.pretune()
+    engs.append(eng)
+    trs.append([eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60) for _ in range(NC)])
+    frs.append(torch.from_numpy(synth_frames(CLIP, H, W, 12, 1702 + s)).cuda())
+def ptr(s, i): return frs[s][(i * B) % CLIP:(i * B) % CLIP + B].data_ptr()
+bar = threading.Barrier(S + 1)
+def worker(s):
+    eng, tr = engs[s], trs[s]
+    eng.stream_submit(ptr(s, 0), B, H, W)
+    for i in range(WARM):
+        eng.stream_submit(ptr(s, i + 1), B, H, W); eng.stream_run(tr, ptr(s, i), B, H, W)
+    eng.sync(); bar.wait()
+    for i in range(WARM, WARM + STEPS):
+        eng.stream_submit(ptr(s, i + 1), B, H, W); eng.stream_run(tr, ptr(s, i), B, H, W)
+    eng.sync(); bar.wait()
+    eng.stream_run(tr, ptr(s, WARM + STEPS), B, H, W)
+th = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+for t in th: t.start()
+bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
+for t in th: t.join()
+print(f"streams {S} x B {B}: {S * STEPS * B / dt:.0f} frames/s aggregate, {dt / STEPS * 1e3:.2f} ms per step round")

@@ -12,6 +12,8 @@ functions one to one (names, argument meaning, quirks):
 from __future__ import annotations
 
 import csv
+
+import numpy as np
 import json
 import math
 
@@ -115,13 +117,15 @@ def csv_records(track_dict):
     rows = []
     for label_id in range(len(track_dict)):
         for track_id, rec in track_dict[label_id].items():
-            boxes, frames = rec["boxes"], rec["frames"]
+            boxes = np.asarray(rec["boxes"]).reshape(-1, 4).tolist()         # one conversion per track, not per value
+            frames = np.asarray(rec["frames"]).reshape(-1).tolist()
             fpoint, lpoint = _centre(boxes[0]), _centre(boxes[-1])
+            tid, colour, direction = int(track_id), rec.get("color", ""), rec["direction"]
+            fp, lp = (float(fpoint[0]), float(fpoint[1])), (float(lpoint[0]), float(lpoint[1]))
+            ff, lf = int(frames[0]), int(frames[-1])
             for box, frame in zip(boxes, frames):
-                rows.append({"track_id": int(track_id), "frame_id": int(frame), "box": [int(v) for v in box],
-                             "color": rec.get("color", ""), "label": label_id, "direction": rec["direction"],
-                             "fpoint": (float(fpoint[0]), float(fpoint[1])), "lpoint": (float(lpoint[0]), float(lpoint[1])),
-                             "fframe": int(frames[0]), "lframe": int(frames[-1])})
+                rows.append({"track_id": tid, "frame_id": int(frame), "box": [int(v) for v in box], "color": colour, "label": label_id,
+                             "direction": direction, "fpoint": fp, "lpoint": lp, "fframe": ff, "lframe": lf})
     return rows
 
 

@@ -403,7 +403,8 @@ int conv_check(const ConvP& p) {
     VC_CHECK((size_t)((p.Cout + 127) / 128 * 128) * p.Kp * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: weights exceed 2 GiB");
     VC_CHECK(p.kh * p.kw <= 40, VC_ERR_ARG, "conv: at most 40 taps (validity mask is 64 bits incl. K padding)");
     VC_CHECK(p.M < (1 << 24), VC_ERR_CAPACITY, "conv: more than 2^24 output pixels in one launch");
-    VC_CHECK((size_t)p.M * std::max(p.out_cs, std::max(p.res_cs, p.out2_cs)) * 4 < (1ull << 31), VC_ERR_CAPACITY, "conv: output tensor exceeds 2 GiB");
+    VC_CHECK((size_t)p.M * std::max(p.out_cs, std::max(p.res_cs, p.out2_cs)) * ((p.prec == PREC_F32 || p.out_f32) ? 4 : 2) < (1ull << 31),
+             VC_ERR_CAPACITY, "conv: output tensor exceeds 2 GiB (32-bit buffer offsets)");
     return VC_OK;
 }
 

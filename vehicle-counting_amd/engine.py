@@ -177,15 +177,30 @@ class Engine:
         return rows[: m.value].copy()
 
     # ---------------------------------------------------------------- fused stream path
-    def stream_run(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows=512):
-        """frames_dev_ptr: integer device address of B x H x W x 3 uint8 BGR frames (e.g. torch_tensor.data_ptr())."""
+    def _stream_call(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows):
+        key = (b, cap_rows)
+        bufs = self._stream_bufs.get(key) if hasattr(self, "_stream_bufs") else None
+        if bufs is None:                                  # output buffers are reused across calls (1.5 MB at b = 64)
+            if not hasattr(self, "_stream_bufs"):
+                self._stream_bufs = {}
+            bufs = self._stream_bufs[key] = (np.empty((b, cap_rows, 6), np.int64), np.zeros(b, np.int32), np.zeros(b, np.int32))
+        rows, m, nd = bufs
         tr = np.ascontiguousarray(tracker_ids, dtype=np.int32)
-        rows = np.zeros((b, cap_rows, 6), np.int64)
-        m = np.zeros(b, np.int32)
-        nd = np.zeros(b, np.int32)
         L.check(L.lib().vc_stream_run(self._h, L.ptr(tr, C.c_int), len(tr), C.c_void_p(frames_dev_ptr), b, h, w,
                                       L.ptr(rows, C.c_int64), cap_rows, L.ptr(m, C.c_int), L.ptr(nd, C.c_int)))
-        return [rows[i, : m[i]].copy() for i in range(b)], nd
+        return rows, m, nd
+
+    def stream_run(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows=512):
+        """frames_dev_ptr: integer device address of B x H x W x 3 uint8 BGR frames (e.g. torch_tensor.data_ptr()).
+        Returns (per-frame row arrays [m_i, 6] = x1,y1,x2,y2,track id,label; detections per frame)."""
+        rows, m, nd = self._stream_call(tracker_ids, frames_dev_ptr, b, h, w, cap_rows)
+        return [rows[i, : m[i]].copy() for i in range(b)], nd.copy()
+
+    def stream_run_packed(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows=512):
+        """Same step, rows of all frames packed: (rows [sum m, 6], frame index of each row [sum m], detections per frame)."""
+        rows, m, nd = self._stream_call(tracker_ids, frames_dev_ptr, b, h, w, cap_rows)
+        keep = np.arange(cap_rows)[None, :] < m[:, None]
+        return rows[keep], np.repeat(np.arange(b), m), nd.copy()
 
     def stream_submit(self, frames_dev_ptr, b, h, w):
         """Enqueue the detector for a batch (returns immediately); the matching stream_run consumes it."""
