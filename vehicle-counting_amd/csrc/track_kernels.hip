@@ -128,6 +128,75 @@ __device__ __forceinline__ void kalman_update_dev(double* m, double* P, const do
     for (int r = 0; r < 8; ++r) m[r] = nm[r];
 }
 
+// ---- one-wavefront forms of initiate / predict / update (lane = covariance element (r, c) = (lane >> 3, lane & 7)) ---
+// Every output element is produced by exactly the operation sequence of the single-thread forms above (same operands,
+// same order, no cross-lane reductions), so the results are bit-identical; what changes is that the ~70 dependent fp64
+// divisions / square roots of an update are spread over the lanes.  Call with the 64 threads of ONE wave; kbuf is 32
+// doubles of LDS.
+__device__ __forceinline__ void kalman_initiate_wave(double* m, double* P, const double* z, int lane) {
+    const int r = lane >> 3, c = lane & 7;
+    const double h = z[3];
+    const double sp = (2 * VC_W_POS) * h, sv = (10 * VC_W_VEL) * h;
+    const double sd = r == 2 ? 1e-2 : r == 6 ? 1e-5 : r < 4 ? sp : sv;
+    P[lane] = r == c ? sd * sd : 0.0;
+    if (lane < 8) m[lane] = lane < 4 ? z[lane] : 0.0;
+}
+
+__device__ __forceinline__ void kalman_predict_wave(double* m, double* P, int lane) {
+    const int r = lane >> 3, c = lane & 7;
+    const double h = m[3];
+    const double sp = VC_W_POS * h, sv = VC_W_VEL * h;
+    const double sd = r == 2 ? 1e-2 : r == 6 ? 1e-5 : r < 4 ? sp : sv;
+    // T = P F^T (column j < 4 gains column j+4), P' = F T + Q (row r < 4 gains row r+4)
+    const double t0 = c < 4 ? P[r * 8 + c] + P[r * 8 + c + 4] : P[r * 8 + c];
+    const int r4 = (r + 4) & 7;
+    const double t1 = c < 4 ? P[r4 * 8 + c] + P[r4 * 8 + c + 4] : P[r4 * 8 + c];
+    double v = r < 4 ? t0 + t1 : t0;
+    if (r == c) v += sd * sd;
+    const double mk = lane < 4 ? m[lane] + m[lane + 4] : 0.0;
+    // every load above feeds a value stored below, so all lanes' loads have returned before the first store issues
+    P[lane] = v;
+    if (lane < 4) m[lane] = mk;
+}
+
+__device__ __forceinline__ void kalman_update_wave(double* m, double* P, const double* z, int lane, volatile double* kbuf) {
+    const int r = lane >> 3, c = lane & 7;
+    double S[16], L[16];
+    project4(m, P, S);
+    chol4(S, L);
+    const double prc = P[lane];
+    double nm = 0.0;
+    if (lane < 8) {                               // K^T = S^-1 (P H^T)^T : state row `lane`
+        double y[4], k[4];
+        for (int a = 0; a < 4; ++a) {            // L y = b
+            double v = P[lane * 8 + a];
+            for (int q = 0; q < a; ++q) v -= L[a * 4 + q] * y[q];
+            y[a] = v / L[a * 4 + a];
+        }
+        for (int a = 3; a >= 0; --a) {           // L^T x = y
+            double v = y[a];
+            for (int q = a + 1; q < 4; ++q) v -= L[q * 4 + a] * k[q];
+            k[a] = v / L[a * 4 + a];
+        }
+        double v = 0.0;
+        for (int a = 0; a < 4; ++a) { v += (z[a] - m[a]) * k[a]; kbuf[lane * 4 + a] = k[a]; }
+        nm = m[lane] + v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double Kr[4], Kc[4];
+    for (int a = 0; a < 4; ++a) { Kr[a] = kbuf[r * 4 + a]; Kc[a] = kbuf[c * 4 + a]; }
+    double v = 0.0;                               // P' = P - K (S K^T)
+    for (int a = 0; a < 4; ++a) {
+        double skt = 0.0;
+        for (int q = 0; q < 4; ++q) skt += S[a * 4 + q] * Kc[q];
+        v += Kr[a] * skt;
+    }
+    P[lane] = prc - v;
+    if (lane < 8) m[lane] = nm;
+}
+
 __global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -151,15 +220,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void host_store(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// Descriptor loads (pinned host memory, or device memory in the KAT entry points): system-scope vector loads, so that
-// every workgroup fetches a whole record / detection chunk in one round trip to pinned memory and stages it in LDS.
-__device__ __forceinline__ unsigned long long sys_load_u64(const void* p) {
-    return __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned sys_load_u32(const void* p) {
-    return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double sys_load_f64(const double* p) { return __longlong_as_double((long long)sys_load_u64(p)); }
+// Descriptor loads (pinned host memory, or device memory in the KAT entry points).  Plain vector loads: a kernel lives for
+// one step, so nothing it reads from pinned memory can be stale, and neighbouring lanes coalesce into a few PCIe reads
+// (per-lane system-scope atomic loads do not coalesce: 16k read transactions per step, +10 us).
+__device__ __forceinline__ unsigned long long sys_load_u64(const void* p) { return *(const volatile unsigned long long*)p; }
+__device__ __forceinline__ unsigned sys_load_u32(const void* p) { return *(const volatile unsigned*)p; }
+__device__ __forceinline__ double sys_load_f64(const double* p) { return *(const volatile double*)p; }
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
@@ -168,6 +234,7 @@ struct TrackShared {
     int featrow[16];                 // feature rows / xyah of the 16 detections being scored
     double xyah[16][4];
     unsigned long long rec[12];      // the chain record being executed
+    double kbuf[32];                 // Kalman gain rows (kalman_update_wave)
 };
 
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
@@ -187,27 +254,31 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
         // the chunk's descriptors -> LDS (one round trip to pinned memory for all 16 detections)
-        if (threadIdx.x < 16) sh.featrow[threadIdx.x] = (int)sys_load_u32(det_feat_row + jb.det_off + min(d0 + (int)threadIdx.x, D - 1));
-        else if (threadIdx.x < 80) {
-            const int t = threadIdx.x - 16, d = min(d0 + (t >> 2), D - 1);
-            sh.xyah[t >> 2][t & 3] = sys_load_f64(det_xyah + (size_t)(jb.det_off + d) * 4 + (t & 3));
+        if (threadIdx.x < 16) {
+            const int d = jb.det_off + min(d0 + (int)threadIdx.x, D - 1);
+            sh.featrow[threadIdx.x] = (int)sys_load_u32(det_feat_row + d);
+        } else if (threadIdx.x < 80) {
+            const int t = threadIdx.x - 16, d = jb.det_off + min(d0 + (t >> 2), D - 1);
+            sh.xyah[t >> 2][t & 3] = sys_load_f64(det_xyah + (size_t)d * 4 + (t & 3));
         }
         __syncthreads();
         const float* fptr = feat + (size_t)sh.featrow[col] * VC_FEAT_DIM + kq * 4;
         float best = -INFINITY, ss = 0.f;
         for (int st = wave; st * 16 < S; st += 4) {
             const float* gptr = gal + (size_t)min(st * 16 + col, S - 1) * VC_FEAT_DIM + kq * 4;
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            // four independent accumulators (k mod 4 chunks): a 32-deep MFMA dependency chain instead of 128
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
             float s2 = 0.f;
 #pragma unroll 8
             for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
                 const float4 a = *(const float4*)(gptr + k0), b = *(const float4*)(fptr + k0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc3, 0, 0, 0);
                 s2 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
             }
+            const f32x4_t acc = (acc0 + acc1) + (acc2 + acc3);
             ss = s2;
 #pragma unroll
             for (int r = 0; r < 4; ++r)                       // acc[r] = <g_{st*16 + kq*4 + r}, f_{d0 + col}>
@@ -291,9 +362,9 @@ __device__ __forceinline__ void run_chain(const TrackPool& tp, const TrackChainR
     __syncthreads();                       // sh.rec is free again
     if (op.kind >= 0) {
         double* m = tp.mean + (size_t)op.slot * 8;
-        if (threadIdx.x == 0) {
-            if (op.kind == 1) kalman_update_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
-            else if (op.kind == 2) kalman_initiate_dev(m, tp.cov + (size_t)op.slot * 64, op.z);
+        if (threadIdx.x < 64) {            // wave 0
+            if (op.kind == 1) kalman_update_wave(m, tp.cov + (size_t)op.slot * 64, op.z, threadIdx.x, sh.kbuf);
+            else if (op.kind == 2) kalman_initiate_wave(m, tp.cov + (size_t)op.slot * 64, op.z, threadIdx.x);
         }
         if (op.feat_row >= 0)              // block-uniform
             store_gallery_row(tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM,
@@ -303,7 +374,7 @@ __device__ __forceinline__ void run_chain(const TrackPool& tp, const TrackChainR
         __syncthreads();
     }
     if (jb.slot >= 0) {
-        if (threadIdx.x == 0) kalman_predict_dev(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64);
+        if (threadIdx.x < 64) kalman_predict_wave(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64, threadIdx.x);
         __syncthreads();
         if (jb.app_off >= 0) {
             const CostJob cj{jb.slot, jb.gal_count, jb.det_off, jb.det_n, jb.app_off, jb.tsu};
