@@ -85,7 +85,7 @@ class Engine:
 
     def debug_layer(self, layer, batch=1):
         dims = (C.c_int * 4)()
-        cap = batch * 640 * 640 * 8
+        cap = batch * max(640, int(self.cfg.img_size)) ** 2 * 32     # largest layer: (size/2)^2 x 64..128 channels
         buf = np.zeros(cap, np.float32)
         L.check(L.lib().vc_detect_debug_layer(self._h, layer, L.ptr(buf, C.c_float), cap, dims))
         b, h, w, c = dims
