@@ -105,8 +105,55 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
 }
 
+// No-resize case (source already at network scale, e.g. 640x640 frames): pad + channel swap + /255 only.  One thread makes
+// four consecutive output pixels: a 12-byte source read and one 32-byte (bf16) / 64-byte (fp32) store.  Same arithmetic
+// as the general kernel ((float)u8 / 255.f, RNE to bf16).
+template <bool F32>
+__global__ __launch_bounds__(256) void letterbox_copy_kernel(const uint8_t* __restrict__ src, void* __restrict__ dst, int B, LetterboxGeom g) {
+    const int wq = g.net_w >> 2;                                          // net_w is a multiple of 32
+    const long total = (long)B * g.net_h * wq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % wq);
+        const int y = (int)((i / wq) % g.net_h);
+        const int b = (int)(i / ((long)wq * g.net_h));
+        const int uy = y - g.top;
+        const uint8_t* row = src + ((size_t)b * g.src_h + uy) * g.src_w * 3;
+        float f[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ux = xq * 4 + k - g.left;
+            int p0 = 114, p1 = 114, p2 = 114;
+            if (ux >= 0 && ux < g.unpad_w && uy >= 0 && uy < g.unpad_h) {
+                const uint8_t* q = row + (size_t)ux * 3;
+                p0 = q[0]; p1 = q[1]; p2 = q[2];
+                if (g.swap_rb) { const int t = p0; p0 = p2; p2 = t; }
+            }
+            f[k][0] = (float)p0 / 255.f; f[k][1] = (float)p1 / 255.f; f[k][2] = (float)p2 / 255.f;
+        }
+        const size_t o = ((size_t)b * g.net_h + y) * g.net_w + (size_t)xq * 4;
+        if (F32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ((float4*)dst)[o + k] = make_float4(f[k][0], f[k][1], f[k][2], 0.f);
+        } else {
+            uint4 t0, t1;
+            t0.x = (uint32_t)f32_to_bf16(f[0][0]) | ((uint32_t)f32_to_bf16(f[0][1]) << 16); t0.y = (uint32_t)f32_to_bf16(f[0][2]);
+            t0.z = (uint32_t)f32_to_bf16(f[1][0]) | ((uint32_t)f32_to_bf16(f[1][1]) << 16); t0.w = (uint32_t)f32_to_bf16(f[1][2]);
+            t1.x = (uint32_t)f32_to_bf16(f[2][0]) | ((uint32_t)f32_to_bf16(f[2][1]) << 16); t1.y = (uint32_t)f32_to_bf16(f[2][2]);
+            t1.z = (uint32_t)f32_to_bf16(f[3][0]) | ((uint32_t)f32_to_bf16(f[3][1]) << 16); t1.w = (uint32_t)f32_to_bf16(f[3][2]);
+            uint4* d = (uint4*)((uint2*)dst + o);
+            d[0] = t0; d[1] = t1;
+        }
+    }
+}
+
 int launch_letterbox(const uint8_t* src, void* dst, int B, const LetterboxGeom& g, int prec, hipStream_t s) {
     const long total = (long)B * g.net_h * g.net_w;
+    if (g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.net_w % 4 == 0) {
+        if (prec == PREC_F32) hipLaunchKernelGGL(letterbox_copy_kernel<true>, dim3(grid_for(total / 4, 256)), dim3(256), 0, s, src, dst, B, g);
+        else hipLaunchKernelGGL(letterbox_copy_kernel<false>, dim3(grid_for(total / 4, 256)), dim3(256), 0, s, src, dst, B, g);
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     if (prec == PREC_F32) hipLaunchKernelGGL(letterbox_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst, B, g);
     else hipLaunchKernelGGL(letterbox_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst, B, g);
     VC_HIP(hipGetLastError());
@@ -203,9 +250,70 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(View cat, int C) {
     }
 }
 
+// Wide LDS version (the one that runs at 20x20): one workgroup per (frame, 32 words of channels = 64 bf16 / 32 fp32 channels).
+// A lane owns one 4-byte word of a position, so a position's slice is one coalesced 128-byte read/write and every LDS access
+// of a wave is 64 consecutive words; the three chained 5x5 max-pools are separable row / column passes on the LDS plane.
+// max() of bf16 values is exact on the two halves of a word (no rounding anywhere).
+template <bool F32>
+__device__ __forceinline__ uint32_t wmax(uint32_t a, uint32_t b) {
+    if (F32) return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
+    const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+    const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
+    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+
+template <bool F32>
+__global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
+    constexpr int ES = F32 ? 4 : 2;
+    constexpr int CW = 128 / ES;                                         // channels per workgroup
+    extern __shared__ __attribute__((aligned(16))) uint32_t smw[];       // two planes of [H*W][32] words
+    const int groups = C / CW;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * CW;
+    const int H = cat.H, W = cat.W, n = H * W;
+    uint32_t* P = smw;
+    uint32_t* T = smw + (size_t)n * 32;
+    const int w = threadIdx.x & 31, pg = threadIdx.x >> 5;               // word of the slice, position group (32 per pass: 16 waves hide the LDS latency)
+    char* base = (char*)cat.ptr + (((size_t)b * n) * cat.cs + cat.co + c0) * ES + w * 4;
+    const size_t pstride = (size_t)cat.cs * ES;
+    for (int i = pg; i < n; i += 32) P[i * 32 + w] = *(const uint32_t*)(base + i * pstride);
+    __syncthreads();
+    const uint32_t NEG = F32 ? 0xff800000u : 0xff80ff80u;                // -inf (both halves)
+    for (int round = 1; round <= 3; ++round) {
+        for (int i = pg; i < n; i += 32) {                                // row pass
+            const int y = i / W, x = i - y * W;
+            uint32_t m = NEG;
+            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = wmax<F32>(m, P[(y * W + xx) * 32 + w]);
+            T[i * 32 + w] = m;
+        }
+        __syncthreads();
+        for (int i = pg; i < n; i += 32) {                                // column pass + store of this round's slice
+            const int y = i / W, x = i - y * W;
+            uint32_t m = NEG;
+            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = wmax<F32>(m, T[(yy * W + x) * 32 + w]);
+            *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = m;
+            P[i * 32 + w] = m;                                           // own position only: no hazard with other threads' T reads
+        }
+        __syncthreads();
+    }
+}
+
 int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
     const int n = prec == PREC_F32 ? 4 : 8;
     VC_CHECK(C % n == 0 && cat.cs % n == 0 && cat.co % n == 0, VC_ERR_ARG, "sppf: channel alignment");
+    const int cw = prec == PREC_F32 ? 32 : 64;
+    const size_t lds_wide = (size_t)2 * cat.H * cat.W * 128;
+    if (C % cw == 0 && cat.cs % 2 == 0 && cat.co % 2 == 0 && lds_wide <= 150 * 1024) {
+        const int blocks = cat.B * (C / cw);
+        if (prec == PREC_F32) {
+            VC_HIP(hipFuncSetAttribute((const void*)sppf_pool_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
+            hipLaunchKernelGGL(sppf_pool_wide_kernel<true>, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
+        } else {
+            VC_HIP(hipFuncSetAttribute((const void*)sppf_pool_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
+            hipLaunchKernelGGL(sppf_pool_wide_kernel<false>, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
+        }
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     const size_t lds = (size_t)2 * cat.H * cat.W * n * sizeof(float);
     if (lds <= 150 * 1024) {
         const int blocks = cat.B * (C / n);

@@ -107,53 +107,77 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, float iou_th
     __shared__ float4 cb[64];
     const int b = blockIdx.z;
     const int n = min(pb.cand_count[b], max_cand);
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    if (row0 >= n || col0 >= n || col0 + 63 < row0) return;     // block strictly below the diagonal: nothing to do
     const size_t base = (size_t)b * max_cand;
     const int t = threadIdx.x;
-    if (col0 + t < n) {
-        const float4 v = *(const float4*)(pb.sort_box + (base + col0 + t) * 4);
-        const float off = (float)pb.sort_cls[base + col0 + t] * VC_MAX_WH;
-        cb[t] = make_float4(v.x + off, v.y + off, v.z + off, v.w + off);
+    // the grid is a fixed 8 x 8 tiles per frame (the candidate count lives on the device): block-stride over the 64 x 64 tiles
+    // of the upper triangle -- a (max_cand/64)^2 grid costs 60 us of empty workgroups at max_cand = 4096
+    for (int rb = blockIdx.y; rb * 64 < n; rb += gridDim.y) {
+        const int row0 = rb * 64;
+        const int i = row0 + t;
+        float ix1 = 0.f, iy1 = 0.f, ix2 = 0.f, iy2 = 0.f, iarea = 0.f;
+        if (i < n) {
+            const float4 v = *(const float4*)(pb.sort_box + (base + i) * 4);
+            const float off = (float)pb.sort_cls[base + i] * VC_MAX_WH;
+            ix1 = v.x + off; iy1 = v.y + off; ix2 = v.z + off; iy2 = v.w + off;
+            iarea = (ix2 - ix1) * (iy2 - iy1);
+        }
+        for (int cbk = blockIdx.x; cbk * 64 < n; cbk += gridDim.x) {
+            const int col0 = cbk * 64;
+            if (col0 + 63 < row0) continue;                                 // tile strictly below the diagonal (block-uniform)
+            __syncthreads();
+            if (col0 + t < n) {
+                const float4 v = *(const float4*)(pb.sort_box + (base + col0 + t) * 4);
+                const float off = (float)pb.sort_cls[base + col0 + t] * VC_MAX_WH;
+                cb[t] = make_float4(v.x + off, v.y + off, v.z + off, v.w + off);
+            }
+            __syncthreads();
+            if (i >= n) continue;
+            unsigned long long bits = 0;
+            const int m = min(64, n - col0);
+            for (int j = 0; j < m; ++j) {
+                if (col0 + j <= i) continue;
+                const float4 c = cb[j];
+                const float xx1 = fmaxf(ix1, c.x), yy1 = fmaxf(iy1, c.y), xx2 = fminf(ix2, c.z), yy2 = fminf(iy2, c.w);
+                const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+                const float inter = w * h;
+                const float carea = (c.z - c.x) * (c.w - c.y);
+                const float ovr = inter / (iarea + carea - inter);
+                if (ovr > iou_thres) bits |= 1ull << j;
+            }
+            pb.mask[(base + i) * (size_t)(max_cand / 64) + cbk] = bits;
+        }
     }
-    __syncthreads();
-    const int i = row0 + t;
-    if (i >= n) return;
-    const float4 v = *(const float4*)(pb.sort_box + (base + i) * 4);
-    const float off = (float)pb.sort_cls[base + i] * VC_MAX_WH;
-    const float ix1 = v.x + off, iy1 = v.y + off, ix2 = v.z + off, iy2 = v.w + off;
-    const float iarea = (ix2 - ix1) * (iy2 - iy1);
-    unsigned long long bits = 0;
-    const int m = min(64, n - col0);
-    for (int j = 0; j < m; ++j) {
-        if (col0 + j <= i) continue;
-        const float4 c = cb[j];
-        const float xx1 = fmaxf(ix1, c.x), yy1 = fmaxf(iy1, c.y), xx2 = fminf(ix2, c.z), yy2 = fminf(iy2, c.w);
-        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-        const float inter = w * h;
-        const float carea = (c.z - c.x) * (c.w - c.y);
-        const float ovr = inter / (iarea + carea - inter);
-        if (ovr > iou_thres) bits |= 1ull << j;
-    }
-    pb.mask[(base + i) * (size_t)(max_cand / 64) + blockIdx.x] = bits;
 }
 
-// One wave per frame walks the sorted candidates, keeps the un-suppressed ones (at most max_det), and writes
-// the surviving boxes mapped back to source pixels (scale_coords + clip_coords).
-__global__ __launch_bounds__(64) void nms_scan_kernel(int max_cand, int max_det, const float* __restrict__ geom, DetectPostBuffers pb) {
-    extern __shared__ unsigned long long removed[];     // max_cand / 64 words
+#define VC_NMS_LDS_ROWS 512      // frames with at most this many candidates scan their suppression matrix from LDS
+
+// One workgroup per frame walks the sorted candidates, keeps the un-suppressed ones (at most max_det), and writes
+// the surviving boxes mapped back to source pixels (scale_coords + clip_coords).  The walk is a chain of dependent
+// row reads (one per kept box): the rows of a frame with <= VC_NMS_LDS_ROWS candidates are first copied to LDS with
+// coalesced loads so the chain runs at LDS latency instead of L2/HBM latency.
+__global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int max_det, const float* __restrict__ geom, DetectPostBuffers pb) {
+    extern __shared__ unsigned long long nms_lds[];     // removed[max_cand / 64], then rows[VC_NMS_LDS_ROWS][VC_NMS_LDS_ROWS / 64]
     const int b = blockIdx.x, lane = threadIdx.x;
     const float gain = geom[b * 5 + 0], padw = geom[b * 5 + 1], padh = geom[b * 5 + 2], src_w = geom[b * 5 + 3], src_h = geom[b * 5 + 4];
     const int n = min(pb.cand_count[b], max_cand);
     const int words = max_cand / 64;
     const int nw = (n + 63) / 64;
-    for (int w = lane; w < words; w += 64) removed[w] = 0;
-    __syncthreads();
+    unsigned long long* removed = nms_lds;
+    unsigned long long* rows = nms_lds + words;
     const size_t base = (size_t)b * max_cand;
+    const bool in_lds = n <= VC_NMS_LDS_ROWS;
+    for (int w = lane; w < words; w += blockDim.x) removed[w] = 0;
+    if (in_lds)
+        for (int e = lane; e < n * nw; e += blockDim.x) {
+            const int r = e / nw, w = e - r * nw;
+            // words left of the diagonal tile are never written by nms_mask_kernel; they are not read below either (w >= i >> 6)
+            rows[e] = w >= (r >> 6) ? pb.mask[(base + r) * (size_t)words + w] : 0ull;
+        }
+    __syncthreads();
     int kept = 0;
     for (int i = 0; i < n && kept < max_det; ++i) {
         const unsigned long long r = removed[i >> 6];
-        if ((r >> (i & 63)) & 1ull) continue;        // wave-uniform
+        if ((r >> (i & 63)) & 1ull) continue;        // block-uniform
         if (lane == 0) {
             const float4 v = *(const float4*)(pb.sort_box + (base + i) * 4);
             float x1 = (v.x - padw) / gain, y1 = (v.y - padh) / gain, x2 = (v.z - padw) / gain, y2 = (v.w - padh) / gain;
@@ -163,8 +187,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_cand, int max_det,
             o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = pb.sort_conf[base + i]; o[5] = (float)pb.sort_cls[base + i];
         }
         ++kept;
-        const unsigned long long* mrow = pb.mask + (base + i) * (size_t)words;
-        for (int w = (i >> 6) + lane; w < nw; w += 64) removed[w] |= mrow[w];
+        __syncthreads();                              // every thread has read removed[] for this i
+        const unsigned long long* mrow = in_lds ? rows + (size_t)i * nw : pb.mask + (base + i) * (size_t)words;
+        for (int w = (i >> 6) + lane; w < nw; w += blockDim.x) removed[w] |= mrow[w];
         __syncthreads();
     }
     if (lane == 0) pb.det_count[b] = kept;
@@ -193,8 +218,10 @@ void scale_geom_host(const ScaleGeom& g, float out5[5]) {
 int launch_nms(int B, int max_cand, int max_det, float iou, const float* geom_dev, DetectPostBuffers& pb, hipStream_t s) {
     VC_CHECK(max_cand % 64 == 0 && max_cand <= 8192, VC_ERR_ARG, "nms: max_candidates must be a multiple of 64 and <= 8192");
     hipLaunchKernelGGL(rank_sort_kernel, dim3(max_cand / 256, B), dim3(256), 0, s, max_cand, pb);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(max_cand / 64, max_cand / 64, B), dim3(64), 0, s, max_cand, iou, pb);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), sizeof(unsigned long long) * (max_cand / 64), s, max_cand, max_det, geom_dev, pb);
+    const int tiles = std::min(max_cand / 64, 8);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(tiles, tiles, B), dim3(64), 0, s, max_cand, iou, pb);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (max_cand / 64 + VC_NMS_LDS_ROWS * (VC_NMS_LDS_ROWS / 64)), s,
+                       max_cand, max_det, geom_dev, pb);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
