@@ -34,6 +34,7 @@ H = W = 640
 NC = 80
 N_OBJ = 12
 CLIP = 128             # distinct synthetic frames per stream (cycled)
+ASYNC = os.environ.get("VC_BENCH_ASYNC", "1") != "0"     # tracker loop on the engine's worker thread (vc_stream_run_async)
 TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
@@ -88,6 +89,29 @@ def main():
             ndet_total[0] += int(nd.sum()); ndet_total[1] += B
             rec.append((i * B + 1, rows, fidx))
 
+    def collect(i, record):
+        rows, fidx, nd = eng.stream_collect()
+        if record:
+            ndet_total[0] += int(nd.sum()); ndet_total[1] += B
+            rec.append((i * B + 1, rows, fidx))
+
+    def run_steps(first, n, record):
+        """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker loop of batch
+        i-1 (the engine's worker thread + tracker stream); rows come back one batch late.  Everything is collected before
+        the function returns, so the timed region contains the whole work of its n steps."""
+        if n <= 0:
+            return
+        if ASYNC:
+            for i in range(first, first + n):
+                eng.stream_submit(batch_ptr(i + 1), B, H, W)
+                eng.stream_run_async(trackers, batch_ptr(i), B, H, W)
+                if i > first:
+                    collect(i - 1, record)
+            collect(first + n - 1, record)
+        else:
+            for i in range(first, first + n):
+                step(i, record)
+
     def sync_all():
         eng.sync()
         torch.cuda.synchronize()
@@ -95,12 +119,10 @@ def main():
             torch.distributed.barrier()
 
     eng.stream_submit(batch_ptr(0), B, H, W)
-    for i in range(args.warmup):
-        step(i, False)
+    run_steps(0, args.warmup, False)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, True)
+    run_steps(args.warmup, args.steps, True)
     # end of run: per-camera counts (VideoCounting) merged with the one collective of the design
     t_post = time.perf_counter()
     tt = [time.perf_counter()]

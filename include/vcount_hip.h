@@ -139,6 +139,14 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
 int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w);
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);
+
+/* Asynchronous form of vc_stream_run: the per-frame tracker loop of the batch runs on the engine's worker thread; the call
+ * returns as soon as the batch's ReID is enqueued.  At most two batches may be outstanding.  vc_stream_collect returns the
+ * rows of the OLDEST outstanding batch (same layout as vc_stream_run) and blocks until they are ready.  Calls that touch
+ * tracker state (vc_tracker_*, vc_deepsort_update, vc_videotracker_run) first wait for outstanding batches. */
+int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                        int cap_rows_per_frame);
+int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b);
 /* Detection injection for throughput studies: replaces the detector's NMS output of the next
  * vc_stream_run frames with caller boxes after the conv stack has run. NULL clears. */
 int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);

@@ -1,7 +1,11 @@
 // Engine internals shared between engine.hip (networks), tracker.hip (DeepSORT) and stream.hip (fused path).
 #pragma once
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -72,7 +76,7 @@ struct vc_engine {
     hipStream_t dstream = nullptr;   // detector (runs ahead of the tracker on the next batch)
     hipStream_t rstream = nullptr;   // ReID of the next batch (stream path), concurrent with detector and tracker
     hipEvent_t ev_det[2] = {nullptr, nullptr};
-    hipEvent_t ev_reid[2] = {nullptr, nullptr};
+    hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
@@ -96,9 +100,11 @@ struct vc_engine {
     int* h_det_count2[2] = {nullptr, nullptr};
     float* h_geom = nullptr;                     // pinned [2][max_batch][5]
     unsigned geom_seq = 0, submit_seq = 0;
-    float* d_feat2[2] = {nullptr, nullptr};      // stream path: features of the batch being tracked / being embedded
-    int* d_crops2[2] = {nullptr, nullptr};
-    int* h_crops2[2] = {nullptr, nullptr};
+    // stream path: three feature / crop buffers -- the batch being tracked (possibly by the worker thread), the batch
+    // whose ReID is running, and the one after it
+    float* d_feat2[3] = {nullptr, nullptr, nullptr};
+    int* d_crops2[3] = {nullptr, nullptr, nullptr};
+    int* h_crops2[3] = {nullptr, nullptr, nullptr};
     unsigned reid_seq = 0;
     struct FrameDets { std::vector<double> xyxy, conf; std::vector<int> label; };
     struct Pending {
@@ -109,6 +115,22 @@ struct vc_engine {
         std::vector<int> row0;           // first feature row of each frame
     };
     std::vector<Pending> pending;
+    // asynchronous tracking (vc_stream_run_async / vc_stream_collect): the tracker loop of a batch runs on a worker thread
+    struct AsyncJob {
+        Pending pd;
+        std::vector<int> trackers;
+        int num_classes = 0, b = 0, h = 0, w = 0, cap = 0;
+        std::vector<int64_t> rows6;
+        std::vector<int> m, ndet;
+        int status = 0;
+        std::string err;
+        bool done = false;
+    };
+    std::thread worker;
+    std::mutex jmu;
+    std::condition_variable jcv;
+    std::deque<std::unique_ptr<AsyncJob>> jobs;      // submission order; front = next to collect
+    bool worker_quit = false;
 
     // ---- ReID ---------------------------------------------------------------------------------------
     vc::Net reid;
@@ -195,6 +217,7 @@ int track_prepare_a(vc_engine* e, StepCtx& c);
 int track_host_b(vc_engine* e, StepCtx& c);
 int track_launch(vc_engine* e, const StepCtx* cb, const float* feat_b, const StepCtx* ca, const float* feat_a);
 int track_wait(vc_engine* e);
+int async_wait_all(vc_engine* e);          // stream.hip: block until the worker thread has finished every queued batch
 void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6);
 void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
                const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0);

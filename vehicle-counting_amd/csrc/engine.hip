@@ -523,7 +523,7 @@ static int reid_alloc(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&e->d_crops, K * 5 * sizeof(int)));
     VC_TRY(host_alloc(e, (void**)&e->h_crops, K * 5 * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&e->d_feat, K * VC_FEAT_DIM * sizeof(float)));
-    for (int q = 0; q < 2; ++q) {                      // stream path: ReID of batch i+1 runs while batch i is tracked
+    for (int q = 0; q < 3; ++q) {                      // stream path: ReID of batches i+1 / i+2 runs while batch i is tracked
         VC_TRY(dev_alloc(e, (void**)&e->d_feat2[q], K * VC_FEAT_DIM * sizeof(float)));
         VC_TRY(dev_alloc(e, (void**)&e->d_crops2[q], K * 5 * sizeof(int)));
         VC_TRY(host_alloc(e, (void**)&e->h_crops2[q], K * 5 * sizeof(int)));
@@ -636,7 +636,8 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         }
         if (!ok) { set_error("stream create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&e->ev_reid[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_reid[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
+            hipEventCreateWithFlags(&e->ev_reid[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_reid[2], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&e->ev_det[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_det[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
@@ -652,6 +653,11 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
 
 int vc_engine_destroy(vc_engine* e) {
     if (!e) return VC_OK;
+    if (e->worker.joinable()) {                         // asynchronous tracker thread (stream.hip)
+        { std::lock_guard<std::mutex> lk(e->jmu); e->worker_quit = true; }
+        e->jcv.notify_all();
+        e->worker.join();
+    }
     tune_cache_save(e);
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);

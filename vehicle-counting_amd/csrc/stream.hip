@@ -109,7 +109,7 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
             marshal(h_det + (size_t)f * md * 6, h_cnt[f], pd.fd[f]);
         }
     }
-    pd.fslot = (int)(e->reid_seq++ & 1);
+    pd.fslot = (int)(e->reid_seq++ % 3);
     int* hc = e->h_crops2[pd.fslot];
     int k = 0;
     for (int f = 0; f < b; ++f) {
@@ -141,35 +141,28 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
 
 // If the detector of the next submission has finished, start its ReID now (it then overlaps the tracking in progress).
 int try_issue_next(vc_engine* e) {
-    if (e->pending.empty() || e->pending[0].stage != 0) return VC_OK;
-    if (hipEventQuery(e->ev_det[e->pending[0].slot]) != hipSuccess) return VC_OK;
-    return issue_reid(e, e->pending[0]);
+    vc_engine::Pending* next = nullptr;
+    int embedded = 0;                                   // batches that own one of the three feature buffers
+    for (vc_engine::Pending& p : e->pending) {
+        if (p.stage == 0) { next = &p; break; }
+        ++embedded;
+    }
+    if (!next) return VC_OK;
+    { std::lock_guard<std::mutex> lk(e->jmu); embedded += (int)e->jobs.size(); }
+    if (embedded >= 3) return VC_OK;
+    if (hipEventQuery(e->ev_det[next->slot]) != hipSuccess) return VC_OK;
+    return issue_reid(e, *next);
 }
 
 }  // namespace
 
 extern "C" {
 
-int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
-                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
-    VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
-    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
-    VC_HIP(hipSetDevice(e->cfg.device));
-    if (e->pending.empty()) VC_TRY(vc_stream_submit(e, frames_dev, b, h, w));
-    {
-        const vc_engine::Pending& fr = e->pending.front();
-        VC_CHECK(fr.frames == frames_dev && fr.b == b && fr.h == h && fr.w == w, VC_ERR_STATE,
-                 "vc_stream_run must consume submissions in the order they were made");
-    }
-    g_tm.start();
-    if (e->pending.front().stage == 0) {
-        VC_HIP(hipEventSynchronize(e->ev_det[e->pending.front().slot]));
-        VC_TRY(issue_reid(e, e->pending.front()));
-    }
-    vc_engine::Pending pd = std::move(e->pending.front());
-    e->pending.erase(e->pending.begin());
-    g_tm.lap(0);
-    VC_TRY(try_issue_next(e));
+// The tracker loop of one batch whose ReID has been enqueued (pd.stage == 1): per-class DeepSORT steps frame by frame, rows
+// [x1,y1,x2,y2,id,label] per frame.  Runs on the caller's thread (vc_stream_run) or on the worker thread
+// (vc_stream_run_async); it only touches the tracker stream and the tracker's own state.
+static int track_batch(vc_engine* e, vc_engine::Pending& pd, const int* trackers, int num_classes, int b, int h, int w,
+                       int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, bool poll_next) {
     // the tracker stream waits (on the GPU) for this batch's features
     VC_HIP(hipStreamWaitEvent(e->stream, e->ev_reid[pd.fslot], 0));
     const float* d_feat = e->d_feat2[pd.fslot];
@@ -194,16 +187,18 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         return VC_OK;
     };
     g_tm.lap(2);
+    std::vector<std::vector<int>> by_class(num_classes);
     for (int f = 0; f < b; ++f) {
         FrameDets& d = fd[f];
         if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
         std::vector<int> ids, labs;
         std::vector<std::vector<int>> groups;
-        for (int c = 0; c < num_classes; ++c) {                                  // modules/track.py:50-59
-            std::vector<int> g;
-            for (size_t i = 0; i < d.label.size(); ++i) if (d.label[i] == c) g.push_back((int)i);
-            if (g.empty()) continue;
-            ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(g));
+        for (size_t i = 0; i < d.label.size(); ++i)                              // modules/track.py:50-59, one pass
+            if (d.label[i] >= 0 && d.label[i] < num_classes) by_class[d.label[i]].push_back((int)i);
+        for (int c = 0; c < num_classes; ++c) {
+            if (by_class[c].empty()) continue;
+            ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(by_class[c]));
+            by_class[c].clear();
         }
         if (ids.empty()) continue;
         build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), pd.row0[f]);
@@ -212,7 +207,7 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         // one launch: the pending operations of the previous frame + the cost jobs of this one
         VC_TRY(track_launch(e, prev_f >= 0 ? &ctx[cur ^ 1] : nullptr, d_feat, &ctx[cur], d_feat));
         g_tm.lap(4);
-        VC_TRY(try_issue_next(e));
+        if (poll_next) VC_TRY(try_issue_next(e));
         VC_TRY(track_wait(e));                            // cost rows of f are here; so are the means of the previous frame
         g_tm.lap(5);
         VC_TRY(flush_prev(cur ^ 1));
@@ -229,9 +224,139 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
         VC_TRY(flush_prev(cur ^ 1));
         g_tm.lap(6);
     }
+    return VC_OK;
+}
+
+// Pop the oldest submission once its detector has finished and its ReID is enqueued.
+static int take_front(vc_engine* e, const void* frames_dev, int b, int h, int w, vc_engine::Pending& out) {
+    if (e->pending.empty()) VC_TRY(vc_stream_submit(e, frames_dev, b, h, w));
+    {
+        const vc_engine::Pending& fr = e->pending.front();
+        VC_CHECK(fr.frames == frames_dev && fr.b == b && fr.h == h && fr.w == w, VC_ERR_STATE,
+                 "vc_stream_run must consume submissions in the order they were made");
+    }
+    g_tm.start();
+    if (e->pending.front().stage == 0) {
+        VC_HIP(hipEventSynchronize(e->ev_det[e->pending.front().slot]));
+        VC_TRY(issue_reid(e, e->pending.front()));
+    }
+    out = std::move(e->pending.front());
+    e->pending.erase(e->pending.begin());
+    g_tm.lap(0);
+    return VC_OK;
+}
+
+static void async_worker(vc_engine* e) {
+    hipSetDevice(e->cfg.device);
+    for (;;) {
+        vc_engine::AsyncJob* job = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(e->jmu);
+            e->jcv.wait(lk, [&] {
+                if (e->worker_quit) return true;
+                for (auto& j : e->jobs) if (!j->done) return true;
+                return false;
+            });
+            if (e->worker_quit) return;
+            for (auto& j : e->jobs) if (!j->done) { job = j.get(); break; }
+        }
+        const int st = track_batch(e, job->pd, job->trackers.data(), job->num_classes, job->b, job->h, job->w, job->rows6.data(), job->cap,
+                                   job->m.data(), job->ndet.data(), /*poll_next=*/false);
+        {
+            std::lock_guard<std::mutex> lk(e->jmu);
+            job->status = st;
+            if (st != VC_OK) job->err = vc::last_error();
+            job->done = true;
+        }
+        e->jcv.notify_all();
+    }
+}
+
+}  // extern "C" (helpers above have internal linkage)
+
+namespace vc {
+int async_wait_all(vc_engine* e) {
+    std::unique_lock<std::mutex> lk(e->jmu);
+    e->jcv.wait(lk, [&] { for (auto& j : e->jobs) if (!j->done) return false; return true; });
+    return VC_OK;
+}
+}  // namespace vc
+
+extern "C" {
+
+int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
+    VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
+    VC_CHECK(e->jobs.empty(), VC_ERR_STATE, "asynchronous batches are outstanding: vc_stream_collect them first");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    vc_engine::Pending pd;
+    VC_TRY(take_front(e, frames_dev, b, h, w, pd));
+    VC_TRY(try_issue_next(e));
+    VC_TRY(track_batch(e, pd, trackers, num_classes, b, h, w, out_rows6, cap_rows_per_frame, out_m, out_ndet, /*poll_next=*/true));
     VC_TRY(try_issue_next(e));
     g_tm.report();
     return VC_OK;
+}
+
+// Asynchronous form: the tracker loop of the batch (a chain of per-frame GPU round trips, ~70 us each) runs on the
+// engine's worker thread while the caller goes on to submit / embed the following batches; results are picked up in order
+// with vc_stream_collect.  Tracker state is only touched by the worker while jobs are outstanding.
+int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                        int cap_rows_per_frame) {
+    VC_CHECK(e && trackers && frames_dev && cap_rows_per_frame > 0, VC_ERR_ARG, "bad argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    {
+        std::lock_guard<std::mutex> lk(e->jmu);
+        VC_CHECK(e->jobs.size() < 2, VC_ERR_STATE, "two asynchronous batches are already outstanding: call vc_stream_collect");
+    }
+    std::unique_ptr<vc_engine::AsyncJob> job(new vc_engine::AsyncJob());
+    VC_TRY(take_front(e, frames_dev, b, h, w, job->pd));
+    job->trackers.assign(trackers, trackers + num_classes);
+    job->num_classes = num_classes; job->b = b; job->h = h; job->w = w; job->cap = cap_rows_per_frame;
+    job->rows6.resize((size_t)b * cap_rows_per_frame * 6);
+    job->m.assign(b, 0);
+    job->ndet.assign(b, 0);
+    if (e->profiling) {                                   // profiling brackets launches with events on shared state: run inline
+        job->status = track_batch(e, job->pd, job->trackers.data(), num_classes, b, h, w, job->rows6.data(), cap_rows_per_frame,
+                                  job->m.data(), job->ndet.data(), true);
+        if (job->status != VC_OK) job->err = vc::last_error();
+        job->done = true;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->jmu);
+        e->jobs.push_back(std::move(job));
+        if (!e->worker.joinable()) e->worker = std::thread(async_worker, e);
+    }
+    e->jcv.notify_all();
+    return try_issue_next(e);
+}
+
+// Results of the oldest asynchronous batch (blocks until its tracker loop has finished).  While waiting, the ReID of the
+// next submission is started as soon as its detector has finished.
+int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b) {
+    VC_CHECK(e && out_rows6 && out_m, VC_ERR_ARG, "null argument");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    std::unique_ptr<vc_engine::AsyncJob> job;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(e->jmu);
+            VC_CHECK(!e->jobs.empty(), VC_ERR_STATE, "no asynchronous batch is outstanding");
+            if (e->jcv.wait_for(lk, std::chrono::microseconds(100), [&] { return e->jobs.front()->done; })) {
+                job = std::move(e->jobs.front());
+                e->jobs.pop_front();
+                break;
+            }
+        }
+        VC_TRY(try_issue_next(e));
+    }
+    if (job->status != VC_OK) { vc::set_error("%s", job->err.c_str()); return job->status; }
+    VC_CHECK(job->b == b && job->cap == cap_rows_per_frame, VC_ERR_ARG, "collect: batch of %d frames x %d rows expected", job->b, job->cap);
+    memcpy(out_rows6, job->rows6.data(), job->rows6.size() * sizeof(int64_t));
+    memcpy(out_m, job->m.data(), (size_t)b * sizeof(int));
+    if (out_ndet) memcpy(out_ndet, job->ndet.data(), (size_t)b * sizeof(int));
+    return try_issue_next(e);
 }
 
 // Zone filter of VideoCounting.run (/root/reference/modules/track.py:102-104 -> utilities/counting/bb_polygon.py:14-114):

@@ -565,6 +565,7 @@ int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
 }
 
 int vc_tracker_reset(vc_engine* e, int id) {
+    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     Tracker& tk = *e->trackers[id];
     for (const TrackRec& t : tk.tracks) slot_free(e, t.slot);
@@ -574,6 +575,7 @@ int vc_tracker_reset(vc_engine* e, int id) {
 }
 
 int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf, const float* feat, int k) {
+    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     VC_CHECK(k == 0 || (tlwh && conf && feat), VC_ERR_ARG, "null argument");
     VC_CHECK(k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
@@ -591,6 +593,7 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
 }
 
 int vc_tracker_count(vc_engine* e, int id, int* n) {
+    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && n && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     *n = (int)e->trackers[id]->tracks.size();
     return VC_OK;
@@ -598,6 +601,7 @@ int vc_tracker_count(vc_engine* e, int id, int* n) {
 
 int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
                      double* cov64, int* gallery_count) {
+    if (e) async_wait_all(e);
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     const Tracker& tk = *e->trackers[id];
     VC_CHECK((int)tk.tracks.size() <= cap, VC_ERR_CAPACITY, "need room for %zu tracks", tk.tracks.size());
@@ -618,6 +622,7 @@ int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, in
 
 int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy, const double* conf, int k,
                        int64_t* out_rows7, int cap_rows, int* out_m) {
+    if (e) async_wait_all(e);
     VC_CHECK(e && bgr && out_m && id >= 0 && id < (int)e->trackers.size(), VC_ERR_ARG, "bad argument");
     VC_CHECK(k >= 1 && bbox_xyxy && conf, VC_ERR_ARG, "DeepSort.update needs at least one box (the reference only calls it then)");
     VC_HIP(hipSetDevice(e->cfg.device));
@@ -641,6 +646,7 @@ int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, c
 
 int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, const uint8_t* bgr, int h, int w, const double* boxes_xywh,
                         const int64_t* labels, const double* scores, int n, int64_t* out_rows6, int cap_rows, int* out_m) {
+    if (e) async_wait_all(e);
     VC_CHECK(e && trackers && bgr && out_m, VC_ERR_ARG, "null argument");
     VC_CHECK(n >= 1 && boxes_xywh && labels && scores, VC_ERR_ARG, "VideoTracker.run needs at least one box (quirk Q1)");
     VC_HIP(hipSetDevice(e->cfg.device));

@@ -202,6 +202,21 @@ class Engine:
         keep = np.arange(cap_rows)[None, :] < m[:, None]
         return rows[keep], np.repeat(np.arange(b), m), nd.copy()
 
+    def stream_run_async(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows=512):
+        """Start tracking the batch on the engine's worker thread and return; `stream_collect` picks the rows up (in order)."""
+        tr = np.ascontiguousarray(tracker_ids, dtype=np.int32)
+        L.check(L.lib().vc_stream_run_async(self._h, L.ptr(tr, C.c_int), len(tr), C.c_void_p(frames_dev_ptr), b, h, w, cap_rows))
+        self._async_shapes = getattr(self, "_async_shapes", [])
+        self._async_shapes.append((b, cap_rows))
+
+    def stream_collect(self):
+        """Rows of the oldest asynchronous batch, packed like `stream_run_packed` (blocks until its tracker loop is done)."""
+        b, cap_rows = self._async_shapes.pop(0)
+        rows, m, nd = np.empty((b, cap_rows, 6), np.int64), np.zeros(b, np.int32), np.zeros(b, np.int32)
+        L.check(L.lib().vc_stream_collect(self._h, L.ptr(rows, C.c_int64), cap_rows, L.ptr(m, C.c_int), L.ptr(nd, C.c_int), b))
+        keep = np.arange(cap_rows)[None, :] < m[:, None]
+        return rows[keep], np.repeat(np.arange(b), m), nd
+
     def stream_submit(self, frames_dev_ptr, b, h, w):
         """Enqueue the detector for a batch (returns immediately); the matching stream_run consumes it."""
         L.check(L.lib().vc_stream_submit(self._h, C.c_void_p(frames_dev_ptr), b, h, w))

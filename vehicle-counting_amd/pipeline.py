@@ -77,7 +77,9 @@ class CountingPipeline:
                     obj["boxes"].append(res["boxes"][j])
         return self._finish(counter, obj, cam_name)
 
-    def run_stream(self, source, cam_name, zone_path, batch=16):
+    def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False):
+        """asynchronous=True: the tracker loop of batch n runs on the engine's worker thread while batch n+1 is submitted and
+        embedded (`stream_run_async` / `stream_collect`); rows are identical, they arrive one batch later."""
         import torch
         tracker, counter = self._stages(cam_name, source.video_info, zone_path)
         obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
@@ -85,17 +87,25 @@ class CountingPipeline:
         t, h, w, _ = frames.shape
         dev = torch.from_numpy(frames).to(f"cuda:{self.engine.cfg.device}")      # tensor container only
         starts = list(range(0, t, batch))
+
+        def record(f0, rows, fidx):
+            obj["frames"].extend((f0 + 1 + fidx).tolist())
+            obj["tracks"].extend(rows[:, 4].tolist())
+            obj["labels"].extend(rows[:, 5].tolist())
+            obj["boxes"].extend(list(rows[:, :4].copy()))
+
         self.engine.stream_submit(dev[0:min(batch, t)].data_ptr(), min(batch, t), h, w)
         for n, f0 in enumerate(starts):
             b = min(batch, t - f0)
             if n + 1 < len(starts):                     # detect the next batch while this one is tracked
                 g0 = starts[n + 1]
                 self.engine.stream_submit(dev[g0:g0 + min(batch, t - g0)].data_ptr(), min(batch, t - g0), h, w)
-            rows, _ = self.engine.stream_run(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)
-            for i, r in enumerate(rows):
-                for row in r:
-                    obj["frames"].append(f0 + i + 1)
-                    obj["tracks"].append(int(row[4]))
-                    obj["labels"].append(int(row[5]))
-                    obj["boxes"].append(row[:4].copy())
+            if asynchronous:
+                self.engine.stream_run_async(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)
+                if n > 0:
+                    record(starts[n - 1], *self.engine.stream_collect()[:2])
+            else:
+                record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)[:2])
+        if asynchronous and starts:
+            record(starts[-1], *self.engine.stream_collect()[:2])
         return self._finish(counter, obj, cam_name)
