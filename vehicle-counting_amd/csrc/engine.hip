@@ -396,8 +396,13 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
                 ConvP cp = op.conv;
-                cp.cfg = tuned_cfg(e, cp, s);
-                {
+                static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
+                if (stem_direct_on && stem_direct_applicable(cp)) {          // YOLO stem, bf16: direct convolution (stem_direct.hip)
+                    cp.cfg = 100;
+                    ProfScope ps(e, VC_PROF_CONV, fl, by, s);
+                    VC_TRY(launch_stem_direct(cp, s));
+                } else {
+                    cp.cfg = tuned_cfg(e, cp, s);
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                     VC_TRY(launch_conv(cp, s));
                 }

@@ -1,0 +1,138 @@
+// YOLOv5 stem (6x6 / stride 2 / pad 2 over 3 input channels, models/yolo.py v6.0 layer 0) as a direct
+// convolution for the bf16 path.
+//
+// The implicit-GEMM kernel treats the stem like any other layer: every output pixel's 6x3 taps (pairs of 4-channel pixels,
+// DESIGN.md section 3) are gathered global -> LDS as 18 separate 16-byte pieces, 2.1 GB through the vector cache per 64
+// frames for a layer whose algorithmic traffic is 0.63 GB.  Here a workgroup stages the input patch of an 8 x 32 output tile
+// ONCE (20 rows x 34 pixel pairs, 11 KB), keeps the whole weight matrix in registers across the tiles it walks, and feeds the
+// same MFMA sequence from the patch: the layer becomes what it is, an HBM stream (read 8 B, write 64 B per input pixel).
+// The MFMA operand order and the k order are those of conv_igemm_kernel, so the results are bit-identical to it.
+#include "vc_common.h"
+
+namespace vc {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+union ChunkS { uint4 u; bf16x8s h; };
+
+#define STEM_TH 8
+#define STEM_TW 32
+#define STEM_PR 20            // patch rows  = 2*TH + 4
+#define STEM_PC 34            // patch pairs = TW + 2
+#define STEM_PP 36            // LDS row pitch in 16-byte chunks
+
+template <int CT>   // Cout = CT * 16
+__global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w, const float* __restrict__ bias,
+                                                          uint16_t* __restrict__ y, int B, int H, int Wp, int Ho, int Wo, int Kw8 /* weight row stride in chunks */,
+                                                          int out_cs, int out_co, int tiles_x, int tiles_y) {
+    __shared__ uint4 patch[STEM_PR * STEM_PP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    // weights: 5 k-steps x CT channel tiles, lane (channel = ct*16 + col, chunk = 4*s + kq); chunks 18..23 of the packed rows are zero
+    ChunkS wf[5][CT];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) wf[s][ct].u = w[(size_t)(ct * 16 + col) * Kw8 + 4 * s + kq];
+    float4 bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bv[ct] = *(const float4*)(bias + ct * 16 + kq * 4);
+    // LDS offsets of this lane's operand chunk per k-step, relative to the pixel's patch origin (row 2*ly, pair lx)
+    int koff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int q = min(4 * s + kq, 17);          // padded chunks multiply zero weights: any finite operand will do
+        koff[s] = (q / 3) * STEM_PP + (q % 3);
+    }
+    const int ntiles = B * tiles_y * tiles_x;
+    // patch of the NEXT tile travels through registers while this tile is multiplied and stored (3 chunks per thread)
+    constexpr int NPRE = (STEM_PR * STEM_PC + 255) / 256;
+    uint4 pre[NPRE];
+    auto fetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int pr = i / STEM_PC, pc = i - pr * STEM_PC;
+            const int iy = 2 * oy0 - 2 + pr, ip = ox0 - 1 + pc;
+            pre[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < STEM_PR * STEM_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) pre[k] = x[((size_t)b * H + iy) * Wp + ip];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
+        __syncthreads();                             // the previous tile's reads are done
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < STEM_PR * STEM_PC) { const int pr = i / STEM_PC; patch[pr * STEM_PP + (i - pr * STEM_PC)] = pre[k]; }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        f32x4s acc[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            ChunkS xf[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int ly = wave * 2 + (pt >> 1), lx = (pt & 1) * 16 + col;
+                xf[pt].u = patch[(2 * ly) * STEM_PP + lx + koff[s]];
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ct].h, xf[pt].h, acc[ct][pt], 0, 0, 0);
+        }
+        // epilogue: bias + SiLU (same expression as conv_igemm.hip::act_apply, fast path), 4 consecutive channels per lane
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int oy = oy0 + wave * 2 + (pt >> 1), ox = ox0 + (pt & 1) * 16 + col;
+            if (oy >= Ho || ox >= Wo) continue;
+            uint16_t* o = y + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_co + kq * 4;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float v[4] = {acc[ct][pt][0] + bv[ct].x, acc[ct][pt][1] + bv[ct].y, acc[ct][pt][2] + bv[ct].z, acc[ct][pt][3] + bv[ct].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
+                typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+                const bf16x2s p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
+                uint2 pk;
+                pk.x = __builtin_bit_cast(uint32_t, p0); pk.y = __builtin_bit_cast(uint32_t, p1);
+                *(uint2*)(o + ct * 16) = pk;
+            }
+        }
+    }
+}
+
+// p describes the stem as launch_conv sees it (pair view: H x W/2 x 8 channels, 6 x 3 kernel, stride (2,1), pad (2,1)).
+bool stem_direct_applicable(const ConvP& p) {
+    return p.prec == PREC_BF16 && p.kh == 6 && p.kw == 3 && p.sh == 2 && p.sw == 1 && p.ph == 2 && p.pw == 1 && p.Cin == 8 && p.in_cs == 8 &&
+           p.in_co == 0 && p.act == ACT_SILU && p.res_mode == RES_NONE && !p.out_f32 && p.split == 0 && p.Cout % 16 == 0 && p.Cout >= 16 &&
+           p.Cout <= 64 && p.Kp >= 160 && p.out_cs % 4 == 0 && p.out_co % 4 == 0;
+}
+
+int launch_stem_direct(const ConvP& p, hipStream_t s) {
+    const int tiles_x = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_y = (p.Ho + STEM_TH - 1) / STEM_TH;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int grid = std::min(ntiles, 256 * 3);      // 3 workgroups per CU are resident (VGPRs); each walks ~ntiles/768 tiles
+    const uint4* x = (const uint4*)p.in; const uint4* w = (const uint4*)p.w;
+    uint16_t* y = (uint16_t*)p.out;
+    const int kw8 = p.Kp / 8;
+    switch (p.Cout / 16) {
+        case 1: hipLaunchKernelGGL(stem_direct_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 2: hipLaunchKernelGGL(stem_direct_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 3: hipLaunchKernelGGL(stem_direct_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        default: hipLaunchKernelGGL(stem_direct_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+    }
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace vc
