@@ -73,12 +73,18 @@ def test_conv2d(case, precision):
         np.testing.assert_allclose(y, ref, rtol=2 ** -7, atol=2e-3)
 
 
-@pytest.mark.parametrize("cfg", range(28))
+@pytest.mark.parametrize("cfg", range(32))
 def test_conv2d_every_tile_config(cfg, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""
     monkeypatch.setenv("VC_CONV_CFG", str(cfg))
-    for case in [(2, 23, 19, 24, 72, 3, 1, 1, 1, 1), (1, 9, 9, 8, 130, 3, 1, 1, 0, 0), (3, 20, 20, 136, 40, 1, 2, 0, 1, 2)]:
+    cases = [(2, 23, 19, 24, 72, 3, 1, 1, 1, 1), (1, 9, 9, 8, 130, 3, 1, 1, 0, 0), (3, 20, 20, 136, 40, 1, 2, 0, 1, 2)]
+    if cfg >= 28:
+        # halo-staged 3x3 / s1 / p1 variants (bf16 path; Cin a multiple of 32): ragged tiles, patches that cross the batch seam
+        # (7x7 and 4x5 maps: one tile spans several images), residual before / after the activation, 2 and 4 channel slices
+        cases = [(2, 23, 19, 64, 72, 3, 1, 1, 1, 1), (5, 7, 7, 32, 40, 3, 1, 1, 2, 2), (9, 4, 5, 128, 130, 3, 1, 1, 1, 0),
+                 (1, 40, 160, 32, 64, 3, 1, 1, 1, 0)]
+    for case in cases:
         B, H, W, Ci, Co, k, s, p, act, rm = case
         rng = np.random.default_rng(cfg * 131 + H)
         x = rng.standard_normal((B, H, W, Ci), dtype=np.float32)
@@ -86,7 +92,7 @@ def test_conv2d_every_tile_config(cfg, monkeypatch):
         b = rng.standard_normal(Co, dtype=np.float32) * 0.1
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         res = rng.standard_normal((B, Ho, Wo, Co), dtype=np.float32) if rm else None
-        for precision in ("bf16", "f32"):
+        for precision in (("bf16",) if cfg >= 28 else ("bf16", "f32")):
             y = E.conv2d(x, w, b, stride=s, pad=p, act=act, res=res, res_mode=rm, precision=precision)
             ref = torch_conv(x, w, b, s, p, act, res, rm, precision)
             if precision == "f32":

@@ -8,7 +8,7 @@ for cfg in ${CFGS:-3 6}; do
     python - <<PY
 import sqlite3
 c = sqlite3.connect("/tmp/ab/a_results.db")
-r = list(c.execute("select min(duration), avg(duration) from kernels where name like '%conv_igemm%'"))[0]
+r = list(c.execute("select min(duration), avg(duration) from kernels where name like '%conv%_kernel%'"))[0]
 print("shape $shape cfg $cfg dyn_lds $lds  min %.1f us avg %.1f us" % (r[0]/1e3, r[1]/1e3))
 PY
   done

@@ -56,6 +56,76 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// Epilogue shared by the conv kernels: D[channel = (lane>>4)*4 + reg][pixel = lane&15] -> bias, activation, residual, bf16
+// pack, concat-slice / split-destination store.  mbase = first pixel of the wave's tile, nbase = this lane's first channel.
+template <int PT, int CT, bool F32>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][PT], int mbase, int nbase, int frow) {
+    float4 bias[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // 32-bit element offsets + buffer stores (SGPR descriptors): no 64-bit address arithmetic per tile
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res_mode != RES_NONE ? p.res : p.bias), 0, 0x7ffffff0, 0x00020000);
+    const bool wide_out = F32 || p.out_f32;
+    const int OES = wide_out ? 4 : 2;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+        const int m = mbase + b * 16 + frow;
+        if (m >= p.M) continue;
+        const int orow = m * p.out_cs + p.out_co, rrow = m * p.res_cs + p.res_co, orow2 = m * p.out2_cs + p.out2_co;
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int n = nbase + a * 16;
+            if (n >= p.Cout) continue;
+            float v[4] = {acc[a][b][0] + bias[a].x, acc[a][b][1] + bias[a].y, acc[a][b][2] + bias[a].z, acc[a][b][3] + bias[a].w};
+            float rv[4] = {0.f, 0.f, 0.f, 0.f};
+            const int nvalid = p.Cout - n >= 4 ? 4 : p.Cout - n;
+            if (p.res_mode != RES_NONE) {
+                if constexpr (F32) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrd, (rrow + n) * 4, 0, 0);
+                    rv[0] = __uint_as_float(t.x); rv[1] = __uint_as_float(t.y); rv[2] = __uint_as_float(t.z); rv[3] = __uint_as_float(t.w);
+                } else {
+                    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (rrow + n) * 2, 0, 0);
+                    rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
+                    rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[j];
+                if (p.res_mode == RES_BEFORE_ACT) t += rv[j];
+                t = act_apply(t, p.act, F32);
+                if (p.res_mode == RES_AFTER_ACT) t += rv[j];
+                v[j] = t;
+            }
+            const bool second = p.split > 0 && n >= p.split;            // uniform per 4-channel group
+            const int eoff = (second ? orow2 + (n - p.split) : orow + n) * OES;
+            if (nvalid == 4) {
+                if (wide_out) {
+                    const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    if (second) __builtin_amdgcn_raw_buffer_store_b128(t, osrd2, eoff, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(t, osrd, eoff, 0, 0);
+                } else {
+                    const u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    if (second) __builtin_amdgcn_raw_buffer_store_b64(t, osrd2, eoff, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(t, osrd, eoff, 0, 0);
+                }
+            } else {                                                      // ragged channel tail (e.g. Detect's 255 outputs)
+                char* ob = (char*)(second ? p.out2 : p.out) + eoff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nvalid) {
+                        if (wide_out) ((float*)ob)[j] = v[j];
+                        else ((uint16_t*)ob)[j] = f32_to_bf16(v[j]);
+                    }
+            }
+        }
+    }
+}
+
 // BP x BC output tile (pixels x channels) per workgroup of WP x WC wavefronts; KC 16-byte chunks of K per tile row.
 //
 // Staging: both operands go global -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA: no VGPR round trip, no ds_write).
@@ -164,9 +234,35 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
         kc_off = (uint32_t)((r * p.W + kc_s) * p.in_cs * ES);
     }
     const int nk = p.Kp / BK;
+    // When Cin is a multiple of the K tile (every layer but the stems) a K tile lies inside ONE tap, the same for every
+    // lane: the tap walk is then scalar state (SALU) instead of a divergent per-lane loop -- the K loop of the 3x3 layers
+    // was VALU-issue bound (35 VALU instructions per 8 MFMAs), and this is where half of them went.
+    const bool ut = (p.Cin % BK) == 0;
+    int u_tap = 0, u_s = 0, u_c = 0;
+    uint32_t u_tapoff = 0;
+    uint32_t xoffl[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) xoffl[i] = xoff[i] + (uint32_t)(kc0 * CH * ES);
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define VC_STAGE(kt, buf)                                                                                                \
+    if (ut) {                                                                                                            \
+        const uint32_t so = u_tapoff + (uint32_t)(u_c * ES);                                                             \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                 \
+            const uint32_t o = ((xmask[i] >> u_tap) & 1ull) ? xoffl[i] + so : OOB;                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[buf][(PASS * i + uwave * RPI) * KC], 16, (int)o, 0, 0, 0); \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[buf][BP * KC + (PASS * i + uwave * RPI) * KC], 16,     \
+                                                     (int)(woff[i] + (uint32_t)((kt) * BK * ES)), 0, 0, 0);             \
+        }                                                                                                                \
+        u_c += BK;                                                                                                       \
+        if (u_c == p.Cin) {                                                                                              \
+            u_c = 0;                                                                                                     \
+            u_tap = min(u_tap + 1, 63);                                                                                  \
+            if (++u_s == p.kw) { u_s = 0; u_tapoff += tap_y; } else { u_tapoff += tap_x; }                               \
+        }                                                                                                                \
+    } else                                                                                                               \
     {                                                                                                                    \
         const uint32_t tc = kc_off + (uint32_t)(kc_c * ES);                                                              \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                 \
@@ -260,73 +356,187 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
 
     // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]
     if (p.ablate == 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }           // no epilogue
-    const int nbase = n0 + wc * WTC + fch * 4;
-    float4 bias[CT];
+    conv_epilogue<PT, CT, F32>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VC_TS(4); }
+#undef VC_TS
+}
+
+// ---- halo-staged 3x3 / stride 1 / pad 1 (bf16) ---------------------------------------------------------------------------
+// The implicit GEMM above stages every output pixel's nine taps separately: each input line travels L2 -> LDS nine times, and
+// the K loops of the 3x3 layers (93 % L2 hits) sit at half of the L2 bandwidth.  Here the K loop is turned inside out: outer
+// loop over 32-channel slices, inner loop over the 9 taps.  A workgroup owns BP consecutive output pixels; per slice it stages
+// the input rows those pixels touch ONCE -- rows g0-1 .. g1+1 of the flattened (batch, y) row space are contiguous in NHWC, so
+// the patch is a plain run of `npix` pixels starting at pixel (g0-1)*W -- and the nine taps read their MFMA operand from that
+// patch at pixel + dy*W + dx.  Taps that fall outside the image (also across the batch seam inside a patch) read a zero
+// pixel instead: a 9-bit validity mask per lane, the addresses of all nine taps are loop invariant.  Weights stream through
+// the same NS-stage LDS-DMA ring as above, one (tap, slice) tile of [BC][32] per step.  The MFMA / accumulation order per
+// output equals the implicit GEMM's only up to the order of the K tiles (tap-major there, slice-major here): results agree
+// to fp32 rounding, not bit for bit (same tolerance as between tile configurations with different K chunking... they are
+// identical there; here the tests' bf16 / fp32 tolerances apply).
+template <int BP, int BC, int WP, int WC, int NS, int XI>
+__global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
+    constexpr int KC = 4, ES = 2, BK = 32;
+    constexpr int PASS = 64;                       // weight rows covered by one DMA instruction of all four waves (16 per wave)
+    constexpr int WI = (BC + PASS - 1) / PASS;
+    constexpr int WROWS = WI * PASS;
+    constexpr int WTP = BP / WP, WTC = BC / WC, PT = WTP / 16, CT = WTC / 16;
+    constexpr int ZP = XI * 64 - 1;                // index of the zero pixel: last pixel of a patch buffer, never reached by a patch
+    constexpr int XCH = XI * 256;                  // 16-byte chunks per patch buffer
+    constexpr uint32_t OOB = 0x80000000u;
+    static_assert(WP * WC == 4 && WTP % 16 == 0 && WTC % 16 == 0, "tile shape");
+    static_assert((NS - 2) * WI + XI <= 63, "counted vmcnt");
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * XCH + NS * WROWS * KC];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int nblk = gridDim.x;
+    const int tiles_c = (p.Cout + BC - 1) / BC;
+    int tile;
+    {
+        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int m0 = (tile / tiles_c) * BP;
+    const int n0 = (tile % tiles_c) * BC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int W = p.W, H = p.H;
+
+    // patch geometry (workgroup-uniform)
+    const int g0 = m0 / W;
+    const int g1 = (min(m0 + BP, p.M) - 1) / W;
+    const int gp0 = (g0 - 1) * W;                  // first patch pixel (may be negative: row -1 of the first image)
+    const int npix = (g1 - g0 + 3) * W;            // <= ZP, checked by the launcher
+
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.in), 0, (int)((size_t)p.B * p.H * p.W * p.in_cs * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.w), 0, (int)((size_t)((p.Cout + 127) / 128 * 128) * p.Kw * ES), 0x00020000);
+
+    // patch staging: instruction i of this wave fills chunks [(i*4 + wave)*64, +64); lane -> (patch pixel, chunk slot)
+    uint32_t xsrc[XI];
 #pragma unroll
-    for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // 32-bit element offsets + buffer stores (SGPR descriptors): no 64-bit address arithmetic per tile
-    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res_mode != RES_NONE ? p.res : p.bias), 0, 0x7ffffff0, 0x00020000);
-    const bool wide_out = F32 || p.out_f32;
-    const int OES = wide_out ? 4 : 2;
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (int i = 0; i < XI; ++i) {
+        const int e = (i * 4 + wave) * 64 + lane;
+        const int pp = e >> 2, cpos = e & 3;
+        const int chunk = cpos ^ ((0x78 >> (((pp >> 2) & 3) * 2)) & 3);          // source-side swizzle (lds_slot<4>)
+        const int gp = gp0 + pp;
+        xsrc[i] = (pp < npix && gp >= 0) ? (uint32_t)((gp * p.in_cs + p.in_co) * ES + chunk * 16) : OOB;
+    }
+    // weight staging: rows of 4 chunks, 16 rows per wave-instruction (as in conv_igemm_kernel with KC = 4)
+    const int prow = wave * 16 + (lane >> 2);
+    const int wchunk = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+    uint32_t woff[WI];
 #pragma unroll
-    for (int b = 0; b < PT; ++b) {
-        const int m = m0 + wp * WTP + b * 16 + frow;
-        if (m >= p.M) continue;
-        const int orow = m * p.out_cs + p.out_co, rrow = m * p.res_cs + p.res_co, orow2 = m * p.out2_cs + p.out2_co;
+    for (int i = 0; i < WI; ++i) woff[i] = (uint32_t)(((n0 + prow + PASS * i) * p.Kw + wchunk * 8) * ES);
+
+    // fragment addresses: this lane's pixel of every pixel tile, its nine taps (byte offsets inside a patch buffer)
+    const int wp = wave % WP, wc = wave / WP;
+    const int frow = lane & 15, fch = lane >> 4;
+    uint32_t xaddr[PT][9];
+    {
+        const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
 #pragma unroll
-        for (int a = 0; a < CT; ++a) {
-            const int n = nbase + a * 16;
-            if (n >= p.Cout) continue;
-            float v[4] = {acc[a][b][0] + bias[a].x, acc[a][b][1] + bias[a].y, acc[a][b][2] + bias[a].z, acc[a][b][3] + bias[a].w};
-            float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            const int nvalid = p.Cout - n >= 4 ? 4 : p.Cout - n;
-            if (p.res_mode != RES_NONE) {
-                if constexpr (F32) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrd, (rrow + n) * 4, 0, 0);
-                    rv[0] = __uint_as_float(t.x); rv[1] = __uint_as_float(t.y); rv[2] = __uint_as_float(t.z); rv[3] = __uint_as_float(t.w);
-                } else {
-                    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (rrow + n) * 2, 0, 0);
-                    rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
-                    rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
-                }
-            }
+        for (int i = 0; i < PT; ++i) {
+            const int m = m0 + wp * WTP + i * 16 + frow;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : m0;
+            int g = (int)((float)mm * inv_w);                                     // global row, +-1 fix-up (mm < 2^24)
+            g -= (g * W > mm) ? 1 : 0;
+            g += ((g + 1) * W <= mm) ? 1 : 0;
+            const int x = mm - g * W;
+            int b = (int)((float)g * inv_h);
+            b -= (b * H > g) ? 1 : 0;
+            b += ((b + 1) * H <= g) ? 1 : 0;
+            const int y = g - b * H;
+            const int pc = mm - gp0;                                              // patch index of the centre tap
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = v[j];
-                if (p.res_mode == RES_BEFORE_ACT) t += rv[j];
-                t = act_apply(t, p.act, F32);
-                if (p.res_mode == RES_AFTER_ACT) t += rv[j];
-                v[j] = t;
-            }
-            const bool second = p.split > 0 && n >= p.split;            // uniform per 4-channel group
-            const int eoff = (second ? orow2 + (n - p.split) : orow + n) * OES;
-            if (nvalid == 4) {
-                if (wide_out) {
-                    const u32x4 t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    if (second) __builtin_amdgcn_raw_buffer_store_b128(t, osrd2, eoff, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(t, osrd, eoff, 0, 0);
-                } else {
-                    const u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    if (second) __builtin_amdgcn_raw_buffer_store_b64(t, osrd2, eoff, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(t, osrd, eoff, 0, 0);
-                }
-            } else {                                                      // ragged channel tail (e.g. Detect's 255 outputs)
-                char* ob = (char*)(second ? p.out2 : p.out) + eoff;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nvalid) {
-                        if (wide_out) ((float*)ob)[j] = v[j];
-                        else ((uint16_t*)ob)[j] = f32_to_bf16(v[j]);
-                    }
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool valid = ok && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+                const int px = valid ? pc + dy * W + dx : ZP;
+                xaddr[i][t] = (uint32_t)((px * 4 + (fch ^ ((0x78 >> (((px >> 2) & 3) * 2)) & 3))) * 16);
             }
         }
     }
-    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VC_TS(4); }
-#undef VC_TS
+    int wfrag[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wfrag[i] = 16 * lds_slot<4>(wc * WTC + i * 16 + frow, fch);
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0];
+    constexpr uint32_t XBYTES = XCH * 16, WSTAGE = WROWS * KC * 16;
+    const uint32_t wring = lds_base + 2 * XBYTES;
+    const int nslices = p.Cin / BK;
+    const int nk = nslices * 9;                    // K tiles, slice-major: kt = slice * 9 + tap
+
+    // zero pixels (one per patch buffer): plain LDS stores, ordered before the first barrier
+    if (tid < 8) lds[(tid >> 2) * XCH + ZP * 4 + (tid & 3)] = make_uint4(0u, 0u, 0u, 0u);
+
+#define VC_XSTAGE(slice, xb)                                                                                              \
+    {                                                                                                                     \
+        const uint32_t so = (slice) < nslices ? (uint32_t)((slice) * BK * ES) : OOB;                                       \
+        _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[(xb) * XCH + (i * 4 + uwave) * 64], 16,           \
+                                                     (int)((xsrc[i] | so) >= OOB ? OOB : xsrc[i] + so), 0, 0, 0);          \
+    }
+#define VC_WSTAGE(kt, st)                                                                                                 \
+    {                                                                                                                     \
+        const int kk = (kt);                                                                                               \
+        const int sl = kk / 9, tp = kk - sl * 9;                                                                           \
+        const uint32_t ko = kk < nk ? (uint32_t)((tp * p.Cin + sl * BK) * ES) : OOB;                                       \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[2 * XCH + (st) * WROWS * KC + (PASS * i + uwave * 16) * KC], 16, \
+                                                     (int)(ko >= OOB ? OOB : woff[i] + ko), 0, 0, 0);                       \
+    }
+
+    VC_XSTAGE(0, 0);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) VC_WSTAGE(st, st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int kt = 0, sbuf = NS - 1;
+    uint32_t woffs = wring;                        // LDS address of the weight stage being multiplied
+    for (int slice = 0; slice < nslices; ++slice) {
+        const uint32_t xb = lds_base + (uint32_t)(slice & 1) * XBYTES;
+        VC_XSTAGE(slice + 1, (slice + 1) & 1);     // next slice's patch: its buffer was last read one slice ago
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++kt) {
+            VC_WSTAGE(kt + NS - 1, sbuf);
+            sbuf = sbuf + 1 == NS ? 0 : sbuf + 1;
+            u32x4v xr[PT], wr[CT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[i]) : "v"(xb + xaddr[i][t]) : "memory");
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wr[i]) : "v"(woffs + wfrag[i]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            Chunk xa[PT], wa[CT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) { asm volatile("" : "+v"(xr[i])); xa[i].u = xr[i]; }
+#pragma unroll
+            for (int i = 0; i < CT; ++i) { asm volatile("" : "+v"(wr[i])); wa[i].u = wr[i]; }
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[a].h, xa[b].h, acc[a][b], 0, 0, 0);
+            woffs = woffs + WSTAGE == wring + NS * WSTAGE ? wring : woffs + WSTAGE;
+            // weight tile kt+1 has landed once at most the newer weight tiles -- and, while it is still older than this
+            // slice's patch prefetch, that prefetch -- are outstanding
+            if (t < NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI + XI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef VC_XSTAGE
+#undef VC_WSTAGE
+    conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
 }
 
 int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights are padded to the widest K tile (KC = 8)
@@ -345,11 +555,13 @@ double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * 
     X(18, 128, 64, 2, 2, 8, 3)  X(19, 128, 128, 2, 2, 4, 4) X(20, 128, 128, 2, 2, 8, 3) X(21, 64, 128, 1, 4, 4, 4)    \
     X(22, 64, 128, 1, 4, 8, 3)  X(23, 256, 32, 4, 1, 4, 4)  X(24, 256, 64, 4, 1, 4, 4)  X(25, 256, 64, 4, 1, 8, 3)    \
     X(26, 256, 128, 2, 2, 4, 4) X(27, 256, 128, 2, 2, 8, 3)
+// halo-staged 3x3 / s1 / p1 (bf16): Y(index, BP, BC, WP, WC, NS)
+#define VC_HALO_CFGS(Y) Y(28, 128, 64, 2, 2, 2) Y(29, 128, 64, 2, 2, 3) Y(30, 128, 128, 2, 2, 2) Y(31, 128, 128, 2, 2, 3)
 struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])); }
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4; }       // + the halo-staged 3x3 variants
 
 template <int BP, int BC, int WP, int WC, int KC, int NS>
 static int launch_one(ConvP p, hipStream_t s) {
@@ -372,9 +584,37 @@ static int conv_heuristic(const ConvP& p) {
     return t128 >= 512 ? 2 : 3;
 }
 
+// patch buffer sizes: XI x 64 pixels of 64 B (the last one is the zero pixel); the smallest that holds the layer's patch is
+// used, because the patch buffers decide how many workgroups share a CU (2 x 16 / 28 / 44 KB)
+static int halo_patch_pixels(const ConvP& p, int bp) {
+    const int rows = (bp - 1 + p.W - 1) / p.W + 1 + 2;               // worst case: a tile that starts at the end of a row
+    return rows * p.W;
+}
+static bool halo_applicable(const ConvP& p, int bp) {
+    if (p.prec != PREC_BF16 || p.kh != 3 || p.kw != 3 || p.sh != 1 || p.sw != 1 || p.ph != 1 || p.pw != 1) return false;
+    if (p.Cin % 32 != 0 || p.in_cs % 8 != 0 || p.in_co % 8 != 0 || p.Ho != p.H || p.Wo != p.W) return false;
+    return halo_patch_pixels(p, bp) <= 11 * 64 - 1;
+}
+
+template <int BP, int BC, int WP, int WC, int NS>
+static int launch_halo(ConvP p, hipStream_t s) {
+    if (!halo_applicable(p, BP)) return VC_ERR_ARG;                   // quietly: the autotuner skips it, launch_conv falls back
+    const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
+    p.Kw = p.Kp;
+    const int px = halo_patch_pixels(p, BP);
+    if (px <= 4 * 64 - 1) hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 4>), dim3(tiles), dim3(256), 0, s, p);
+    else if (px <= 7 * 64 - 1) hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 7>), dim3(tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 11>), dim3(tiles), dim3(256), 0, s, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
     switch (cfg) {
+#define VC_Y(i, bp, bc, wp, wc, ns) case i: return launch_halo<bp, bc, wp, wc, ns>(p, s);
+        VC_HALO_CFGS(VC_Y)
+#undef VC_Y
 #define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
         VC_CONV_CFGS(VC_X)
 #undef VC_X
