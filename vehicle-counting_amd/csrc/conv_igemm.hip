@@ -191,11 +191,17 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
     uint32_t xoff[XI];
     unsigned long long xmask[XI];
+    const bool pointwise = p.kh == 1 && p.kw == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;    // uniform
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int m = m0 + prow + PASS * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
+        if (pointwise) {                                         // 1x1 / stride 1: output pixel m reads input pixel m, one tap
+            xoff[i] = (uint32_t)((mm * p.in_cs + p.in_co) * ES);
+            xmask[i] = ok ? 1ull : 0ull;
+            continue;
+        }
         int b = (int)((float)mm * inv_howo);                     // mm < 2^24: the float product is within 1 of the quotient
         b -= (b * HoWo > mm) ? 1 : 0;
         b += ((b + 1) * HoWo <= mm) ? 1 : 0;
