@@ -73,11 +73,16 @@ def test_conv2d(case, precision):
         np.testing.assert_allclose(y, ref, rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("slots", [0, 8])
 @pytest.mark.parametrize("cfg", range(32))
-def test_conv2d_every_tile_config(cfg, monkeypatch):
+def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""
     monkeypatch.setenv("VC_CONV_CFG", str(cfg))
+    if slots:
+        if cfg >= 28:
+            pytest.skip("the halo variants are not persistent")
+        monkeypatch.setenv("VC_CONV_SLOTS", str(slots))       # 8 persistent workgroups walk all tiles: the K ring crosses tile boundaries
     cases = [(2, 23, 19, 24, 72, 3, 1, 1, 1, 1), (1, 9, 9, 8, 130, 3, 1, 1, 0, 0), (3, 20, 20, 136, 40, 1, 2, 0, 1, 2)]
     if cfg >= 28:
         # halo-staged 3x3 / s1 / p1 variants (bf16 path; Cin a multiple of 32): ragged tiles, patches that cross the batch seam

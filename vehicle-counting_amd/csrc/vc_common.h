@@ -77,6 +77,7 @@ struct ConvP {
     int act, res_mode, out_f32, prec;
     int M;               // B*Ho*Wo
     int cfg;             // tile configuration index (conv_igemm.hip kCfg), -1 = heuristic
+    int ntiles;          // set by the launcher: output tiles of the chosen configuration (the grid may be smaller: persistent)
     // optional second destination: output channels >= split go to out2 (two 1x1 convs over the same input fused into
     // one launch, e.g. C3.cv1 + C3.cv2); split is a multiple of 4, 0 = single destination
     void* out2;
