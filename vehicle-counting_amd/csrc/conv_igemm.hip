@@ -71,6 +71,61 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
     const int OES = wide_out ? 4 : 2;
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // bf16 fast path: 16-byte stores.  The MFMA layout leaves 4 consecutive channels of one pixel in a lane (an 8-byte
+    // store); lane pairs (lane, lane ^ 16) hold channels [8g, 8g+4) and [8g+4, 8g+8) of the SAME pixels, so for two pixel
+    // tiles they swap halves -- the even lane ends with 8 channels of the first tile's pixel, the odd lane with 8 channels of
+    // the second tile's pixel -- and each stores one dwordx4.  Half the store instructions: the store tail of these kernels
+    // is issue-bound (MI355X_MICROARCH.md, "epilogue store tail").
+    if constexpr (!F32 && PT % 2 == 0) {
+        const bool fast = !p.out_f32 && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_co % 8 == 0 &&
+                          (p.split == 0 || (p.split % 8 == 0 && p.out2_cs % 8 == 0 && p.out2_co % 8 == 0));
+        if (fast) {
+            const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+#pragma unroll
+            for (int b = 0; b < PT; b += 2) {
+#pragma unroll
+                for (int a = 0; a < CT; ++a) {
+                    const int n = nbase + a * 16;
+                    const bool grp_ok = n < p.Cout;                     // the same for both lanes of a pair (Cout % 8 == 0)
+                    u32x2 P[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int m = mbase + (b + t) * 16 + frow;
+                        const bool ok = grp_ok && m < p.M;
+                        float v[4] = {acc[a][b + t][0] + bias[a].x, acc[a][b + t][1] + bias[a].y, acc[a][b + t][2] + bias[a].z, acc[a][b + t][3] + bias[a].w};
+                        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.res_mode != RES_NONE) {
+                            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrd, ok ? (m * p.res_cs + p.res_co + n) * 2 : 0, 0, 0);
+                            rv[0] = __uint_as_float(r.x << 16); rv[1] = __uint_as_float(r.x & 0xffff0000u);
+                            rv[2] = __uint_as_float(r.y << 16); rv[3] = __uint_as_float(r.y & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = v[j];
+                            if (p.res_mode == RES_BEFORE_ACT) x += rv[j];
+                            x = act_apply(x, p.act, false);
+                            if (p.res_mode == RES_AFTER_ACT) x += rv[j];
+                            v[j] = x;
+                        }
+                        P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    }
+                    const u32x2 send = odd ? P[0] : P[1];
+                    u32x2 recv;
+                    recv.x = (unsigned)__shfl_xor((int)send.x, 16);
+                    recv.y = (unsigned)__shfl_xor((int)send.y, 16);
+                    const u32x4 o4 = odd ? (u32x4){recv.x, recv.y, P[1].x, P[1].y} : (u32x4){P[0].x, P[0].y, recv.x, recv.y};
+                    const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
+                    const int nn = odd ? n - 4 : n;
+                    if (grp_ok && m < p.M) {
+                        const bool second = p.split > 0 && nn >= p.split;
+                        if (second) __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (m * p.out2_cs + p.out2_co + nn - p.split) * 2, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (m * p.out_cs + p.out_co + nn) * 2, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
         const int m = mbase + b * 16 + frow;

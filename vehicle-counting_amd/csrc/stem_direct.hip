@@ -90,22 +90,33 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][ct].h, xf[pt].h, acc[ct][pt], 0, 0, 0);
         }
-        // epilogue: bias + SiLU (same expression as conv_igemm.hip::act_apply, fast path), 4 consecutive channels per lane
+        // epilogue: bias + SiLU (same expression as conv_igemm.hip::act_apply, fast path).  A lane holds 4 consecutive channels of a
+        // pixel; lane pairs (lane, lane ^ 16) swap halves across two pixel tiles so that each lane stores 8 channels (16 bytes) of
+        // ONE pixel -- half the store instructions (see conv_igemm.hip::conv_epilogue).
+        const bool odd = (kq & 1) != 0;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const int oy = oy0 + wave * 2 + (pt >> 1), ox = ox0 + (pt & 1) * 16 + col;
-            if (oy >= Ho || ox >= Wo) continue;
-            uint16_t* o = y + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_co + kq * 4;
+        for (int pt = 0; pt < 4; pt += 2) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                float v[4] = {acc[ct][pt][0] + bv[ct].x, acc[ct][pt][1] + bv[ct].y, acc[ct][pt][2] + bv[ct].z, acc[ct][pt][3] + bv[ct].w};
+                uint2 P[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
-                typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
-                const bf16x2s p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
-                uint2 pk;
-                pk.x = __builtin_bit_cast(uint32_t, p0); pk.y = __builtin_bit_cast(uint32_t, p1);
-                *(uint2*)(o + ct * 16) = pk;
+                for (int t = 0; t < 2; ++t) {
+                    float v[4] = {acc[ct][pt + t][0] + bv[ct].x, acc[ct][pt + t][1] + bv[ct].y, acc[ct][pt + t][2] + bv[ct].z, acc[ct][pt + t][3] + bv[ct].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
+                    typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+                    const bf16x2s p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
+                    P[t].x = __builtin_bit_cast(uint32_t, p0); P[t].y = __builtin_bit_cast(uint32_t, p1);
+                }
+                const uint2 send = odd ? P[0] : P[1];
+                uint2 recv;
+                recv.x = (unsigned)__shfl_xor((int)send.x, 16);
+                recv.y = (unsigned)__shfl_xor((int)send.y, 16);
+                const uint4 o4 = odd ? make_uint4(recv.x, recv.y, P[1].x, P[1].y) : make_uint4(P[0].x, P[0].y, recv.x, recv.y);
+                const int ptm = pt + (odd ? 1 : 0);
+                const int oy = oy0 + wave * 2 + (ptm >> 1), ox = ox0 + (ptm & 1) * 16 + col;
+                if (oy < Ho && ox < Wo)
+                    *(uint4*)(y + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
         }
     }
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
 bool stem_direct_applicable(const ConvP& p) {
     return p.prec == PREC_BF16 && p.kh == 6 && p.kw == 3 && p.sh == 2 && p.sw == 1 && p.ph == 2 && p.pw == 1 && p.Cin == 8 && p.in_cs == 8 &&
            p.in_co == 0 && p.act == ACT_SILU && p.res_mode == RES_NONE && !p.out_f32 && p.split == 0 && p.Cout % 16 == 0 && p.Cout >= 16 &&
-           p.Cout <= 64 && p.Kp >= 160 && p.out_cs % 4 == 0 && p.out_co % 4 == 0;
+           p.Cout <= 64 && p.Kp >= 160 && p.out_cs % 8 == 0 && p.out_co % 8 == 0;
 }
 
 int launch_stem_direct(const ConvP& p, hipStream_t s) {
