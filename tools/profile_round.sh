@@ -20,7 +20,7 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
 cd $GRAFT_REPO_ROOT
 python tools/prof_summary.py $OUT/trace/trace_results.db "VC_TUNE_CACHE=tune.txt rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline" > $OUT/kernel_stats.md
 python tools/pmc_traffic.py $OUT/fetch/fetch_results.db $OUT/write/write_results.db > $OUT/pmc_traffic.json
-python tools/pmc_summary.py $OUT/mfma/mfma_results.db conv_igemm > $OUT/pmc_mfma.txt 2>&1
+python tools/pmc_summary.py $OUT/mfma/mfma_results.db vc:: > $OUT/pmc_mfma.txt 2>&1
 python tools/gpu_busy.py $OUT/trace/trace_results.db > $OUT/gpu_busy.txt 2>&1
 python tools/track_gaps.py $OUT/trace/trace_results.db >> $OUT/gpu_busy.txt 2>&1
 unset VC_TUNE_CACHE

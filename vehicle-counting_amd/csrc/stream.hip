@@ -260,8 +260,10 @@ static void async_worker(vc_engine* e) {
             if (e->worker_quit) return;
             for (auto& j : e->jobs) if (!j->done) { job = j.get(); break; }
         }
+        g_tm.start();
         const int st = track_batch(e, job->pd, job->trackers.data(), job->num_classes, job->b, job->h, job->w, job->rows6.data(), job->cap,
                                    job->m.data(), job->ndet.data(), /*poll_next=*/false);
+        g_tm.report();
         {
             std::lock_guard<std::mutex> lk(e->jmu);
             job->status = st;
