@@ -388,7 +388,8 @@ static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
 }
 
 static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStream_t s) {
-    for (const Op& op : ops) {
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        const Op& op = ops[oi];
         switch (op.kind) {
             case Op::CONV: {
                 const double fl = 2.0 * op.conv.M * (double)op.conv.Cout * op.C;
@@ -397,10 +398,17 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
                 ConvP cp = op.conv;
                 static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
+                static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
+                const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
                 if (stem_direct_on && stem_direct_applicable(cp)) {          // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                     VC_TRY(launch_stem_direct(cp, s));
+                } else if (reid_stem_on && nx && nx->kind == Op::MAXPOOL && nx->a.ptr == cp.out && reid_stem_applicable(cp, nx->b.cs, nx->b.co)) {
+                    cp.cfg = 101;                                            // ReID stem: conv + ReLU + MaxPool in one kernel (reid_stem.hip)
+                    ProfScope ps(e, VC_PROF_CONV, fl, by, s);
+                    VC_TRY(launch_reid_stem_pool(cp, nx->b.ptr, s));
+                    ++oi;                                                    // the pool op is done
                 } else {
                     cp.cfg = tuned_cfg(e, cp, s);
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);

@@ -91,6 +91,8 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument 
 int conv_num_cfgs();
 bool stem_direct_applicable(const ConvP& p);                    // stem_direct.hip: YOLO 6x6/s2 stem in bf16
 int launch_stem_direct(const ConvP& p, hipStream_t s);
+bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
+int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s);
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
 double conv_flops(const ConvP& p);
 
