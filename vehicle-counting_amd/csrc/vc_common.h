@@ -83,7 +83,7 @@ struct ConvP {
     void* out2;
     int split, out2_cs, out2_co;
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
-    int ablate;          // diagnostics only (VC_CONV_ABLATE): 1 = skip the staging DMA after the first tile, 2 = skip the MFMAs
+    int ablate;          // diagnostics only (VC_CONV_ABLATE): 6 = return at once (launch floor of the grid); per-phase times come from dbg
 };
 
 int launch_conv(const ConvP& p, hipStream_t s);
