@@ -248,9 +248,6 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
     const int col = lane & 15, kq = lane >> 4;
     const int S = jb.gal_count, D = jb.det_n;
     const double* m = tp.mean + (size_t)jb.slot * 8;
-    double Sg[16], L[16];
-    project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
-    chol4(Sg, L);
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
         // the chunk's descriptors -> LDS (one round trip to pinned memory for all 16 detections)
@@ -293,6 +290,9 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
         if (wave == 0 && lane < 16 && d0 + lane < D) {
             const float bmax = fmaxf(fmaxf(sh.smax[0][lane], sh.smax[1][lane]), fmaxf(sh.smax[2][lane], sh.smax[3][lane]));
             const float cosv = bmax * (1.0f / sqrtf(ss));
+            double Sg[16], L[16];                          // gate: only these 16 lanes need the 4x4 Cholesky factor (fp64, ~100 dependent ops)
+            project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
+            chol4(Sg, L);
             const double g2 = maha4(m, L, sh.xyah[lane]);
             host_store(out + jb.out_off + d0 + lane, g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv));
         }
