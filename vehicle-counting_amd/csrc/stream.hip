@@ -172,9 +172,30 @@ static int track_batch(vc_engine* e, vc_engine::Pending& pd, const int* trackers
         out_m[f] = 0;
     }
     g_tm.lap(1);
-    // Tracker pipeline: the operations of frame f and the cost jobs of the next non-empty frame are one launch.
-    StepCtx ctx[2];
-    int cur = 0, prev_f = -1;
+    // Tracker pipeline: the operations of frame f and the cost jobs of the next non-empty frame are one launch; the host
+    // preparation of the next frame (class grouping, confidence filter, DeepSORT NMS: independent of tracker state) runs while
+    // the launch is in flight.
+    struct FramePlan { int f; std::vector<int> ids, labs; std::vector<std::vector<int>> groups; };
+    std::vector<FramePlan> plan;
+    {
+        std::vector<std::vector<int>> by_class(num_classes);
+        for (int f = 0; f < b; ++f) {
+            FrameDets& d = fd[f];
+            if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
+            FramePlan pl;
+            pl.f = f;
+            for (size_t i = 0; i < d.label.size(); ++i)                              // modules/track.py:50-59, one pass
+                if (d.label[i] >= 0 && d.label[i] < num_classes) by_class[d.label[i]].push_back((int)i);
+            for (int c = 0; c < num_classes; ++c) {
+                if (by_class[c].empty()) continue;
+                pl.ids.push_back(trackers[c]); pl.labs.push_back(c); pl.groups.push_back(std::move(by_class[c]));
+                by_class[c].clear();
+            }
+            if (!pl.ids.empty()) plan.push_back(std::move(pl));
+        }
+    }
+    StepCtx ctx[3];
+    int prev_f = -1;
     auto flush_prev = [&](int which) -> int {             // rows of the previously stepped frame (its means have landed)
         if (prev_f < 0) return VC_OK;
         std::vector<int64_t> rows6;
@@ -186,42 +207,36 @@ static int track_batch(vc_engine* e, vc_engine::Pending& pd, const int* trackers
         prev_f = -1;
         return VC_OK;
     };
+    auto build = [&](size_t j) {
+        const FramePlan& pl = plan[j];
+        FrameDets& d = fd[pl.f];
+        build_ctx(e, ctx[j % 3], h, w, pl.ids, pl.labs, pl.groups, d.xyxy.data(), d.conf.data(), pd.row0[pl.f]);
+    };
     g_tm.lap(2);
-    std::vector<std::vector<int>> by_class(num_classes);
-    for (int f = 0; f < b; ++f) {
-        FrameDets& d = fd[f];
-        if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
-        std::vector<int> ids, labs;
-        std::vector<std::vector<int>> groups;
-        for (size_t i = 0; i < d.label.size(); ++i)                              // modules/track.py:50-59, one pass
-            if (d.label[i] >= 0 && d.label[i] < num_classes) by_class[d.label[i]].push_back((int)i);
-        for (int c = 0; c < num_classes; ++c) {
-            if (by_class[c].empty()) continue;
-            ids.push_back(trackers[c]); labs.push_back(c); groups.push_back(std::move(by_class[c]));
-            by_class[c].clear();
-        }
-        if (ids.empty()) continue;
-        build_ctx(e, ctx[cur], h, w, ids, labs, groups, d.xyxy.data(), d.conf.data(), pd.row0[f]);
+    if (!plan.empty()) build(0);
+    for (size_t j = 0; j < plan.size(); ++j) {
+        const int cur = (int)(j % 3), prv = (int)((j + 2) % 3);
         g_tm.lap(3);
         VC_TRY(track_prepare_a(e, ctx[cur]));
         // one launch: the pending operations of the previous frame + the cost jobs of this one
-        VC_TRY(track_launch(e, prev_f >= 0 ? &ctx[cur ^ 1] : nullptr, d_feat, &ctx[cur], d_feat));
+        VC_TRY(track_launch(e, prev_f >= 0 ? &ctx[prv] : nullptr, d_feat, &ctx[cur], d_feat));
         g_tm.lap(4);
+        if (j + 1 < plan.size()) build(j + 1);            // overlapped with the launch in flight
         if (poll_next) VC_TRY(try_issue_next(e));
         VC_TRY(track_wait(e));                            // cost rows of f are here; so are the means of the previous frame
         g_tm.lap(5);
-        VC_TRY(flush_prev(cur ^ 1));
+        VC_TRY(flush_prev(prv));
         g_tm.lap(6);
         VC_TRY(track_host_b(e, ctx[cur]));
         g_tm.lap(7);
-        prev_f = f;
-        cur ^= 1;
+        prev_f = plan[j].f;
     }
     if (prev_f >= 0) {
-        VC_TRY(track_launch(e, &ctx[cur ^ 1], d_feat, nullptr, nullptr));
+        const int last = (int)((plan.size() - 1) % 3);
+        VC_TRY(track_launch(e, &ctx[last], d_feat, nullptr, nullptr));
         VC_TRY(track_wait(e));
         g_tm.lap(5);
-        VC_TRY(flush_prev(cur ^ 1));
+        VC_TRY(flush_prev(last));
         g_tm.lap(6);
     }
     return VC_OK;
