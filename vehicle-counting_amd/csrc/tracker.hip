@@ -29,9 +29,13 @@ enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
 // (D. F. Crouse, "On implementing 2D rectangular assignment algorithms", 2016): returns pairs sorted by row.
 static int lsap_core(int nr, int nc, const double* cost, std::vector<int>& col4row) {
     const double INF = std::numeric_limits<double>::infinity();
-    std::vector<double> u(nr, 0.0), v(nc, 0.0), spc(nc);
-    std::vector<int> path(nc, -1), row4col(nc, -1), remaining(nc);
-    std::vector<char> SR(nr), SC(nc);
+    // scratch reused across calls (a frame makes 10-20 small assignments; the heap traffic was a third of the host step)
+    static thread_local std::vector<double> u, v, spc;
+    static thread_local std::vector<int> path, row4col, remaining;
+    static thread_local std::vector<char> SR, SC;
+    u.assign(nr, 0.0); v.assign(nc, 0.0); spc.resize(nc);
+    path.assign(nc, -1); row4col.assign(nc, -1); remaining.resize(nc);
+    SR.resize(nr); SC.resize(nc);
     col4row.assign(nr, -1);
     for (int cur = 0; cur < nr; ++cur) {
         double minVal = 0;
@@ -74,9 +78,10 @@ static int lsap_core(int nr, int nc, const double* cost, std::vector<int>& col4r
 int lap_solve(const double* cost, int nr, int nc, std::vector<int>& rows, std::vector<int>& cols) {
     rows.clear(); cols.clear();
     if (nr == 0 || nc == 0) return VC_OK;
-    std::vector<int> c4r;
+    static thread_local std::vector<int> c4r;
+    static thread_local std::vector<double> t;
     if (nc < nr) {                       // SciPy transposes so that rows <= cols
-        std::vector<double> t((size_t)nr * nc);
+        t.resize((size_t)nr * nc);
         for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) t[(size_t)j * nr + i] = cost[(size_t)i * nc + j];
         VC_CHECK(lsap_core(nc, nr, t.data(), c4r) == 0, VC_ERR_ARG, "lap: infeasible cost matrix");
         std::vector<int> order(nc);
@@ -97,15 +102,17 @@ static int min_cost_matching(const std::vector<const double*>& row_ptr, const st
     out.matches.clear(); out.un_rows.clear(); out.un_cols.clear();
     const int nr = (int)rows.size(), nc = (int)cols.size();
     if (nr == 0 || nc == 0) { out.un_rows = rows; out.un_cols = cols; return VC_OK; }
-    std::vector<double> c((size_t)nr * nc);
+    static thread_local std::vector<double> c;
+    static thread_local std::vector<int> ri, ci;
+    static thread_local std::vector<char> col_used, row_used;
+    c.resize((size_t)nr * nc);
     for (int i = 0; i < nr; ++i)
         for (int j = 0; j < nc; ++j) {
             const double v = row_ptr[i][cols[j]];
             c[(size_t)i * nc + j] = v > max_cost ? max_cost + 1e-5 : v;
         }
-    std::vector<int> ri, ci;
     VC_TRY(lap_solve(c.data(), nr, nc, ri, ci));
-    std::vector<char> col_used(nc, 0), row_used(nr, 0);
+    col_used.assign(nc, 0); row_used.assign(nr, 0);
     for (size_t k = 0; k < ri.size(); ++k) { row_used[ri[k]] = 1; col_used[ci[k]] = 1; }
     for (int j = 0; j < nc; ++j) if (!col_used[j]) out.un_cols.push_back(cols[j]);
     for (int i = 0; i < nr; ++i) if (!row_used[i]) out.un_rows.push_back(rows[i]);
@@ -349,32 +356,38 @@ int track_host_b(vc_engine* e, StepCtx& c) {
         const Prepared& pr = c.prep[j];
         const int k = (int)pr.conf.size();
         const int nt = (int)tk.tracks.size();
-        std::vector<int> confirmed, unconfirmed;
+        // scratch reused across trackers and frames (no heap traffic in the per-frame step)
+        static thread_local std::vector<int> confirmed, unconfirmed, left, lvl, un_a, cand, un_tracks;
+        static thread_local std::vector<std::pair<int, int>> matches;
+        static thread_local std::vector<char> matched_track;
+        static thread_local std::vector<const double*> rp;
+        static thread_local MatchOut mo;
+        confirmed.clear(); unconfirmed.clear(); matches.clear();
         for (int t = 0; t < nt; ++t) (tk.tracks[t].state == CONFIRMED ? confirmed : unconfirmed).push_back(t);
-        std::vector<std::pair<int, int>> matches;
-        std::vector<int> left(k);
+        left.resize(k);
         std::iota(left.begin(), left.end(), 0);
-        MatchOut mo;
         // matching_cascade, sort/linear_assignment.py:124-145
-        std::vector<char> matched_track(nt, 0);
-        for (int level = 0; level < tk.p.max_age; ++level) {
+        matched_track.assign(nt, 0);
+        int max_tsu = 0;
+        for (int t : confirmed) max_tsu = std::max(max_tsu, tk.tracks[t].tsu);
+        for (int level = 0; level < tk.p.max_age && level < max_tsu; ++level) {      // levels above the oldest track are empty
             if (left.empty()) break;
-            std::vector<int> lvl;
+            lvl.clear();
             for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
             if (lvl.empty()) continue;
-            std::vector<const double*> rp;
+            rp.clear();
             for (int t : lvl) rp.push_back(e->h_cost + c.app_job[j][t]);
             VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
             for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
             left = mo.un_cols;
         }
-        std::vector<int> un_a;                                   // set(confirmed) - matched, ascending ("set order")
+        un_a.clear();                                            // set(confirmed) - matched, ascending ("set order")
         for (int t : confirmed) if (!matched_track[t]) un_a.push_back(t);
         // IoU stage, sort/tracker.py:118-127
-        std::vector<int> cand = unconfirmed, un_tracks;
+        cand = unconfirmed; un_tracks.clear();
         for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
         {
-            std::vector<const double*> rp;
+            rp.clear();
             if (k > 0) for (int t : cand) rp.push_back(e->h_cost + c.iou_job[j][t]);
             else rp.assign(cand.size(), nullptr);
             VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
