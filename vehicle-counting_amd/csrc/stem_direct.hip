@@ -132,7 +132,7 @@ bool stem_direct_applicable(const ConvP& p) {
 int launch_stem_direct(const ConvP& p, hipStream_t s) {
     const int tiles_x = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_y = (p.Ho + STEM_TH - 1) / STEM_TH;
     const int ntiles = p.B * tiles_x * tiles_y;
-    const int grid = std::min(ntiles, 256 * 3);      // 3 workgroups per CU are resident (VGPRs); each walks ~ntiles/768 tiles
+    const int grid = std::min(ntiles, 256 * 3 - 64); // 3 workgroups per CU can be resident (VGPRs); 64 slots stay free for the tracker stream (conv_igemm.hip)
     const uint4* x = (const uint4*)p.in; const uint4* w = (const uint4*)p.w;
     uint16_t* y = (uint16_t*)p.out;
     const int kw8 = p.Kp / 8;
