@@ -184,7 +184,7 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes per conv launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
-                         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / stem_direct_kernel<*> (all YOLOv5s + ReID conv launches of a step)",
+                         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
                          "launches_per_step": conv["launches"] / 2, "avg_launch_us": conv["ms"] * 1e3 / max(conv["launches"], 1),
                          "algorithmic_gflop_per_step": conv["flops"] / 2 / 1e9},
             "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},
