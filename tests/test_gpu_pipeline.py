@@ -50,3 +50,48 @@ def test_csv_parity(golden_dir, tmp_path):
         assert counts == ref_counts, mode
         assert os.path.exists(os.path.join(str(tmp_path), "cam_04.csv"))
         eng.close()
+
+
+def test_async_stream_same_rows_and_errors():
+    """vc_stream_run_async / vc_stream_collect on the bf16 engine: the worker-thread tracker loop returns exactly the rows of the
+    synchronous call (same engine, trackers reset in between), in order, one batch late; misuse is reported, not hung."""
+    import torch
+    from vehicle_counting_amd._lib import VcError
+    B, H, W, NB = 8, 360, 640, 4
+    frames = synth_frames(B * NB, H, W, n_obj=8, seed=11)
+    ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+    eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W), max_crops=B * 64, max_tracks=2048, nn_budget_cap=60)
+    trk = [eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
+           for _ in range(NC)]
+    dev = torch.from_numpy(frames).cuda()
+    ptr = lambda i: dev[i * B:(i + 1) * B].data_ptr()
+    sync_rows = []
+    eng.stream_submit(ptr(0), B, H, W)
+    for i in range(NB):
+        if i + 1 < NB:
+            eng.stream_submit(ptr(i + 1), B, H, W)
+        rows, fidx, nd = eng.stream_run_packed(trk, ptr(i), B, H, W)
+        sync_rows.append((rows, fidx, nd))
+    assert sum(len(r[0]) for r in sync_rows) > 20
+    for t in trk:
+        eng.tracker_reset(t)
+    with pytest.raises(VcError):
+        eng._async_shapes = [(B, 512)]
+        eng.stream_collect()                                  # nothing outstanding
+    eng._async_shapes = []
+    got = []
+    eng.stream_submit(ptr(0), B, H, W)
+    for i in range(NB):
+        if i + 1 < NB:
+            eng.stream_submit(ptr(i + 1), B, H, W)
+        eng.stream_run_async(trk, ptr(i), B, H, W)
+        if i > 0:
+            got.append(eng.stream_collect())
+    with pytest.raises(VcError):
+        eng.stream_run_packed(trk, ptr(0), B, H, W)           # synchronous call while a batch is outstanding
+    got.append(eng.stream_collect())
+    for (r0, f0, n0), (r1, f1, n1) in zip(sync_rows, got):
+        np.testing.assert_array_equal(n0, n1)
+        np.testing.assert_array_equal(f0, f1)
+        np.testing.assert_array_equal(r0, r1)
+    eng.close()
