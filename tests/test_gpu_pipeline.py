@@ -33,13 +33,17 @@ def test_csv_parity(golden_dir, tmp_path):
     cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
     args = types.SimpleNamespace(weight=None, mapping=None, output_path=str(tmp_path))
     cam_cfg = {"cam": {"cam_04": {"tracking_config": TRACK_CFG}}}
-    for mode in ("loop", "stream", "stream_async"):
+    for mode in ("loop", "stream", "stream_async", "frame_sharded"):
         eng = E.Engine(ysd, rsd, precision="f32", num_classes=NC, max_batch=8, max_frame_hw=(H, W), max_crops=512,
                        max_tracks=1024, nn_budget_cap=60)
         pipe = CountingPipeline(args, cfg, cam_cfg, engine=eng, class_names=[f"c{i}" for i in range(NC)])
         src = FrameSource(frames)
-        rows, counts = (pipe.run(src, "cam_04", zone) if mode == "loop" else
-                        pipe.run_stream(src, "cam_04", zone, batch=4 if mode == "stream_async" else 8, asynchronous=mode == "stream_async"))
+        if mode == "loop":
+            rows, counts = pipe.run(src, "cam_04", zone)
+        elif mode == "frame_sharded":                    # SURVEY.md 8f.1 driver on one rank: detect + embed + external-feature tracker
+            rows, counts = pipe.run_frame_sharded(src, "cam_04", zone, chunk=4)
+        else:
+            rows, counts = pipe.run_stream(src, "cam_04", zone, batch=4 if mode == "stream_async" else 8, asynchronous=mode == "stream_async")
         # track_id / label / frame / direction / first-last frame exact; boxes within 1 px (int truncation of an fp64 state
         # that only depends on fp32-identical detections); fpoint/lpoint within 0.5
         assert key(rows) == key(ref_rows), mode

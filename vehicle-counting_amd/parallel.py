@@ -1,6 +1,10 @@
 """Multi-GPU: camera streams shard across ranks (one process per GPU), the only exchange is one all-gather of the
 per-camera count tensors int32[n_dir, n_cls] over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).
-The reference has no distributed code at all: this is the new merge step of SURVEY.md 8(e)."""
+The reference has no distributed code at all: this is the new merge step of SURVEY.md 8(e).
+
+SURVEY.md 8(f).1, a single stream on several GPUs: the stateless front end (detect + NMS + ReID) shards by frame chunk
+(`shard_frames`), the per-detection payloads (box, confidence, class, 512-d feature) are gathered in frame order
+(`gather_rows`) and the rank that owns the camera runs the sequential tracker on them."""
 from __future__ import annotations
 
 import os
@@ -48,3 +52,40 @@ def allgather_counts(local_counts, device=None):
 def shard_streams(n_streams, rank, world):
     """Stream i is owned by rank i % world (whole streams only: tracker state never shards below a camera)."""
     return [i for i in range(n_streams) if i % world == rank]
+
+
+def shard_frames(n_frames, rank, world, chunk):
+    """Chunk j = frames [j*chunk, (j+1)*chunk) belongs to rank j % world.  Returns the (start, stop) chunks of `rank`, in order;
+    round r of every rank covers the consecutive chunks r*world .. r*world + world - 1."""
+    out = []
+    for j, s in enumerate(range(0, n_frames, chunk)):
+        if j % world == rank:
+            out.append((s, min(s + chunk, n_frames)))
+    return out
+
+
+def gather_rows(local_rows, device=None):
+    """local_rows: float64 (n, C) whose column 0 is a frame index.  Every rank receives the rows of all ranks ordered by frame
+    index (rows of one frame keep their rank-local order; a frame lives on exactly one rank).  Two collectives: the row counts,
+    then the rows padded to the largest count (RCCL all_gather wants equal shapes)."""
+    rows = np.ascontiguousarray(local_rows, dtype=np.float64)
+    if rows.ndim != 2:
+        raise ValueError("gather_rows expects a 2-D array")
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows[np.argsort(rows[:, 0], kind="stable")] if len(rows) else rows
+    world = dist.get_world_size()
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64)
+    if device is not None:
+        n = n.to(device)
+    counts = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    pad = torch.zeros((cap, rows.shape[1]), dtype=torch.float64)
+    pad[: rows.shape[0]] = torch.from_numpy(rows)
+    if device is not None:
+        pad = pad.to(device)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    allr = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], 0)
+    return allr[np.argsort(allr[:, 0], kind="stable")] if len(allr) else allr

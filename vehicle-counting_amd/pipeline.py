@@ -4,9 +4,11 @@ Video decode/encode (cv2.VideoCapture / VideoWriter, modules/datasets.py) is out
 `FrameSource` over an in-memory BGR array (or any iterable of such batches) that honours the reference's input contract
 -- RGB frame for the detector, BGR original for the tracker, 1-based frame ids (modules/datasets.py:47-76).
 
-Two drivers with identical results:
-  run()         the reference's loop, one frame at a time through ImageDetect.run / VideoTracker.run (host frames);
-  run_stream()  frames resident in HBM, B frames per `vc_stream_run` call (detect batched, trackers stepped in order).
+Drivers with identical results:
+  run()                the reference's loop, one frame at a time through ImageDetect.run / VideoTracker.run (host frames);
+  run_stream()         frames resident in HBM, B frames per `vc_stream_run` call (detect batched, trackers stepped in order);
+  run_frame_sharded()  ONE stream on several GPUs: detect + ReID shard by frame chunk over the ranks, the
+                       per-detection payloads are gathered in frame order, rank 0 runs the sequential tracker.
 """
 from __future__ import annotations
 
@@ -108,4 +110,53 @@ class CountingPipeline:
                 record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)[:2])
         if asynchronous and starts:
             record(starts[-1], *self.engine.stream_collect()[:2])
+        return self._finish(counter, obj, cam_name)
+
+    def run_frame_sharded(self, source, cam_name, zone_path, chunk=8, device=None):
+        """One camera stream, the stateless front end sharded by frame chunk over the ranks of torch.distributed (chunk j on rank
+        j % world), one ordered gather of [frame, x1, y1, x2, y2, conf, label, feature(512)] rows per round, the tracker and the
+        counting on rank 0 (tracker state never shards below a camera).  Returns (rows, counts) on rank 0, (None, None) elsewhere.
+        The detections are marshalled exactly as in run(): ImageDetect.run -> xywh -> xyxy (modules/track.py:39-41)."""
+        import torch.distributed as dist
+
+        from . import parallel
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        frames = source.frames
+        t, h, w, _ = frames.shape
+        mine = parallel.shard_frames(t, rank, world, chunk)
+        n_rounds = (len(range(0, t, chunk)) + world - 1) // world
+        tracker, counter = self._stages(cam_name, source.video_info, zone_path) if rank == 0 else (None, None)
+        obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
+        for r in range(n_rounds):
+            local = []
+            if r < len(mine):
+                for f in range(*mine[r]):
+                    bgr = frames[f]
+                    preds = self.detector.run({"imgs": [bgr[:, :, ::-1]], "ori_imgs": [bgr], "frames": [f + 1]})
+                    boxes, labels, scores = preds["boxes"][0], preds["labels"][0], preds["scores"][0]
+                    if len(boxes) == 0:                                              # modules/__init__.py:68-69 (Q1)
+                        continue
+                    xyxy = np.asarray(boxes, np.float64).copy()
+                    xyxy[:, 2] += xyxy[:, 0]; xyxy[:, 3] += xyxy[:, 1]               # modules/track.py:39-41
+                    bw, bh = xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]        # deep_sort.py:78-87
+                    cxcywh = np.stack([xyxy[:, 0] + bw / 2, xyxy[:, 1] + bh / 2, bw, bh], 1)
+                    feat = self.engine.embed(bgr, cxcywh)
+                    local.append(np.concatenate([np.full((len(xyxy), 1), f + 1, np.float64), xyxy, np.asarray(scores, np.float64)[:, None],
+                                                 np.asarray(labels, np.float64)[:, None], feat.astype(np.float64)], 1))
+            rows = parallel.gather_rows(np.concatenate(local, 0) if local else np.zeros((0, 7 + 512)), device=device)
+            if rank != 0:
+                continue
+            for fid in np.unique(rows[:, 0]) if len(rows) else []:                   # ascending frame ids
+                fr = rows[rows[:, 0] == fid]
+                lab = fr[:, 6].astype(np.int64)
+                for c in range(len(self.class_names)):                               # modules/track.py:50-59
+                    sel = fr[lab == c]
+                    if len(sel) == 0:
+                        continue
+                    out = tracker.deepsort[c].update_with_features(sel[:, 1:5], sel[:, 5], sel[:, 7:].astype(np.float32), h, w)
+                    for row in out:
+                        obj["frames"].append(int(fid)); obj["tracks"].append(int(row[4])); obj["labels"].append(c); obj["boxes"].append(row[:4].copy())
+        if rank != 0:
+            return None, None
         return self._finish(counter, obj, cam_name)

@@ -15,12 +15,40 @@ class DeepSort:
         if engine is None:
             raise ValueError("DeepSort needs the HIP engine (there is no CPU path)")
         self.engine = engine
+        self.min_confidence, self.nms_max_overlap = min_confidence, nms_max_overlap
         self.tracker_id = engine.tracker_create(max_dist=max_dist, min_confidence=min_confidence, nms_max_overlap=nms_max_overlap,
                                                 max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, nn_budget=nn_budget)
 
     def update(self, bbox_xyxy, confidences, ori_img):
         rows = self.engine.deepsort_update(self.tracker_id, bbox_xyxy, confidences, ori_img)
         return rows if len(rows) > 0 else []          # deep_sort.py:57-59
+
+    def update_with_features(self, bbox_xyxy, confidences, features, height, width):
+        """DeepSort.update with the embeddings supplied by the caller (frame-sharded front end, SURVEY.md 8f.1: another rank
+        ran the detector and the ReID net).  Same steps as deep_sort.py:25-59 minus `_get_features`: confidence filter (:31),
+        tlwh (:68-87), DeepSORT NMS in pick order (:37-41), tracker predict/update (:44-45), rows of the confirmed tracks seen
+        within one frame as clamped ints (:47-56, 97-108)."""
+        from . import engine as E
+        b = np.asarray(bbox_xyxy, np.float64).reshape(-1, 4)
+        c = np.asarray(confidences, np.float64).reshape(-1)
+        f = np.asarray(features, np.float32).reshape(-1, 512)
+        keep = c > self.min_confidence
+        b, c, f = b[keep], c[keep], f[keep]
+        w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+        cx, cy = b[:, 0] + w / 2, b[:, 1] + h / 2
+        tlwh = np.stack([cx - w / 2., cy - h / 2., w, h], 1) if len(b) else np.zeros((0, 4))
+        pick = E.dsort_nms(tlwh, c, self.nms_max_overlap) if len(b) else []
+        self.engine.tracker_step(self.tracker_id, tlwh[pick], c[pick], f[pick])
+        st = self.engine.tracker_state(self.tracker_id, with_cov=False)
+        rows = []
+        for i in range(len(st["ids"])):
+            if st["state"][i] != 2 or st["tsu"][i] > 1:          # confirmed, time_since_update <= 1
+                continue
+            m = st["mean"][i]
+            tw, th = m[2] * m[3], m[3]
+            x, y = m[0] - tw / 2, m[1] - th / 2
+            rows.append([max(int(x), 0), max(int(y), 0), min(int(x + tw), width - 1), min(int(y + th), height - 1), int(st["ids"][i])])
+        return np.asarray(rows, np.int64).reshape(-1, 5)
 
 
 class VideoTracker:
