@@ -116,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
                     const u32x4 o4 = odd ? (u32x4){recv.x, recv.y, P[1].x, P[1].y} : (u32x4){P[0].x, P[0].y, recv.x, recv.y};
                     const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
                     const int nn = odd ? n - 4 : n;
-                    if (grp_ok && m < p.M) {
+                    if (grp_ok && m < p.M && !((p.ablate == 2 || p.ablate == 3) && o4.x != 0x7fc07fc0u)) {     // ablate 2: no stores (timing experiment)
                         const bool second = p.split > 0 && nn >= p.split;
                         if (second) __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (m * p.out2_cs + p.out2_co + nn - p.split) * 2, 0, 0);
                         else __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (m * p.out_cs + p.out_co + nn) * 2, 0, 0);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     unsigned long long xmask[XI];
     int kc_c = 0, kc_t = 0, kc_s = 0, u_tap = 0, u_s = 0, u_c = 0;
     uint32_t kc_off = 0, u_tapoff = 0;
-    int s_v = blockIdx.x, s_kt = 0;
+    int s_v = blockIdx.x, s_kt = 0, s_issued = 0;
 #define VC_TILE_STATE(v)                                                                                                  \
     if ((v) < ntiles) {                                                                                                   \
         const int tile_ = VC_TILE_OF(v);                                                                                  \
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     // stage K tile s_kt of the staged tile into ring slot `buf`, then advance (to the next tile of this workgroup at the end)
 #define VC_STAGE_NEXT(buf)                                                                                               \
-    if (ut) {                                                                                                            \
+    if ((p.ablate == 1 || p.ablate == 3) && s_issued >= NS) {                                                                               \
+    } else if (ut) {                                                                                                            \
         const uint32_t so = u_tapoff + (uint32_t)(u_c * ES);                                                             \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                 \
             const uint32_t o = ((xmask[i] >> u_tap) & 1ull) ? xoffl[i] + so : OOB;                                       \
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
         }                                                                                                                \
         kc_c = cc;                                                                                                       \
     }                                                                                                                    \
+    ++s_issued;                                                                                                          \
     if (++s_kt == nk) {                                                                                                  \
         s_kt = 0;                                                                                                        \
         s_v += G;                                                                                                        \

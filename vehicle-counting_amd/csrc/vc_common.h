@@ -83,7 +83,8 @@ struct ConvP {
     void* out2;
     int split, out2_cs, out2_co;
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
-    int ablate;          // diagnostics only (VC_CONV_ABLATE): 6 = return at once (launch floor of the grid); per-phase times come from dbg
+    int ablate;          // diagnostics only (VC_CONV_ABLATE, timing experiments with wrong results): 1 = no staging DMA after the first tiles,
+                         // 2 = no output stores, 3 = both, 6 = return at once (launch floor of the grid); per-phase times come from dbg
 };
 
 int launch_conv(const ConvP& p, hipStream_t s);
