@@ -157,7 +157,8 @@ int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int*
 #define VC_PROF_REID_AUX 2   /* crop/resize, pools, L2 norm */
 #define VC_PROF_TRACK 3      /* Kalman, cost matrices */
 #define VC_PROF_NCAT 4
-int vc_profile_enable(vc_engine* e, int on);   /* brackets every launch with hipEvents on its own stream; disables graphs */
+int vc_profile_enable(vc_engine* e, int on);   /* 0 off; 1 blocking events around every launch (serialises the streams);
+                                                  2 in-flight event pairs around conv launches only, resolved by vc_profile_read */   /* brackets every launch with hipEvents on its own stream; disables graphs */
 int vc_profile_read(vc_engine* e, int category, double* total_ms, int64_t* launches, double* flops, double* bytes);
 int vc_profile_reset(vc_engine* e);
 int vc_profile_ops(vc_engine* e, char* buf, size_t cap);   /* per-conv-launch lines "conv M= N= K= ... ms= tflops=" recorded while profiling */

@@ -664,12 +664,12 @@ static int launch_one(ConvP p, hipStream_t s) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>), dim3(grid), dim3(256), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, dim3(grid), dim3(256), dyn_lds, s, p);
     } else {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>), dim3(grid), dim3(256), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, dim3(grid), dim3(256), dyn_lds, s, p);
     }
     VC_HIP(hipGetLastError());
     return VC_OK;
@@ -701,9 +701,9 @@ static int launch_halo(ConvP p, hipStream_t s) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     p.Kw = p.Kp;
     const int px = halo_patch_pixels(p, BP);
-    if (px <= 4 * 64 - 1) hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 4>), dim3(tiles), dim3(256), 0, s, p);
-    else if (px <= 7 * 64 - 1) hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 7>), dim3(tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<BP, BC, WP, WC, NS, 11>), dim3(tiles), dim3(256), 0, s, p);
+    if (px <= 4 * 64 - 1) launch_timed(p, conv3x3_halo_kernel<BP, BC, WP, WC, NS, 4>, dim3(tiles), dim3(256), 0, s, p);
+    else if (px <= 7 * 64 - 1) launch_timed(p, conv3x3_halo_kernel<BP, BC, WP, WC, NS, 7>, dim3(tiles), dim3(256), 0, s, p);
+    else launch_timed(p, conv3x3_halo_kernel<BP, BC, WP, WC, NS, 11>, dim3(tiles), dim3(256), 0, s, p);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

@@ -163,6 +163,12 @@ struct vc_engine {
 
     // ---- measurement ----------------------------------------------------------------------------------
     bool profiling = false;
+    // in-flight conv profiling (vc_profile_enable(e, 2)): event pairs recorded on the launch stream WITHOUT synchronising, so the
+    // timed steps keep their three overlapping streams; resolved by vc_profile_read.  Only the thread that issues convs uses it.
+    bool prof_async = false;
+    struct ProfPair { hipEvent_t a, b; double flops, bytes; };
+    std::vector<ProfPair> prof_pairs;
+    size_t prof_used = 0;
     vc::ProfCat prof[VC_PROF_NCAT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, int> tuned;            // conv autotune cache: shape signature -> tile config (engine.hip::tune_key)

@@ -387,6 +387,15 @@ static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
     return best;
 }
 
+// in-flight profiling of one conv launch (see vc_engine::prof_async): the launch itself reports its start / stop timestamps
+// into an event pair (hipExtLaunchKernel), no host wait
+static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes) {
+    if (!e->prof_async || e->profiling || e->prof_used >= e->prof_pairs.size()) return;
+    vc_engine::ProfPair& pp = e->prof_pairs[e->prof_used++];
+    pp.flops = flops; pp.bytes = bytes;
+    cp.ev_start = pp.a; cp.ev_stop = pp.b;
+}
+
 static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStream_t s) {
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         const Op& op = ops[oi];
@@ -400,6 +409,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
                 const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
+                conv_timer_arm(e, cp, fl, by);
                 if (stem_direct_on && stem_direct_applicable(cp)) {          // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
@@ -678,6 +688,7 @@ int vc_engine_destroy(vc_engine* e) {
     if (e->rstream) hipStreamSynchronize(e->rstream);
     for (void* p : e->allocs) hipFree(p);
     for (void* p : e->host_allocs) hipHostFree(p);
+    for (auto& pp : e->prof_pairs) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -905,7 +916,17 @@ int vc_embed_tensor(vc_engine* e, const float* x, int k, float* out_feat) {
 }
 
 // ---- measurement ---------------------------------------------------------------------------------------
-int vc_profile_enable(vc_engine* e, int on) { VC_CHECK(e, VC_ERR_ARG, "null engine"); e->profiling = on != 0; return VC_OK; }
+int vc_profile_enable(vc_engine* e, int on) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    e->profiling = on == 1;                 // 1: blocking per-launch events for every category (serialises the streams)
+    e->prof_async = on == 2;                // 2: in-flight event pairs around conv launches only, resolved by vc_profile_read
+    if (on == 2 && e->prof_pairs.empty()) {
+        e->prof_pairs.resize(16384);
+        for (auto& pp : e->prof_pairs) { VC_HIP(hipEventCreate(&pp.a)); VC_HIP(hipEventCreate(&pp.b)); }
+    }
+    if (on == 2) e->prof_used = 0;
+    return VC_OK;
+}
 int vc_profile_reset(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     for (auto& c : e->prof) c = ProfCat{};
@@ -919,6 +940,16 @@ int vc_profile_ops(vc_engine* e, char* buf, size_t cap) {
 }
 int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double* flops, double* bytes) {
     VC_CHECK(e && cat >= 0 && cat < VC_PROF_NCAT, VC_ERR_ARG, "bad category");
+    if (cat == VC_PROF_CONV && e->prof_used > 0) {          // resolve the in-flight pairs into the conv category
+        VC_HIP(hipStreamSynchronize(e->dstream)); VC_HIP(hipStreamSynchronize(e->rstream)); VC_HIP(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < e->prof_used; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, e->prof_pairs[i].a, e->prof_pairs[i].b) != hipSuccess) continue;
+            ProfCat& c = e->prof[VC_PROF_CONV];
+            c.ms += t; c.flops += e->prof_pairs[i].flops; c.bytes += e->prof_pairs[i].bytes; c.launches += 1;
+        }
+        e->prof_used = 0;
+    }
     if (ms) *ms = e->prof[cat].ms;
     if (launches) *launches = e->prof[cat].launches;
     if (flops) *flops = e->prof[cat].flops;

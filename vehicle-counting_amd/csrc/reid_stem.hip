@@ -139,7 +139,7 @@ int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s) {
     const int k = p.B;
     if (k <= 0) return VC_OK;
     const int grid = std::min(k * RS_BANDS, 256 * 3 - 64);      // 3 workgroups per CU can be resident; 64 slots stay free for the tracker stream
-    hipLaunchKernelGGL(reid_stem_pool_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)p.in, (const uint4*)p.w, p.bias, (uint32_t*)pooled, k, p.Kp / 8);
+    launch_timed(p, reid_stem_pool_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)p.in, (const uint4*)p.w, p.bias, (uint32_t*)pooled, k, p.Kp / 8);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

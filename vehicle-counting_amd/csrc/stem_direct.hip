@@ -137,10 +137,10 @@ int launch_stem_direct(const ConvP& p, hipStream_t s) {
     uint16_t* y = (uint16_t*)p.out;
     const int kw8 = p.Kp / 8;
     switch (p.Cout / 16) {
-        case 1: hipLaunchKernelGGL(stem_direct_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        case 2: hipLaunchKernelGGL(stem_direct_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        case 3: hipLaunchKernelGGL(stem_direct_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        default: hipLaunchKernelGGL(stem_direct_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 1: launch_timed(p, stem_direct_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 2: launch_timed(p, stem_direct_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 3: launch_timed(p, stem_direct_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        default: launch_timed(p, stem_direct_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
     }
     VC_HIP(hipGetLastError());
     return VC_OK;

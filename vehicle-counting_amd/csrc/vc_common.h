@@ -1,6 +1,7 @@
 // Shared declarations for libvcount_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +78,7 @@ struct ConvP {
     int act, res_mode, out_f32, prec;
     int M;               // B*Ho*Wo
     int cfg;             // tile configuration index (conv_igemm.hip kCfg), -1 = heuristic
+    hipEvent_t ev_start, ev_stop;   // optional (in-flight profiling): receive the kernel's own start / stop timestamps (hipExtLaunchKernel)
     int ntiles;          // set by the launcher: output tiles of the chosen configuration (the grid may be smaller: persistent)
     // optional second destination: output channels >= split go to out2 (two 1x1 convs over the same input fused into
     // one launch, e.g. C3.cv1 + C3.cv2); split is a multiple of 4, 0 = single destination
@@ -86,6 +88,14 @@ struct ConvP {
     int ablate;          // diagnostics only (VC_CONV_ABLATE, timing experiments with wrong results): 1 = no staging DMA after the first tiles,
                          // 2 = no output stores, 3 = both, 6 = return at once (launch floor of the grid); per-phase times come from dbg
 };
+
+// launch, optionally with the dispatch's own start/stop timestamps written to p.ev_start / p.ev_stop (what rocprofv3 reports as the
+// kernel duration; a hipEventRecord pair around a launch also counts the time the dispatch waits behind other queues)
+template <class K, class... A>
+static inline void launch_timed(const ConvP& p, K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t s, A... args) {
+    if (p.ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, p.ev_start, p.ev_stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+}
 
 int launch_conv(const ConvP& p, hipStream_t s);
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument checks: for the autotuner

@@ -231,7 +231,9 @@ class Engine:
 
     # ---------------------------------------------------------------- measurement
     def profile(self, on):
-        L.check(L.lib().vc_profile_enable(self._h, 1 if on else 0))
+        """False/0 off; True/1 blocking per-launch events for every stage (serialises the streams); 2 in-flight event pairs
+        around the conv launches only (no host waits: usable inside a timed region), resolved by profile_read(PROF_CONV)."""
+        L.check(L.lib().vc_profile_enable(self._h, 2 if on == 2 else (1 if on else 0)))
 
     def profile_reset(self):
         L.check(L.lib().vc_profile_reset(self._h))
