@@ -44,7 +44,7 @@ __device__ __forceinline__ int lds_slot(int row, int chunk) {
 
 __device__ __forceinline__ float act_apply(float v, int act, bool precise) {
     if (act == ACT_SILU) {
-        return precise ? v / (1.0f + expf(-v)) : v * __frcp_rn(1.0f + __expf(-v));
+        return precise ? v / (1.0f + expf(-v)) : v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     }
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     return v;
@@ -54,6 +54,79 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
+}
+
+// bf16 epilogue with 16-byte stores.  The MFMA layout leaves 4 consecutive channels of one pixel in a lane (an 8-byte store);
+// lane pairs (lane, lane ^ 16) hold channels [8g, 8g+4) and [8g+4, 8g+8) of the SAME pixels, so for two pixel tiles they swap
+// halves -- the even lane ends with 8 channels of the first tile's pixel, the odd lane with 8 channels of the second tile's
+// pixel -- and each stores one dwordx4.  Half the store instructions: the store tail of these kernels is issue-bound
+// (MI355X_MICROARCH.md, "epilogue store tail").  Residual reads of the whole wave tile are issued before the first value is
+// touched (one memory latency per tile instead of one per 16x16 block).  SiLU = x * rcp(1 + exp2(-x * log2 e)): v_exp_f32 and
+// v_rcp_f32 directly (1 ulp each, far below the bf16 rounding that follows) -- a correctly rounded division costs 11 more
+// VALU instructions per value, and the epilogue is the larger part of the 1x1 layers.
+// Preconditions (checked by the caller): Cout, channel strides and offsets multiples of 8.
+template <int PT, int CT, int ACT, int RES>
+__device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[CT][PT], const float4 (&bias)[CT], int mbase, int nbase, int frow) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
+    u32x2 R[PT][CT];
+    if constexpr (RES != RES_NONE) {
+        const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < PT; ++b) {
+            const int m = mbase + b * 16 + frow;
+            const int rrow = m * p.res_cs + p.res_co;
+#pragma unroll
+            for (int a = 0; a < CT; ++a) {
+                const int n = nbase + a * 16;
+                R[b][a] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (n < p.Cout && m < p.M) ? (rrow + n) * 2 : 0, 0, 0);
+            }
+        }
+    }
+    const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+#pragma unroll
+    for (int b = 0; b < PT; b += 2) {
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int n = nbase + a * 16;
+            const bool grp_ok = n < p.Cout;                     // the same for both lanes of a pair (Cout % 8 == 0)
+            u32x2 P[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[4] = {acc[a][b + t][0] + bias[a].x, acc[a][b + t][1] + bias[a].y, acc[a][b + t][2] + bias[a].z, acc[a][b + t][3] + bias[a].w};
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RES != RES_NONE) {
+                    const u32x2 r = R[b + t][a];
+                    rv[0] = __uint_as_float(r.x << 16); rv[1] = __uint_as_float(r.x & 0xffff0000u);
+                    rv[2] = __uint_as_float(r.y << 16); rv[3] = __uint_as_float(r.y & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = v[j];
+                    if constexpr (RES == RES_BEFORE_ACT) x += rv[j];
+                    if constexpr (ACT == ACT_SILU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                    if constexpr (ACT == ACT_RELU) x = x > 0.f ? x : 0.f;
+                    if constexpr (RES == RES_AFTER_ACT) x += rv[j];
+                    v[j] = x;
+                }
+                P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+            const u32x2 send = odd ? P[0] : P[1];
+            u32x2 recv;
+            recv.x = (unsigned)__shfl_xor((int)send.x, 16);
+            recv.y = (unsigned)__shfl_xor((int)send.y, 16);
+            const u32x4 o4 = odd ? (u32x4){recv.x, recv.y, P[1].x, P[1].y} : (u32x4){P[0].x, P[0].y, recv.x, recv.y};
+            const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
+            const int nn = odd ? n - 4 : n;
+            if (grp_ok && m < p.M && !((p.ablate == 2 || p.ablate == 3) && o4.x != 0x7fc07fc0u)) {     // ablate 2: no stores (timing experiment)
+                const bool second = p.split > 0 && nn >= p.split;
+                if (second) __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (m * p.out2_cs + p.out2_co + nn - p.split) * 2, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (m * p.out_cs + p.out_co + nn) * 2, 0, 0);
+            }
+        }
+    }
 }
 
 // Epilogue shared by the conv kernels: D[channel = (lane>>4)*4 + reg][pixel = lane&15] -> bias, activation, residual, bf16
@@ -71,59 +144,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
     const int OES = wide_out ? 4 : 2;
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    // bf16 fast path: 16-byte stores.  The MFMA layout leaves 4 consecutive channels of one pixel in a lane (an 8-byte
-    // store); lane pairs (lane, lane ^ 16) hold channels [8g, 8g+4) and [8g+4, 8g+8) of the SAME pixels, so for two pixel
-    // tiles they swap halves -- the even lane ends with 8 channels of the first tile's pixel, the odd lane with 8 channels of
-    // the second tile's pixel -- and each stores one dwordx4.  Half the store instructions: the store tail of these kernels
-    // is issue-bound (MI355X_MICROARCH.md, "epilogue store tail").
+    // bf16 fast path: conv_epilogue_bf16 above
     if constexpr (!F32 && PT % 2 == 0) {
         const bool fast = !p.out_f32 && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_co % 8 == 0 &&
                           (p.split == 0 || (p.split % 8 == 0 && p.out2_cs % 8 == 0 && p.out2_co % 8 == 0));
         if (fast) {
-            const bool odd = ((threadIdx.x >> 4) & 1) != 0;
-#pragma unroll
-            for (int b = 0; b < PT; b += 2) {
-#pragma unroll
-                for (int a = 0; a < CT; ++a) {
-                    const int n = nbase + a * 16;
-                    const bool grp_ok = n < p.Cout;                     // the same for both lanes of a pair (Cout % 8 == 0)
-                    u32x2 P[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int m = mbase + (b + t) * 16 + frow;
-                        const bool ok = grp_ok && m < p.M;
-                        float v[4] = {acc[a][b + t][0] + bias[a].x, acc[a][b + t][1] + bias[a].y, acc[a][b + t][2] + bias[a].z, acc[a][b + t][3] + bias[a].w};
-                        float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (p.res_mode != RES_NONE) {
-                            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrd, ok ? (m * p.res_cs + p.res_co + n) * 2 : 0, 0, 0);
-                            rv[0] = __uint_as_float(r.x << 16); rv[1] = __uint_as_float(r.x & 0xffff0000u);
-                            rv[2] = __uint_as_float(r.y << 16); rv[3] = __uint_as_float(r.y & 0xffff0000u);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float x = v[j];
-                            if (p.res_mode == RES_BEFORE_ACT) x += rv[j];
-                            x = act_apply(x, p.act, false);
-                            if (p.res_mode == RES_AFTER_ACT) x += rv[j];
-                            v[j] = x;
-                        }
-                        P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    }
-                    const u32x2 send = odd ? P[0] : P[1];
-                    u32x2 recv;
-                    recv.x = (unsigned)__shfl_xor((int)send.x, 16);
-                    recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-                    const u32x4 o4 = odd ? (u32x4){recv.x, recv.y, P[1].x, P[1].y} : (u32x4){P[0].x, P[0].y, recv.x, recv.y};
-                    const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
-                    const int nn = odd ? n - 4 : n;
-                    if (grp_ok && m < p.M && !((p.ablate == 2 || p.ablate == 3) && o4.x != 0x7fc07fc0u)) {     // ablate 2: no stores (timing experiment)
-                        const bool second = p.split > 0 && nn >= p.split;
-                        if (second) __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (m * p.out2_cs + p.out2_co + nn - p.split) * 2, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (m * p.out_cs + p.out_co + nn) * 2, 0, 0);
-                    }
-                }
-            }
-            return;
+            // activation / residual mode are launch constants: one straight-line instance per combination the networks use
+            // (no per-value scalar branches), anything else takes the general loop below
+            const int key = p.act * 4 + p.res_mode;
+            if (key == ACT_SILU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
+            if (key == ACT_SILU * 4 + RES_AFTER_ACT) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_AFTER_ACT>(p, acc, bias, mbase, nbase, frow); return; }
+            if (key == ACT_RELU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
+            if (key == ACT_RELU * 4 + RES_BEFORE_ACT) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_BEFORE_ACT>(p, acc, bias, mbase, nbase, frow); return; }
+            if (key == ACT_NONE * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_NONE, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
         }
     }
 #pragma unroll

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
                 for (int t = 0; t < 2; ++t) {
                     float v[4] = {acc[ct][pt + t][0] + bv[ct].x, acc[ct][pt + t][1] + bv[ct].y, acc[ct][pt + t][2] + bv[ct].z, acc[ct][pt + t][3] + bv[ct].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __frcp_rn(1.0f + __expf(-v[j]));
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
                     typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
                     const bf16x2s p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
                     P[t].x = __builtin_bit_cast(uint32_t, p0); P[t].y = __builtin_bit_cast(uint32_t, p1);
