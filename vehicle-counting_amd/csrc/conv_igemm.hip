@@ -56,6 +56,22 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// MFMA with the accumulator updated in place, as inline assembly.  With the builtin, the register allocator renames the
+// accumulators of the halo kernel's 9-tap unrolled loop (vdst != src C on a third of the MFMAs) and repairs the rotation
+// with ~90 v_accvgpr_read/write copies + s_nop stalls per 144 MFMAs.  The compiler cannot see that this statement is an
+// MFMA, so the wait states it would insert before a VALU reads the result are provided by mfma_results_settle().
+__device__ __forceinline__ void mfma_bf16_inplace(f32x4& c, const u32x4v& a, const u32x4v& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// >= 18 wait states between the last MFMA and the first VALU read of an accumulator (CDNA3/4 ISA: XDL write VGPR -> VALU
+// read, 8-pass MFMA: 11), tied to every accumulator so that no read is scheduled above it.
+template <int N>
+__device__ __forceinline__ void mfma_results_settle(f32x4* acc) {
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(acc[i]));
+}
+
 // bf16 epilogue with 16-byte stores.  The MFMA layout leaves 4 consecutive channels of one pixel in a lane (an 8-byte store);
 // lane pairs (lane, lane ^ 16) hold channels [8g, 8g+4) and [8g+4, 8g+8) of the SAME pixels, so for two pixel tiles they swap
 // halves -- the even lane ends with 8 channels of the first tile's pixel, the odd lane with 8 channels of the second tile's
@@ -622,15 +638,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
 #pragma unroll
             for (int i = 0; i < CT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wr[i]) : "v"(woffs + wfrag[i]) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            Chunk xa[PT], wa[CT];
 #pragma unroll
-            for (int i = 0; i < PT; ++i) { asm volatile("" : "+v"(xr[i])); xa[i].u = xr[i]; }
+            for (int i = 0; i < PT; ++i) asm volatile("" : "+v"(xr[i]));
 #pragma unroll
-            for (int i = 0; i < CT; ++i) { asm volatile("" : "+v"(wr[i])); wa[i].u = wr[i]; }
+            for (int i = 0; i < CT; ++i) asm volatile("" : "+v"(wr[i]));
 #pragma unroll
             for (int a = 0; a < CT; ++a)
 #pragma unroll
-                for (int b = 0; b < PT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[a].h, xa[b].h, acc[a][b], 0, 0, 0);
+                for (int b = 0; b < PT; ++b) mfma_bf16_inplace(acc[a][b], wr[a], xr[b]);
             woffs = woffs + WSTAGE == wring + NS * WSTAGE ? wring : woffs + WSTAGE;
             // weight tile kt+1 has landed once at most the newer weight tiles -- and, while it is still older than this
             // slice's patch prefetch, that prefetch -- are outstanding
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mfma_results_settle<CT * PT>(&acc[0][0]);
 #undef VC_XSTAGE
 #undef VC_WSTAGE
     conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
