@@ -20,6 +20,7 @@ namespace vc {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeLevel l0, const DecodeLevel l1, const DecodeLevel l2, int B, int nc,
                                                      float conf_thres, int max_cand, DetectPostBuffers pb, float* pred_debug,
                                                      int n_total) {
@@ -33,10 +34,14 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeLevel l0, const
         const int x = li % lv.nx;
         const int y = (li / lv.nx) % lv.ny;
         const int a = li / (lv.nx * lv.ny);
-        const float* q = lv.logits + (((size_t)b * lv.ny + y) * lv.nx + x) * lv.cs + a * no;
-        const float obj = sigmoidf_(q[4]);
+        const size_t qoff = (((size_t)b * lv.ny + y) * lv.nx + x) * lv.cs + a * no;
+        auto ld = [&](int c) -> float {
+            if constexpr (BF16) return __uint_as_float((uint32_t)((const uint16_t*)lv.logits)[qoff + c] << 16);
+            else return ((const float*)lv.logits)[qoff + c];
+        };
+        const float obj = sigmoidf_(ld(4));
         if (pred_debug == nullptr && !(obj > conf_thres)) continue;
-        const float sx = sigmoidf_(q[0]), sy = sigmoidf_(q[1]), sw = sigmoidf_(q[2]), sh = sigmoidf_(q[3]);
+        const float sx = sigmoidf_(ld(0)), sy = sigmoidf_(ld(1)), sw = sigmoidf_(ld(2)), sh = sigmoidf_(ld(3));
         const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
         const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
         const float tw = sw * 2.0f, th = sh * 2.0f;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeLevel l0, const
         float* dbg = pred_debug ? pred_debug + (size_t)g * no : nullptr;
         if (dbg) { dbg[0] = cx; dbg[1] = cy; dbg[2] = w; dbg[3] = h; dbg[4] = obj; }
         for (int c = 0; c < nc; ++c) {
-            const float sc = sigmoidf_(q[5 + c]);
+            const float sc = sigmoidf_(ld(5 + c));
             if (dbg) dbg[5 + c] = sc;
             const float v = sc * obj;
             if (v > best) { best = v; bj = c; }
@@ -203,7 +208,9 @@ int launch_decode(const DecodeLevel* lv, int nlv, int B, int nc, float conf, int
     const long total = (long)B * n_total;
     long grid = (total + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(decode_kernel, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
+    VC_CHECK(lv[0].bf16 == lv[1].bf16 && lv[1].bf16 == lv[2].bf16, VC_ERR_ARG, "decode: mixed logits types");
+    if (lv[0].bf16) hipLaunchKernelGGL(decode_kernel<true>, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
+    else hipLaunchKernelGGL(decode_kernel<false>, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

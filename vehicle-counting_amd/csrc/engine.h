@@ -32,6 +32,7 @@ struct Op {
     ConvP conv{};
     View a{}, b{};
     int C = 0;
+    int cout_logical = 0;            // > 0: the launch covers zero-padded output channels, FLOPs count this many
     int param = -1;                  // index into Net::params for CONV
 };
 

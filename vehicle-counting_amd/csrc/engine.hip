@@ -227,7 +227,7 @@ static int yolo_alloc(vc_engine* e) {
     VC_TRY(c3(20, 16, c[3])); VC_TRY(alloc_buf(e, m, "l20", px(16), c[3], es));
     VC_TRY(c3(23, 32, c[4])); VC_TRY(alloc_buf(e, m, "l23", px(32), c[4], es));
     const int no = 3 * (e->cfg.num_classes + 5);
-    const int lcs = round_up(no, 4);
+    const int lcs = round_up(no, 8);
     const int strides[3] = {8, 16, 32};
     for (int i = 0; i < 3; ++i) VC_TRY(dev_alloc(e, (void**)&e->d_logits[i], px(strides[i]) * lcs * sizeof(float)));
     // post-processing
@@ -318,12 +318,16 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     lv[21] = pb.conv("model.21.conv", p4, mkview(cat22, B, Hn / 32, Wn / 32, c[3], 0), 3, 2, 1, ACT_SILU);
     lv[22] = cat22;
     View p5 = lv[23] = yolo_c3(pb, e, 23, cat22, full("l23", 32, c[4]), c[4], e->rep[0], false);
-    // Detect.m[i]: 1x1 conv + bias, fp32 logits (models/yolo.py::Detect)
-    const int no = 3 * (e->cfg.num_classes + 5), lcs = round_up(no, 4);
+    // Detect.m[i]: 1x1 conv + bias (models/yolo.py::Detect).  fp32 mode: fp32 logits.  bf16 mode: bf16 logits like every other
+    // activation, and the launch covers round_up(no, 8) output channels (the packed weight / bias rows past `no` are zero) so
+    // that the 255-channel head takes the 16-byte-store epilogue; FLOPs are still counted for `no` channels (Op::cout_logical).
+    const int no = 3 * (e->cfg.num_classes + 5), lcs = round_up(no, 8);
     const View heads[3] = {p3, p4, p5};
     for (int i = 0; i < 3; ++i) {
         View o{}; o.ptr = e->d_logits[i]; o.cs = lcs; o.co = 0;
-        pb.conv("model.24.m." + std::to_string(i), heads[i], o, 1, 1, 0, ACT_NONE, nullptr, RES_NONE, true);
+        const bool wide = e->prec == PREC_F32;
+        pb.conv("model.24.m." + std::to_string(i), heads[i], o, 1, 1, 0, ACT_NONE, nullptr, RES_NONE, wide);
+        if (!wide && pb.status == VC_OK) { Op& op = ops.back(); op.cout_logical = op.conv.Cout; op.conv.Cout = lcs; }
     }
     return pb.status;
 }
@@ -401,7 +405,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
         const Op& op = ops[oi];
         switch (op.kind) {
             case Op::CONV: {
-                const double fl = 2.0 * op.conv.M * (double)op.conv.Cout * op.C;
+                const double fl = 2.0 * op.conv.M * (double)(op.cout_logical ? op.cout_logical : op.conv.Cout) * op.C;
                 const double es = elem_size(op.conv.prec);
                 const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                   (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
@@ -470,12 +474,12 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
     // decode + NMS
-    const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 4);
+    const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 8);
     DecodeLevel lv[3];
     int base = 0;
     const int strides[3] = {8, 16, 32};
     for (int i = 0; i < 3; ++i) {
-        lv[i].logits = e->d_logits[i]; lv[i].ny = nh / strides[i]; lv[i].nx = nw / strides[i]; lv[i].cs = lcs;
+        lv[i].logits = e->d_logits[i]; lv[i].bf16 = e->prec == PREC_F32 ? 0 : 1; lv[i].ny = nh / strides[i]; lv[i].nx = nw / strides[i]; lv[i].cs = lcs;
         lv[i].stride = (float)strides[i];
         for (int a = 0; a < 3; ++a) { lv[i].anchor_w[a] = kAnchors[i][2 * a]; lv[i].anchor_h[a] = kAnchors[i][2 * a + 1]; }
         lv[i].base = base;

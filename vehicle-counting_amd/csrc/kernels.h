@@ -26,9 +26,11 @@ int launch_letterbox(const uint8_t* src, void* dst, int B, const LetterboxGeom& 
 int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s);
 int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s);
 
-// Detect decode + candidate filter.  logits: B x ny x nx x lc_stride f32 (channel a*(5+nc)+o).
+// Detect decode + candidate filter.  logits: B x ny x nx x lc_stride (channel a*(5+nc)+o), f32 in the fp32 parity mode, bf16 in
+// the bf16 mode (like every other activation there).
 struct DecodeLevel {
-    const float* logits;
+    const void* logits;
+    int bf16;             // element type of `logits`
     int ny, nx, cs;       // cs = channel stride of the logits buffer
     float stride;
     float anchor_w[3], anchor_h[3];

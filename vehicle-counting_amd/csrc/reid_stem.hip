@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const uint4* __rest
                                                              const float* __restrict__ bias, uint32_t* __restrict__ y /* [k][25][25][32] bf16x2 */, int k,
                                                              int Kw8) {
     __shared__ uint4 patch[7 * RS_PW];
-    __shared__ uint32_t cbuf[RS_ROWS * RS_S * 32];          // conv rows of the band, [row][col][32 channel pairs]
+    // conv rows of the band, [row][col][32 channel pairs].  A pixel is 32 words = one pass over the banks, and a ds_write_b64
+    // group is 16 consecutive pixels at one channel offset (16-way conflict as is): the index of the 16-byte chunk inside the
+    // pixel is XORed with (pixel & 7), which leaves 2 lanes per bank pair and keeps the chunks the pool reads whole.
+    __shared__ __attribute__((aligned(16))) uint32_t cbuf[RS_ROWS * RS_S * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     // weights: 3 k-steps x 4 channel tiles, lane (channel = ct*16 + col, chunk = 4*s + kq); chunks 9..15 of the packed rows are zero
@@ -99,31 +102,31 @@ __global__ __launch_bounds__(256) void reid_stem_pool_kernel(const uint4* __rest
                     const bf16x2r p0 = {(__bf16)v0, (__bf16)v1}, p1 = {(__bf16)v2, (__bf16)v3};
                     uint2 pk;
                     pk.x = __builtin_bit_cast(uint32_t, p0); pk.y = __builtin_bit_cast(uint32_t, p1);
-                    *(uint2*)&cbuf[p * 32 + ct * 8 + kq * 2] = pk;
+                    *(uint2*)&cbuf[p * 32 + ((ct * 8 + kq * 2) ^ ((p & 7) << 2))] = pk;
                 }
             }
         }
         __syncthreads();
-        // pool: 2 pooled rows x 25 columns x 32 channel pairs
-        for (int i = threadIdx.x; i < 2 * RS_P * 32; i += 256) {
-            const int prow = i / (RS_P * 32), rem = i - prow * (RS_P * 32);
-            const int px = rem >> 5, cp = rem & 31;
+        // pool: 2 pooled rows x 25 columns x 8 chunks of 8 channels; a thread owns one 16-byte chunk of one pooled pixel.  Taps
+        // outside the image are clamped onto the window's own border tap (max is idempotent), so the loop has no branches.
+        for (int u = threadIdx.x; u < 2 * RS_P * 8; u += 256) {
+            const int prow = u / (RS_P * 8), rem = u - prow * (RS_P * 8);
+            const int px = rem >> 3, c4 = rem & 7;
             const int py = 2 * band + prow;
             if (py >= RS_P) continue;
-            uint32_t m = 0u;                         // every window holds at least one value and all values are >= +0
+            uint4 m = make_uint4(0u, 0u, 0u, 0u);    // all values are >= +0
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const int cy = 2 * py - 1 + dy;
-                if (cy < 0 || cy >= RS_S) continue;
-                const int cr = cy - cy0;
+                const int cr = max(2 * py - 1 + dy, 0) - cy0;
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
-                    const int cx = 2 * px + dx;
-                    if (cx < 0 || cx >= RS_S) continue;
-                    m = max_bf16x2_nonneg(m, cbuf[(cr * RS_S + cx) * 32 + cp]);
+                    const int cpix = cr * RS_S + max(2 * px + dx, 0);
+                    const uint4 v = *(const uint4*)&cbuf[cpix * 32 + ((c4 ^ (cpix & 7)) << 2)];
+                    m.x = max_bf16x2_nonneg(m.x, v.x); m.y = max_bf16x2_nonneg(m.y, v.y);
+                    m.z = max_bf16x2_nonneg(m.z, v.z); m.w = max_bf16x2_nonneg(m.w, v.w);
                 }
             }
-            y[(((size_t)crop * RS_P + py) * RS_P + px) * 32 + cp] = m;
+            ((uint4*)y)[(((size_t)crop * RS_P + py) * RS_P + px) * 8 + c4] = m;
         }
     }
 }
