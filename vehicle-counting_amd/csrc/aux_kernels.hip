@@ -105,9 +105,23 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
 }
 
+// (float)p / 255.f for an integer p in 0..255 without the division sequence: q = p * r, one residual correction
+// q' = fma(fma(-255, q, p), r, q) with r = RN(1/255).  Equal to the IEEE quotient for all 256 inputs (checked exhaustively in
+// exact arithmetic, tools/div255_check.py; the fp32 detector test compares the network input bit for bit).
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2a __attribute__((ext_vector_type(2)));
+    const bf16x2a v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float div255_exact(float p) {
+    const float r = 1.0f / 255.0f;
+    const float q = p * r;
+    return __fmaf_rn(__fmaf_rn(-255.0f, q, p), r, q);
+}
+
 // No-resize case (source already at network scale, e.g. 640x640 frames): pad + channel swap + /255 only.  One thread makes
-// four consecutive output pixels: a 12-byte source read and one 32-byte (bf16) / 64-byte (fp32) store.  Same arithmetic
-// as the general kernel ((float)u8 / 255.f, RNE to bf16).
+// four consecutive output pixels: a 12-byte source read (three dwords when the run is inside the image and 4-byte aligned)
+// and one 32-byte (bf16) / 64-byte (fp32) store.  Same values as the general kernel ((float)u8 / 255.f, RNE to bf16).
 template <bool F32>
 __global__ __launch_bounds__(256) void letterbox_copy_kernel(const uint8_t* __restrict__ src, void* __restrict__ dst, int B, LetterboxGeom g) {
     const int wq = g.net_w >> 2;                                          // net_w is a multiple of 32
@@ -117,29 +131,38 @@ __global__ __launch_bounds__(256) void letterbox_copy_kernel(const uint8_t* __re
         const int y = (int)((i / wq) % g.net_h);
         const int b = (int)(i / ((long)wq * g.net_h));
         const int uy = y - g.top;
-        const uint8_t* row = src + ((size_t)b * g.src_h + uy) * g.src_w * 3;
+        const int ux0 = xq * 4 - g.left;
+        const uint8_t* q0 = src + (((size_t)b * g.src_h + uy) * g.src_w + ux0) * 3;
+        int pv[12];
+        if (uy >= 0 && uy < g.unpad_h && ux0 >= 0 && ux0 + 3 < g.unpad_w && ((uintptr_t)q0 & 3) == 0) {
+            const uint32_t w0 = ((const uint32_t*)q0)[0], w1 = ((const uint32_t*)q0)[1], w2 = ((const uint32_t*)q0)[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pv[k] = (w0 >> (8 * k)) & 255; pv[4 + k] = (w1 >> (8 * k)) & 255; pv[8 + k] = (w2 >> (8 * k)) & 255; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ux = ux0 + k;
+                const bool in = ux >= 0 && ux < g.unpad_w && uy >= 0 && uy < g.unpad_h;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pv[3 * k + c] = in ? q0[3 * k + c] : 114;
+            }
+        }
         float f[4][3];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ux = xq * 4 + k - g.left;
-            int p0 = 114, p1 = 114, p2 = 114;
-            if (ux >= 0 && ux < g.unpad_w && uy >= 0 && uy < g.unpad_h) {
-                const uint8_t* q = row + (size_t)ux * 3;
-                p0 = q[0]; p1 = q[1]; p2 = q[2];
-                if (g.swap_rb) { const int t = p0; p0 = p2; p2 = t; }
-            }
-            f[k][0] = (float)p0 / 255.f; f[k][1] = (float)p1 / 255.f; f[k][2] = (float)p2 / 255.f;
+            const int p0 = g.swap_rb ? pv[3 * k + 2] : pv[3 * k], p2 = g.swap_rb ? pv[3 * k] : pv[3 * k + 2];
+            f[k][0] = div255_exact((float)p0); f[k][1] = div255_exact((float)pv[3 * k + 1]); f[k][2] = div255_exact((float)p2);
         }
         const size_t o = ((size_t)b * g.net_h + y) * g.net_w + (size_t)xq * 4;
         if (F32) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((float4*)dst)[o + k] = make_float4(f[k][0], f[k][1], f[k][2], 0.f);
         } else {
-            uint4 t0, t1;
-            t0.x = (uint32_t)f32_to_bf16(f[0][0]) | ((uint32_t)f32_to_bf16(f[0][1]) << 16); t0.y = (uint32_t)f32_to_bf16(f[0][2]);
-            t0.z = (uint32_t)f32_to_bf16(f[1][0]) | ((uint32_t)f32_to_bf16(f[1][1]) << 16); t0.w = (uint32_t)f32_to_bf16(f[1][2]);
-            t1.x = (uint32_t)f32_to_bf16(f[2][0]) | ((uint32_t)f32_to_bf16(f[2][1]) << 16); t1.y = (uint32_t)f32_to_bf16(f[2][2]);
-            t1.z = (uint32_t)f32_to_bf16(f[3][0]) | ((uint32_t)f32_to_bf16(f[3][1]) << 16); t1.w = (uint32_t)f32_to_bf16(f[3][2]);
+            uint4 t0, t1;                                                 // v_cvt_pk_bf16_f32: RNE like f32_to_bf16
+            t0.x = pack2_bf16(f[0][0], f[0][1]); t0.y = pack2_bf16(f[0][2], 0.f);
+            t0.z = pack2_bf16(f[1][0], f[1][1]); t0.w = pack2_bf16(f[1][2], 0.f);
+            t1.x = pack2_bf16(f[2][0], f[2][1]); t1.y = pack2_bf16(f[2][2], 0.f);
+            t1.z = pack2_bf16(f[3][0], f[3][1]); t1.w = pack2_bf16(f[3][2], 0.f);
             uint4* d = (uint4*)((uint2*)dst + o);
             d[0] = t0; d[1] = t1;
         }
