@@ -19,11 +19,21 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD2 >
 timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $OUT/mfma -o mfma -- $CMD2 > $OUT/mfma.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/prof_summary.py $OUT/trace/trace_results.db "VC_TUNE_CACHE=tune.txt rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline" > $OUT/kernel_stats.md
+python - >> $OUT/kernel_stats.md <<PY
+import json, re
+line = [l for l in open("$OUT/trace.log", errors="replace") if l.startswith("{") and "avg_launch_us" in l]
+if line:
+    d = json.loads(line[-1])
+    r = d["roofline"]
+    print("\nthe traced command's own bench line (HIP start/stop events of the conv launches of its timed steps): average %.2f us per "
+          "launch, %.1f TFLOP/s; end to end %.0f frames/s under the tracer" % (r["avg_launch_us"], r["achieved"], d["value"]))
+PY
 python tools/pmc_traffic.py $OUT/fetch/fetch_results.db $OUT/write/write_results.db > $OUT/pmc_traffic.json
 python tools/pmc_summary.py $OUT/mfma/mfma_results.db vc:: > $OUT/pmc_mfma.txt 2>&1
 python tools/gpu_busy.py $OUT/trace/trace_results.db > $OUT/gpu_busy.txt 2>&1
 python tools/track_gaps.py $OUT/trace/trace_results.db >> $OUT/gpu_busy.txt 2>&1
 unset VC_TUNE_CACHE
+cp $OUT/pmc_traffic.json profiles/${R}_pmc_traffic.json      # the bench line quotes the traffic of THESE passes
 timeout 600 python bench.py > $OUT/bench_n1.json 2> $OUT/bench.log
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
 ls -la $OUT
