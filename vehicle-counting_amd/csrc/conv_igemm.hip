@@ -661,6 +661,72 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
 }
 
+// ---- 1x1 / stride 1 with the weights in registers (bf16) -------------------------------------------------------------------
+// The narrow pointwise layers (K <= 128) are bound by everything but the matrix work: two K tiles per output tile, each with its
+// DMA issue, vmcnt wait and workgroup barrier, around 16 MFMAs.  With K*N this small a wave can keep its share of the weight
+// matrix in registers (CT x KS fragments = 32 / 64 VGPRs) for the whole launch and read its MFMA "B" operand -- lane (pixel,
+// 16-byte chunk of the pixel's channel run) -- straight from global memory: no LDS, no barrier, waves fully independent, the
+// next pixel block's fragments are fetched before this block's MFMAs and epilogue.  A wave owns one channel group of CT*16
+// outputs (NG = Cout / (CT*16) groups, 1, 2 or 4) and walks pixel blocks of PT*16 pixels; the NG waves that share a pixel block
+// run side by side in one workgroup (the second to fourth read of a pixel hits L2/L1).  K order, MFMA operand order and the
+// epilogue are those of conv_igemm_kernel: bit-identical results.
+template <int CT, int KS, int PT, int OCC, int ACT>     // OCC = waves per SIMD the register budget is sized for
+__global__ __launch_bounds__(256, OCC) void conv1x1_direct_kernel(const ConvP p) {
+    constexpr uint32_t OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fch = lane >> 4;
+    const int NG = p.Cout / (CT * 16);
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;           // 4 % NG == 0: a workgroup holds whole sets of groups
+    const int g = gw % NG, stride = nw / NG;
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)((size_t)p.B * p.H * p.W * p.in_cs * 2), 0x00020000);
+    Chunk wf[CT][KS];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wf[ct][ks].u = *(const u32x4v*)((const char*)p.w + ((size_t)((g * CT + ct) * 16 + frow) * p.Kw + ks * 32 + fch * 8) * 2);
+    float4 bias[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) bias[a] = *(const float4*)(p.bias + (g * CT + a) * 16 + fch * 4);
+    u32x4 x[PT][KS], xn[PT][KS];
+    auto fetch = [&](int blk, u32x4 (&dst)[PT][KS]) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = (blk * PT + pt) * 16 + frow;
+            const uint32_t base = (blk < nblk && m < p.M) ? (uint32_t)((m * p.in_cs + p.in_co + fch * 8) * 2) : OOB;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dst[pt][ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, (int)(base >= OOB ? OOB : base + ks * 64), 0, 0);
+        }
+    };
+    int blk = gw / NG;
+    fetch(blk, x);
+    for (; blk < nblk; blk += stride) {
+        fetch(blk + stride, xn);
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+            for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) {
+                    Chunk xa;
+                    xa.u = (u32x4v){x[b][ks].x, x[b][ks].y, x[b][ks].z, x[b][ks].w};
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a][ks].h, xa.h, acc[a][b], 0, 0, 0);
+                }
+        conv_epilogue_bf16<PT, CT, ACT, RES_NONE>(p, acc, bias, blk * PT * 16, g * CT * 16 + fch * 4, frow);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) x[pt][ks] = xn[pt][ks];
+    }
+}
+
 int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights are padded to the widest K tile (KC = 8)
 
 double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * (double)p.K; }
@@ -683,7 +749,9 @@ struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4; }       // + the halo-staged 3x3 variants
+// weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
+#define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4; }   // + the halo-staged 3x3 and the direct 1x1 variants
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 template <class K>
@@ -757,12 +825,44 @@ static int launch_halo(ConvP p, hipStream_t s) {
     return VC_OK;
 }
 
+static bool direct1x1_applicable(const ConvP& p, int ct, int ks) {
+    if (p.prec != PREC_BF16 || p.kh != 1 || p.kw != 1 || p.sh != 1 || p.sw != 1 || p.ph != 0 || p.pw != 0) return false;
+    if (p.Cin != ks * 32 || p.K != p.Cin || p.Ho != p.H || p.Wo != p.W || p.in_cs % 8 != 0 || p.in_co % 8 != 0) return false;
+    // the 16-byte-store epilogue only (conv_epilogue_bf16's preconditions), SiLU or no activation, no residual
+    if (p.out_f32 || p.res_mode != RES_NONE || (p.act != ACT_SILU && p.act != ACT_NONE) || p.out_cs % 8 != 0 || p.out_co % 8 != 0) return false;
+    if (p.split != 0 && (p.split % 8 != 0 || p.out2_cs % 8 != 0 || p.out2_co % 8 != 0)) return false;
+    const int ng = p.Cout / (ct * 16);
+    return p.Cout % (ct * 16) == 0 && (ng == 1 || ng == 2 || ng == 4);
+}
+
+template <int CT, int KS, int PT, int OCC>
+static int launch_direct1x1(ConvP p, hipStream_t s) {
+    static const bool enabled = !(getenv("VC_CONV_DIRECT") && atoi(getenv("VC_CONV_DIRECT")) == 0);   // A/B switch
+    if (!enabled || !direct1x1_applicable(p, CT, KS)) return VC_ERR_ARG;          // quietly, like launch_halo
+    p.Kw = p.Kp;
+    const int ng = p.Cout / (CT * 16);
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    const int need = (nblk * ng + 3) / 4;
+    static const int slots_hw = resident_workgroups(conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>);
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
+    const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;
+    const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
+    p.ntiles = nblk * ng;
+    if (p.act == ACT_SILU) launch_timed(p, conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>, dim3(std::min(need, slots)), dim3(256), 0, s, p);
+    else launch_timed(p, conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_NONE>, dim3(std::min(need, slots)), dim3(256), 0, s, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
     switch (cfg) {
 #define VC_Y(i, bp, bc, wp, wc, ns) case i: return launch_halo<bp, bc, wp, wc, ns>(p, s);
         VC_HALO_CFGS(VC_Y)
 #undef VC_Y
+#define VC_Z(i, ct, ks, pt, occ) case i: return launch_direct1x1<ct, ks, pt, occ>(p, s);
+        VC_DIRECT_CFGS(VC_Z)
+#undef VC_Z
 #define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
         VC_CONV_CFGS(VC_X)
 #undef VC_X
