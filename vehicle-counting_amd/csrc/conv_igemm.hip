@@ -63,6 +63,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {       // v
 __device__ __forceinline__ void mfma_bf16_inplace(f32x4& c, const u32x4v& a, const u32x4v& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// The other direction: the compiler is free to materialise the accumulators' zeros with v_mov right in front of the first
+// inline-asm MFMA, which then reads src C before the VALU write has landed (seen: the last two v_mov of a tile).  Tying the
+// accumulators to an asm statement forces the zeros into registers here, the s_nop covers the VALU-write -> MFMA-read wait states.
+template <int N>
+__device__ __forceinline__ void mfma_inputs_settle(f32x4* acc) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(acc[i]));
+    asm volatile("s_nop 4" ::: "memory");
+}
 // >= 18 wait states between the last MFMA and the first VALU read of an accumulator (CDNA3/4 ISA: XDL write VGPR -> VALU
 // read, 8-pass MFMA: 11), tied to every accumulator so that no read is scheduled above it.
 template <int N>
@@ -589,6 +598,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     for (int a = 0; a < CT; ++a)
 #pragma unroll
         for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_inputs_settle<CT * PT>(&acc[0][0]);
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0];
     constexpr uint32_t XBYTES = XCH * 16, WSTAGE = WROWS * KC * 16;
@@ -776,7 +786,7 @@ static int launch_one(ConvP p, hipStream_t s) {
     // A persistent grid that fills every workgroup slot of the chip leaves no room for the tracker stream's small per-frame
     // kernels, which then wait for a conv launch to end: 64 slots are left free (measured: +4..10 % end to end, conv time
     // unchanged; 256 free slots cost 9 % of conv time).
-    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
     if (p.prec == PREC_F32) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
@@ -844,7 +854,7 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
     const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
     const int need = (nblk * ng + 3) / 4;
     static const int slots_hw = resident_workgroups(conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>);
-    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
     const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;
     const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
     p.ntiles = nblk * ng;
@@ -853,6 +863,7 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
+
 
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
