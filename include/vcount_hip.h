@@ -122,6 +122,12 @@ int vc_tracker_step(vc_engine* e, int tracker_id, const double* tlwh, const doub
 int vc_tracker_count(vc_engine* e, int tracker_id, int* n);
 int vc_tracker_state(vc_engine* e, int tracker_id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu,
                      double* mean8, double* cov64, int* gallery_count);
+/* Tracker state for stream migration (the reference keeps it in Python objects, sort/tracker.py:40-60 and
+ * sort/track.py:64-80, and cannot move a stream): parameters, id counter, per track the FSM counters, fp64 Kalman mean and
+ * covariance and the valid gallery rows.  vc_tracker_snapshot with buf == NULL only reports the size.  vc_tracker_restore
+ * replaces the state (and parameters) of an existing tracker of any engine whose nn_budget_cap >= the snapshot's nn_budget. */
+int vc_tracker_snapshot(vc_engine* e, int tracker_id, void* buf, size_t cap, size_t* size);
+int vc_tracker_restore(vc_engine* e, int tracker_id, const void* buf, size_t size);
 /* DeepSort.update: boxes xyxy (k x 4 f64) + confidences on a BGR frame -> rows [x1,y1,x2,y2,track_id,-1,0]. */
 int vc_deepsort_update(vc_engine* e, int tracker_id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy,
                        const double* conf, int k, int64_t* out_rows7, int cap_rows, int* out_m);

@@ -47,6 +47,43 @@ def test_tracker_traces(eng, golden_dir, name):
     eng.tracker_reset(tid)
 
 
+@pytest.mark.parametrize("name", list(scenarios.SCENARIOS))
+def test_tracker_snapshot_restore_continues_the_stream(eng, golden_dir, name):
+    """Stream migration: snapshot a tracker mid-stream, restore it on a SECOND engine and feed both the rest of
+    the detections -- ids, FSM counters, fp64 means / covariances and gallery sizes stay identical, and equal to the reference's
+    own trace.  A corrupted or truncated blob is refused without touching the tracker."""
+    g = np.load(os.path.join(golden_dir, f"tracker_{name}.npz"))
+    p, frames = scenarios.build(name)
+    kw = dict(max_dist=p["max_dist"], max_iou_distance=p["max_iou_distance"], max_age=p["max_age"], n_init=p["n_init"], nn_budget=p["budget"])
+    tid = eng.tracker_create(**kw)
+    eng2 = E.Engine(None, synth_reid(1702), precision="f32", max_crops=64, max_frame_hw=(360, 640), max_tracks=256, nn_budget_cap=60)
+    tid2 = eng2.tracker_create(max_dist=0.5, max_iou_distance=0.1, max_age=3, n_init=1, nn_budget=7)     # parameters come from the snapshot
+
+    def feed(e, t_id, dets):
+        e.tracker_step(t_id, np.array([d["tlwh"] for d in dets]).reshape(-1, 4), np.array([d["conf"] for d in dets]),
+                       np.array([d["feature"] for d in dets], dtype=np.float32).reshape(-1, 512))
+
+    cut = len(frames) // 2
+    for dets in frames[:cut]:
+        feed(eng, tid, dets)
+    blob = eng.tracker_snapshot(tid)
+    with pytest.raises(E.L.VcError):
+        eng2.tracker_restore(tid2, blob[:-5])
+    with pytest.raises(E.L.VcError):
+        eng2.tracker_restore(tid2, b"XXXXXXXX" + blob[8:])
+    eng2.tracker_restore(tid2, blob)
+    assert eng2.tracker_snapshot(tid2) == blob                 # round trip is exact
+    for t in range(cut, len(frames)):
+        feed(eng, tid, frames[t])
+        feed(eng2, tid2, frames[t])
+        a, b = eng.tracker_state(tid), eng2.tracker_state(tid2)
+        for k in ("ids", "state", "hits", "age", "tsu", "gallery", "mean", "cov"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} frame {t}")
+        np.testing.assert_array_equal(b["ids"], g[f"f{t}_ids"], err_msg=f"frame {t}")
+        np.testing.assert_array_equal(b["state"], g[f"f{t}_state"], err_msg=f"frame {t}")
+    eng2.close()
+
+
 def test_deepsort_update_and_videotracker(eng):
     """B1-B4 glue: same boxes through the oracle (f32 oracle embedder) and through the HIP path."""
     sd = synth_reid(1702)

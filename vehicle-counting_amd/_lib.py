@@ -70,6 +70,8 @@ SIGNATURES = {
     "vc_tracker_step": [_vp, _i, _pd, _pd, _pf, _i],
     "vc_tracker_count": [_vp, _i, _pi],
     "vc_tracker_state": [_vp, _i, _i, _pl, _pi, _pi, _pi, _pi, _pd, _pd, _pi],
+    "vc_tracker_snapshot": [_vp, _i, _vp, C.c_size_t, _P(C.c_size_t)],
+    "vc_tracker_restore": [_vp, _i, _vp, C.c_size_t],
     "vc_deepsort_update": [_vp, _i, _pu8, _i, _i, _pd, _pd, _i, _pl, _i, _pi],
     "vc_videotracker_run": [_vp, _pi, _i, _pu8, _i, _i, _pd, _pl, _pd, _i, _pl, _i, _pi],
     "vc_stream_run": [_vp, _pi, _i, _vp, _i, _i, _i, _pl, _i, _pi, _pi],

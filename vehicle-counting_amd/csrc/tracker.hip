@@ -11,6 +11,7 @@
 //   deep_sort.py:25-59            DeepSort.update; modules/track.py:30-70 VideoTracker.run
 //   scipy.optimize.linear_sum_assignment (third-party; Crouse's shortest augmenting path, restated in lap_solve)
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -629,6 +630,95 @@ int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, in
         if (gallery_count) gallery_count[t] = tr.state == CONFIRMED ? tr.gal_count : 0;
         if (mean8) VC_HIP(hipMemcpy(mean8 + t * 8, e->pool.mean + (size_t)tr.slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost));
         if (cov64) VC_HIP(hipMemcpy(cov64 + t * 64, e->pool.cov + (size_t)tr.slot * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return VC_OK;
+}
+
+// ---- tracker snapshot / restore (tracker state for stream migration) -----------------------------------------
+// Everything Tracker.predict/update reads: parameters, id counter, and per track the FSM counters, the Kalman mean / covariance
+// (fp64, bit for bit) and the valid rows of the appearance gallery ring.  Little-endian, packed; restoring on another engine (or
+// GPU) and feeding the same detections continues the stream with identical ids and states (tests/test_gpu_tracker.py).
+namespace {
+struct SnapHeader { char magic[8]; int32_t feat_dim, n_tracks; int64_t next_id; double max_dist, min_confidence, nms_max_overlap, max_iou_distance; int32_t max_age, n_init, nn_budget, pad; };
+struct SnapTrack { int64_t id; int32_t state, hits, age, tsu, gal_count, gal_head; double last_conf; double mean[8]; double cov[64]; };
+const char kSnapMagic[8] = {'V', 'C', 'T', 'R', 'K', '0', '1', 0};
+}  // namespace
+
+int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* size) {
+    if (e) async_wait_all(e);
+    VC_CHECK(e && size && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    const Tracker& tk = *e->trackers[id];
+    size_t need = sizeof(SnapHeader);
+    for (const TrackRec& tr : tk.tracks) need += sizeof(SnapTrack) + (size_t)std::min(tr.gal_count, tk.p.nn_budget) * VC_FEAT_DIM * sizeof(float);
+    *size = need;
+    if (!buf) return VC_OK;                       // size query
+    VC_CHECK(cap >= need, VC_ERR_CAPACITY, "snapshot needs %zu bytes", need);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    char* o = (char*)buf;
+    SnapHeader h{};
+    memcpy(h.magic, kSnapMagic, 8);
+    h.feat_dim = VC_FEAT_DIM; h.n_tracks = (int32_t)tk.tracks.size(); h.next_id = tk.next_id;
+    h.max_dist = tk.p.max_dist; h.min_confidence = tk.p.min_confidence; h.nms_max_overlap = tk.p.nms_max_overlap;
+    h.max_iou_distance = tk.p.max_iou_distance; h.max_age = tk.p.max_age; h.n_init = tk.p.n_init; h.nn_budget = tk.p.nn_budget;
+    memcpy(o, &h, sizeof(h)); o += sizeof(h);
+    for (const TrackRec& tr : tk.tracks) {
+        SnapTrack t{};
+        t.id = tr.id; t.state = tr.state; t.hits = tr.hits; t.age = tr.age; t.tsu = tr.tsu; t.gal_count = tr.gal_count; t.gal_head = tr.gal_head;
+        t.last_conf = tr.last_conf;
+        VC_HIP(hipMemcpy(t.mean, e->pool.mean + (size_t)tr.slot * 8, sizeof(t.mean), hipMemcpyDeviceToHost));
+        VC_HIP(hipMemcpy(t.cov, e->pool.cov + (size_t)tr.slot * 64, sizeof(t.cov), hipMemcpyDeviceToHost));
+        memcpy(o, &t, sizeof(t)); o += sizeof(t);
+        const size_t rows = (size_t)std::min(tr.gal_count, tk.p.nn_budget);
+        if (rows) VC_HIP(hipMemcpy(o, e->pool.gallery + (size_t)tr.slot * e->pool.budget_cap * VC_FEAT_DIM, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost));
+        o += rows * VC_FEAT_DIM * sizeof(float);
+    }
+    return VC_OK;
+}
+
+int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
+    if (e) async_wait_all(e);
+    VC_CHECK(e && buf && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(size >= sizeof(SnapHeader), VC_ERR_ARG, "snapshot truncated");
+    const char* in = (const char*)buf;
+    SnapHeader h;
+    memcpy(&h, in, sizeof(h)); in += sizeof(h);
+    VC_CHECK(memcmp(h.magic, kSnapMagic, 8) == 0 && h.feat_dim == VC_FEAT_DIM && h.n_tracks >= 0, VC_ERR_ARG, "not a tracker snapshot");
+    VC_CHECK(h.nn_budget >= 1 && h.nn_budget <= e->cfg.nn_budget_cap, VC_ERR_CAPACITY, "snapshot nn_budget %d exceeds nn_budget_cap %d", h.nn_budget, e->cfg.nn_budget_cap);
+    // validate the whole blob before touching the tracker
+    {
+        const char* q = in;
+        for (int i = 0; i < h.n_tracks; ++i) {
+            VC_CHECK((size_t)(q - (const char*)buf) + sizeof(SnapTrack) <= size, VC_ERR_ARG, "snapshot truncated");
+            SnapTrack t;
+            memcpy(&t, q, sizeof(t)); q += sizeof(t);
+            VC_CHECK(t.gal_count >= 0 && t.gal_head >= 0 && t.gal_head < h.nn_budget, VC_ERR_ARG, "snapshot corrupt (gallery ring)");
+            q += (size_t)std::min(t.gal_count, h.nn_budget) * VC_FEAT_DIM * sizeof(float);
+        }
+        VC_CHECK((size_t)(q - (const char*)buf) == size, VC_ERR_ARG, "snapshot size mismatch");
+    }
+    Tracker& tk = *e->trackers[id];
+    VC_CHECK((int)e->free_slots.size() + (int)tk.tracks.size() >= h.n_tracks, VC_ERR_CAPACITY, "track pool too small for %d tracks", h.n_tracks);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    for (const TrackRec& t : tk.tracks) slot_free(e, t.slot);
+    tk.tracks.clear();
+    tk.p.max_dist = h.max_dist; tk.p.min_confidence = h.min_confidence; tk.p.nms_max_overlap = h.nms_max_overlap;
+    tk.p.max_iou_distance = h.max_iou_distance; tk.p.max_age = h.max_age; tk.p.n_init = h.n_init; tk.p.nn_budget = h.nn_budget;
+    tk.next_id = h.next_id;
+    for (int i = 0; i < h.n_tracks; ++i) {
+        SnapTrack t;
+        memcpy(&t, in, sizeof(t)); in += sizeof(t);
+        TrackRec tr{};
+        tr.id = t.id; tr.state = t.state; tr.hits = t.hits; tr.age = t.age; tr.tsu = t.tsu; tr.gal_count = t.gal_count; tr.gal_head = t.gal_head;
+        tr.last_conf = t.last_conf;
+        tr.slot = slot_alloc(e);
+        VC_HIP(hipMemcpy(e->pool.mean + (size_t)tr.slot * 8, t.mean, sizeof(t.mean), hipMemcpyHostToDevice));
+        VC_HIP(hipMemcpy(e->pool.cov + (size_t)tr.slot * 64, t.cov, sizeof(t.cov), hipMemcpyHostToDevice));
+        const size_t rows = (size_t)std::min(t.gal_count, h.nn_budget);
+        if (rows) VC_HIP(hipMemcpy(e->pool.gallery + (size_t)tr.slot * e->pool.budget_cap * VC_FEAT_DIM, in, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice));
+        in += rows * VC_FEAT_DIM * sizeof(float);
+        tk.tracks.push_back(tr);
     }
     return VC_OK;
 }

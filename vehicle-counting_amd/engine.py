@@ -153,6 +153,19 @@ class Engine:
                                          L.ptr(cov, C.c_double), L.ptr(gal, C.c_int)))
         return {"ids": ids, "state": st, "hits": hits, "age": age, "tsu": tsu, "mean": mean, "cov": cov, "gallery": gal}
 
+    def tracker_snapshot(self, tid) -> bytes:
+        """Serialised tracker state (parameters, id counter, Kalman state, galleries) for stream migration."""
+        n = C.c_size_t()
+        L.check(L.lib().vc_tracker_snapshot(self._h, tid, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        L.check(L.lib().vc_tracker_snapshot(self._h, tid, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def tracker_restore(self, tid, blob: bytes):
+        """Replace tracker `tid`'s state and parameters with a snapshot (possibly taken on another engine / GPU)."""
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        L.check(L.lib().vc_tracker_restore(self._h, tid, buf, len(blob)))
+
     def deepsort_update(self, tid, bbox_xyxy, confidences, ori_img):
         img = np.ascontiguousarray(ori_img, dtype=np.uint8)
         b, c = L.f64(bbox_xyxy).reshape(-1, 4), L.f64(confidences).reshape(-1)
