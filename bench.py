@@ -195,7 +195,7 @@ def main():
                          "achieved_note": "sum of conv FLOPs / sum of conv launch durations over the timed steps (HIP event pairs on the launch stream, kernels of three streams overlapping)",
                          "achieved_isolated": isolated,
                          "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
-                         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
+                         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
                          "launches_per_step": conv_timed["launches"] / max(args.steps, 1),
                          "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),
                          "algorithmic_gflop_per_step": conv_timed["flops"] / max(args.steps, 1) / 1e9},
