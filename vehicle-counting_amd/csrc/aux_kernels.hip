@@ -277,12 +277,27 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(View cat, int C) {
 // A lane owns one 4-byte word of a position, so a position's slice is one coalesced 128-byte read/write and every LDS access
 // of a wave is 64 consecutive words; the three chained 5x5 max-pools are separable row / column passes on the LDS plane.
 // max() of bf16 values is exact on the two halves of a word (no rounding anywhere).
+// Order-preserving keys: a float's bits compare like unsigned integers once negative values have all bits flipped and
+// non-negative ones the sign bit set.  bf16 pairs are keyed per half, so the 30 max() of a position are one v_pk_max_u16
+// (v_max_u32 for fp32) each instead of an unpack / two fmaxf / repack; keys are turned back into values on the way out.
+// (No NaNs reach this kernel: its input is the SiLU output of a finite convolution.)
 template <bool F32>
-__device__ __forceinline__ uint32_t wmax(uint32_t a, uint32_t b) {
-    if (F32) return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
-    const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
-    const float hi = fmaxf(__uint_as_float(a & 0xffff0000u), __uint_as_float(b & 0xffff0000u));
-    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+__device__ __forceinline__ uint32_t to_key(uint32_t v) {
+    if (F32) return v ^ (((int32_t)v >> 31) | 0x80000000u);
+    const uint32_t neg = (v >> 15) & 0x00010001u;                     // sign of each half
+    return v ^ ((neg * 0x7fffu) | 0x80008000u);                        // negative: flip all 16 bits, else flip the sign bit
+}
+template <bool F32>
+__device__ __forceinline__ uint32_t from_key(uint32_t k) {
+    if (F32) return k ^ ((~((int32_t)k >> 31)) | 0x80000000u);
+    const uint32_t pos = (k >> 15) & 0x00010001u;                     // key has its top bit set <=> the value was non-negative
+    return k ^ (((pos ^ 0x00010001u) * 0x7fffu) | 0x80008000u);
+}
+template <bool F32>
+__device__ __forceinline__ uint32_t kmax(uint32_t a, uint32_t b) {
+    if (F32) return a > b ? a : b;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
 template <bool F32>
@@ -298,22 +313,22 @@ __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
     const int w = threadIdx.x & 31, pg = threadIdx.x >> 5;               // word of the slice, position group (32 per pass: 16 waves hide the LDS latency)
     char* base = (char*)cat.ptr + (((size_t)b * n) * cat.cs + cat.co + c0) * ES + w * 4;
     const size_t pstride = (size_t)cat.cs * ES;
-    for (int i = pg; i < n; i += 32) P[i * 32 + w] = *(const uint32_t*)(base + i * pstride);
+    for (int i = pg; i < n; i += 32) P[i * 32 + w] = to_key<F32>(*(const uint32_t*)(base + i * pstride));
     __syncthreads();
-    const uint32_t NEG = F32 ? 0xff800000u : 0xff80ff80u;                // -inf (both halves)
+    const uint32_t NEG = 0u;                                             // smallest key (below -inf)
     for (int round = 1; round <= 3; ++round) {
         for (int i = pg; i < n; i += 32) {                                // row pass
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = wmax<F32>(m, P[(y * W + xx) * 32 + w]);
+            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = kmax<F32>(m, P[(y * W + xx) * 32 + w]);
             T[i * 32 + w] = m;
         }
         __syncthreads();
         for (int i = pg; i < n; i += 32) {                                // column pass + store of this round's slice
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = wmax<F32>(m, T[(yy * W + x) * 32 + w]);
-            *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = m;
+            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = kmax<F32>(m, T[(yy * W + x) * 32 + w]);
+            *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = from_key<F32>(m);
             P[i * 32 + w] = m;                                           // own position only: no hazard with other threads' T reads
         }
         __syncthreads();
