@@ -105,20 +105,6 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
     }
 }
 
-// (float)p / 255.f for an integer p in 0..255 without the division sequence: q = p * r, one residual correction
-// q' = fma(fma(-255, q, p), r, q) with r = RN(1/255).  Equal to the IEEE quotient for all 256 inputs (checked exhaustively in
-// exact arithmetic, tools/div255_check.py; the fp32 detector test compares the network input bit for bit).
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    typedef __bf16 bf16x2a __attribute__((ext_vector_type(2)));
-    const bf16x2a v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, v);
-}
-__device__ __forceinline__ float div255_exact(float p) {
-    const float r = 1.0f / 255.0f;
-    const float q = p * r;
-    return __fmaf_rn(__fmaf_rn(-255.0f, q, p), r, q);
-}
-
 // No-resize case (source already at network scale, e.g. 640x640 frames): pad + channel swap + /255 only.  One thread makes
 // four consecutive output pixels: a 12-byte source read (three dwords when the run is inside the image and 4-byte aligned)
 // and one 32-byte (bf16) / 64-byte (fp32) store.  Same values as the general kernel ((float)u8 / 255.f, RNE to bf16).

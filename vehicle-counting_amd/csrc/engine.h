@@ -95,6 +95,11 @@ struct vc_engine {
     float* d_pred_debug = nullptr;
     bool want_pred_debug = false;
     int last_B = 0, last_nh = 0, last_nw = 0, last_ntotal = 0;
+    // letterbox folded into the stem (stem_direct.hip, U8): source of the running / last detector pass; the letterboxed tensor
+    // ybuf["in"] is then only produced on demand (vc_detect_debug_layer(-1))
+    const uint8_t* stem_src = nullptr;
+    vc::LetterboxGeom stem_geom{};
+    bool in_stale = false;
     float* h_det = nullptr;                      // pinned [max_batch][max_det][6]
     int* h_det_count = nullptr;                  // pinned [max_batch]
     float* h_det2[2] = {nullptr, nullptr};       // pinned detector outputs of the (up to) two submissions in flight

@@ -414,10 +414,13 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
                 const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
                 conv_timer_arm(e, cp, fl, by);
+                if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only the u8 stem can run it
+                    VC_CHECK(stem_direct_on && stem_u8_applicable(cp, e->stem_geom), VC_ERR_STATE, "letterbox fold-in: the direct stem does not apply");
                 if (stem_direct_on && stem_direct_applicable(cp)) {          // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
-                    VC_TRY(launch_stem_direct(cp, s));
+                    if (e->stem_src && cp.in == e->ybuf["in"].ptr) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s));   // letterbox folded in
+                    else VC_TRY(launch_stem_direct(cp, s));
                 } else if (reid_stem_on && nx && nx->kind == Op::MAXPOOL && nx->a.ptr == cp.out && reid_stem_applicable(cp, nx->b.cs, nx->b.co)) {
                     cp.cfg = 101;                                            // ReID stem: conv + ReLU + MaxPool in one kernel (reid_stem.hip)
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
@@ -510,8 +513,18 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     scale_geom_host(ScaleGeom{nh, nw, h, w}, hg);
     for (int b = 1; b < B; ++b) memcpy(hg + (size_t)b * 5, hg, 5 * sizeof(float));
     VC_HIP(hipMemcpyAsync(e->d_geom, hg, (size_t)B * 5 * sizeof(float), hipMemcpyHostToDevice, e->dstream));
-    { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->dstream)); }
-    return yolo_forward(e, B, nh, nw);
+    // bf16, frame already at network scale: the stem reads the u8 frames itself (same arithmetic per pixel, bit-identical stem
+    // output) and the 8-byte-per-pixel letterboxed tensor is neither written nor read back
+    static const bool fuse_on = !(getenv("VC_STEM_U8") && atoi(getenv("VC_STEM_U8")) == 0) && !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
+    const bool fuse = fuse_on && e->prec == PREC_BF16 && g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0 &&
+                      e->ch[0] % 16 == 0 && e->ch[0] <= 64;
+    e->stem_src = fuse ? d_frames : nullptr;
+    e->stem_geom = g;
+    e->in_stale = fuse;
+    if (!fuse) { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->dstream)); }
+    const int st = yolo_forward(e, B, nh, nw);
+    if (fuse) e->stem_src = d_frames;             // kept for vc_detect_debug_layer(-1)
+    return st;
 }
 
 // ------------------------------------------------------------------------------------------------ ReID net
@@ -854,6 +867,11 @@ int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int d
     VC_CHECK(e->last_B > 0, VC_ERR_STATE, "no detector run yet");
     VC_CHECK(layer >= -1 && layer < 24, VC_ERR_ARG, "layer must be -1..23");
     if (layer == -1) {
+        if (e->in_stale && e->stem_src) {         // the last pass folded the letterbox into the stem: produce the tensor now (the frames must still be there)
+            VC_TRY(launch_letterbox(e->stem_src, e->ybuf["in"].ptr, e->last_B, e->stem_geom, e->prec, e->dstream));
+            VC_HIP(hipStreamSynchronize(e->dstream));
+            e->in_stale = false;
+        }
         View v = mkview(e->ybuf["in"], e->last_B, e->last_nh, e->last_nw, 3, 0);
         return read_view_f32(e, v, out, cap, dims);
     }

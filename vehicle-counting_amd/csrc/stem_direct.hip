@@ -7,7 +7,7 @@
 // ONCE (20 rows x 34 pixel pairs, 11 KB), keeps the whole weight matrix in registers across the tiles it walks, and feeds the
 // same MFMA sequence from the patch: the layer becomes what it is, an HBM stream (read 8 B, write 64 B per input pixel).
 // The MFMA operand order and the k order are those of conv_igemm_kernel, so the results are bit-identical to it.
-#include "vc_common.h"
+#include "kernels.h"
 
 namespace vc {
 
@@ -21,10 +21,12 @@ union ChunkS { uint4 u; bf16x8s h; };
 #define STEM_PC 34            // patch pairs = TW + 2
 #define STEM_PP 36            // LDS row pitch in 16-byte chunks
 
-template <int CT>   // Cout = CT * 16
+// U8: the patch comes straight from the u8 frames (letterbox_copy_kernel's arithmetic applied per fetched pixel pair: pad value
+// 114, optional R/B swap, exact /255, RNE to bf16), so the letterboxed tensor is never written or read.
+template <int CT, bool U8>   // Cout = CT * 16
 __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w, const float* __restrict__ bias,
                                                           uint16_t* __restrict__ y, int B, int H, int Wp, int Ho, int Wo, int Kw8 /* weight row stride in chunks */,
-                                                          int out_cs, int out_co, int tiles_x, int tiles_y) {
+                                                          int out_cs, int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g) {
     __shared__ uint4 patch[STEM_PR * STEM_PP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -57,7 +59,25 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
             const int pr = i / STEM_PC, pc = i - pr * STEM_PC;
             const int iy = 2 * oy0 - 2 + pr, ip = ox0 - 1 + pc;
             pre[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < STEM_PR * STEM_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) pre[k] = x[((size_t)b * H + iy) * Wp + ip];
+            if (i < STEM_PR * STEM_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
+                if constexpr (!U8) {
+                    pre[k] = x[((size_t)b * H + iy) * Wp + ip];
+                } else {
+                    const int uy = iy - g.top, ux = 2 * ip - g.left;                  // left is even here: a pair is inside or outside as a whole
+                    int pv[6] = {114, 114, 114, 114, 114, 114};
+                    if (uy >= 0 && uy < g.unpad_h && ux >= 0 && ux + 1 < g.unpad_w) {
+                        const uint16_t* q = (const uint16_t*)(src8 + (((size_t)b * g.src_h + uy) * g.src_w + ux) * 3);      // 2-byte aligned (even width)
+                        const uint32_t h0 = q[0], h1 = q[1], h2 = q[2];
+                        pv[0] = h0 & 255; pv[1] = h0 >> 8; pv[2] = h1 & 255; pv[3] = h1 >> 8; pv[4] = h2 & 255; pv[5] = h2 >> 8;
+                    }
+                    const int a0 = g.swap_rb ? pv[2] : pv[0], a2 = g.swap_rb ? pv[0] : pv[2];
+                    const int b0 = g.swap_rb ? pv[5] : pv[3], b2 = g.swap_rb ? pv[3] : pv[5];
+                    pre[k].x = pack2_bf16(div255_exact((float)a0), div255_exact((float)pv[1]));
+                    pre[k].y = pack2_bf16(div255_exact((float)a2), 0.f);
+                    pre[k].z = pack2_bf16(div255_exact((float)b0), div255_exact((float)pv[4]));
+                    pre[k].w = pack2_bf16(div255_exact((float)b2), 0.f);
+                }
+            }
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -129,21 +149,42 @@ bool stem_direct_applicable(const ConvP& p) {
            p.Cout <= 64 && p.Kp >= 160 && p.out_cs % 8 == 0 && p.out_co % 8 == 0;
 }
 
-int launch_stem_direct(const ConvP& p, hipStream_t s) {
+static int launch_stem_impl(const ConvP& p, const uint8_t* src8, const LetterboxGeom& g, hipStream_t s) {
     const int tiles_x = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_y = (p.Ho + STEM_TH - 1) / STEM_TH;
     const int ntiles = p.B * tiles_x * tiles_y;
     const int grid = std::min(ntiles, 256 * 3 - 64); // 3 workgroups per CU can be resident (VGPRs); 64 slots stay free for the tracker stream (conv_igemm.hip)
     const uint4* x = (const uint4*)p.in; const uint4* w = (const uint4*)p.w;
     uint16_t* y = (uint16_t*)p.out;
     const int kw8 = p.Kp / 8;
+#define VC_STEM_LAUNCH(CT)                                                                                                          \
+    if (src8) launch_timed(p, stem_direct_kernel<CT, true>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, \
+                           p.out_cs, p.out_co, tiles_x, tiles_y, src8, g);                                                             \
+    else launch_timed(p, stem_direct_kernel<CT, false>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8,    \
+                      p.out_cs, p.out_co, tiles_x, tiles_y, src8, g);
     switch (p.Cout / 16) {
-        case 1: launch_timed(p, stem_direct_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        case 2: launch_timed(p, stem_direct_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        case 3: launch_timed(p, stem_direct_kernel<3>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
-        default: launch_timed(p, stem_direct_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, p.out_cs, p.out_co, tiles_x, tiles_y); break;
+        case 1: VC_STEM_LAUNCH(1) break;
+        case 2: VC_STEM_LAUNCH(2) break;
+        case 3: VC_STEM_LAUNCH(3) break;
+        case 4: VC_STEM_LAUNCH(4) break;
+        default: return VC_ERR_ARG;
     }
+#undef VC_STEM_LAUNCH
     VC_HIP(hipGetLastError());
     return VC_OK;
+}
+
+int launch_stem_direct(const ConvP& p, hipStream_t s) { return launch_stem_impl(p, nullptr, LetterboxGeom{}, s); }
+
+// no-resize geometry only (the frame is already at network scale), pairs never straddle the image edge (even left pad and
+// width), 2-byte aligned pair reads (even source width)
+bool stem_u8_applicable(const ConvP& p, const LetterboxGeom& g) {
+    return stem_direct_applicable(p) && g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0 &&
+           g.net_h == p.H && g.net_w == 2 * p.W;
+}
+
+int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s) {
+    if (!frames || !stem_u8_applicable(p, g)) return VC_ERR_ARG;
+    return launch_stem_impl(p, frames, g, s);
 }
 
 }  // namespace vc

@@ -57,6 +57,22 @@ __host__ __device__ static inline float bf16_to_f32(uint16_t h) {
     return f;
 }
 
+#ifdef __HIPCC__
+// (float)p / 255.f for an integer p in 0..255 without the division sequence: q = p * r, one residual correction
+// q' = fma(fma(-255, q, p), r, q) with r = RN(1/255).  Equal to the IEEE quotient for all 256 inputs (checked exhaustively in
+// exact arithmetic, tools/div255_check.py; the fp32 detector test compares the network input bit for bit).
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2a __attribute__((ext_vector_type(2)));
+    const bf16x2a v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float div255_exact(float p) {
+    const float r = 1.0f / 255.0f;
+    const float q = p * r;
+    return __fmaf_rn(__fmaf_rn(-255.0f, q, p), r, q);
+}
+#endif
+
 // ---- convolution as implicit GEMM (conv_igemm.hip) ----------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 enum ResMode : int { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
@@ -102,6 +118,10 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument 
 int conv_num_cfgs();
 bool stem_direct_applicable(const ConvP& p);                    // stem_direct.hip: YOLO 6x6/s2 stem in bf16
 int launch_stem_direct(const ConvP& p, hipStream_t s);
+struct LetterboxGeom;
+// the same with the letterbox folded into the patch fetch: reads the u8 frames directly (no-resize geometry, even source width)
+bool stem_u8_applicable(const ConvP& p, const LetterboxGeom& g);
+int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s);
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
 int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s);
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
