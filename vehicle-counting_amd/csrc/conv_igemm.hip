@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     for (int i = 0; i < XI; ++i) {
         const int e = (i * 4 + wave) * 64 + lane;
         const int pp = e >> 2, cpos = e & 3;
-        const int chunk = cpos ^ ((0x78 >> (((pp >> 2) & 3) * 2)) & 3);          // source-side swizzle (lds_slot<4>)
+        const int chunk = cpos ^ ((pp >> 1) & 2);                                 // source-side swizzle, see xaddr below
         const int gp = gp0 + pp;
         xsrc[i] = (pp < npix && gp >= 0) ? (uint32_t)((gp * p.in_cs + p.in_co) * ES + chunk * 16) : OOB;
     }
@@ -585,7 +585,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
                 const bool valid = ok && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
                 const int px = valid ? pc + dy * W + dx : ZP;
-                xaddr[i][t] = (uint32_t)((px * 4 + (fch ^ ((0x78 >> (((px >> 2) & 3) * 2)) & 3))) * 16);
+                // chunk slot = fch ^ 2 * bit 2 of the pixel index.  The fragment reads of a tap start at an ARBITRARY patch pixel
+                // (lds_slot<4>'s permutation is conflict-free only for bases that are multiples of 16: 33 % of the LDS cycles of this
+                // kernel were bank conflicts); this one keeps the four lanes of a ds_read_b128 group that share pixel & 3 on four
+                // different 16-byte slots for every base (exhaustive check over bases and the hardware's lane groups).
+                xaddr[i][t] = (uint32_t)((px * 4 + (fch ^ ((px >> 1) & 2))) * 16);
             }
         }
     }
@@ -754,14 +758,18 @@ double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * 
     X(22, 64, 128, 1, 4, 8, 3)  X(23, 256, 32, 4, 1, 4, 4)  X(24, 256, 64, 4, 1, 4, 4)  X(25, 256, 64, 4, 1, 8, 3)    \
     X(26, 256, 128, 2, 2, 4, 4) X(27, 256, 128, 2, 2, 8, 3)
 // halo-staged 3x3 / s1 / p1 (bf16): Y(index, BP, BC, WP, WC, NS)
-#define VC_HALO_CFGS(Y) Y(28, 128, 64, 2, 2, 2) Y(29, 128, 64, 2, 2, 3) Y(30, 128, 128, 2, 2, 2) Y(31, 128, 128, 2, 2, 3)
+// 36 - 39: the four waves side by side in pixels (wave tiles 32 x 64 and 64 x 128): half the per-tile tap-address set-up per MFMA
+// of the 2 x 2 arrangement -- the narrow layers issue 7 VALU instructions per MFMA, most of them set-up and epilogue (measured:
+// 64 -> 64 at 25^2 -8 %, 128 -> 128 at 40^2 -10 %; 256 x 64 and 128 x 128 tiles in this arrangement gained nothing)
+#define VC_HALO_CFGS(Y) Y(28, 128, 64, 2, 2, 2) Y(29, 128, 64, 2, 2, 3) Y(30, 128, 128, 2, 2, 2) Y(31, 128, 128, 2, 2, 3) \
+                        Y(36, 128, 64, 4, 1, 2) Y(37, 128, 64, 4, 1, 3) Y(38, 256, 128, 4, 1, 2) Y(39, 256, 128, 4, 1, 3)
 struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
 // weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
 #define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4; }   // + the halo-staged 3x3 and the direct 1x1 variants
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39) and the direct 1x1 (32-35) variants
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 template <class K>
