@@ -138,11 +138,11 @@ __device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[
                 }
                 P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
-            const u32x2 send = odd ? P[0] : P[1];
-            u32x2 recv;
-            recv.x = (unsigned)__shfl_xor((int)send.x, 16);
-            recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-            const u32x4 o4 = odd ? (u32x4){recv.x, recv.y, P[1].x, P[1].y} : (u32x4){P[0].x, P[0].y, recv.x, recv.y};
+            // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second, i.e. exactly the exchange
+            // between lane and lane ^ 16 described above, in one VALU instruction per dword (no LDS-pipe round trip)
+            const u32x2 sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
+            const u32x2 sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+            const u32x4 o4 = {sx.x, sy.x, sx.y, sy.y};
             const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
             const int nn = odd ? n - 4 : n;
             if (grp_ok && m < p.M && !((p.ablate == 2 || p.ablate == 3) && o4.x != 0x7fc07fc0u)) {     // ablate 2: no stores (timing experiment)

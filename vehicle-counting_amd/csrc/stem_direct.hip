@@ -128,11 +128,10 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
                     const bf16x2s p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
                     P[t].x = __builtin_bit_cast(uint32_t, p0); P[t].y = __builtin_bit_cast(uint32_t, p1);
                 }
-                const uint2 send = odd ? P[0] : P[1];
-                uint2 recv;
-                recv.x = (unsigned)__shfl_xor((int)send.x, 16);
-                recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-                const uint4 o4 = odd ? make_uint4(recv.x, recv.y, P[1].x, P[1].y) : make_uint4(P[0].x, P[0].y, recv.x, recv.y);
+                typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+                const u32x2s sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);      // lane <-> lane ^ 16, see conv_epilogue_bf16
+                const u32x2s sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+                const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
                 const int ptm = pt + (odd ? 1 : 0);
                 const int oy = oy0 + wave * 2 + (ptm >> 1), ox = ox0 + (ptm & 1) * 16 + col;
                 if (oy < Ho && ox < Wo)
