@@ -111,6 +111,7 @@ __device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[
         }
     }
     const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+    const bool no_store = p.ablate == 2 || p.ablate == 3;      // timing experiment (VC_CONV_ABLATE): everything but the stores
 #pragma unroll
     for (int b = 0; b < PT; b += 2) {
 #pragma unroll
@@ -145,10 +146,15 @@ __device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[
             const u32x4 o4 = {sx.x, sy.x, sx.y, sy.y};
             const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
             const int nn = odd ? n - 4 : n;
-            if (grp_ok && m < p.M && !((p.ablate == 2 || p.ablate == 3) && o4.x != 0x7fc07fc0u)) {     // ablate 2: no stores (timing experiment)
-                const bool second = p.split > 0 && nn >= p.split;
-                if (second) __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (m * p.out2_cs + p.out2_co + nn - p.split) * 2, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (m * p.out_cs + p.out_co + nn) * 2, 0, 0);
+            // masked lanes store to an out-of-range offset, which the buffer unit drops: no exec-mask branches around the stores
+            const bool ok = grp_ok && m < p.M && !no_store;
+            const int off1 = (m * p.out_cs + p.out_co + nn) * 2;
+            if (p.split == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, ok ? off1 : (int)0x80000000u, 0, 0);
+            } else {
+                const bool second = nn >= p.split;
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (ok && !second) ? off1 : (int)0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (ok && second) ? (m * p.out2_cs + p.out2_co + nn - p.split) * 2 : (int)0x80000000u, 0, 0);
             }
         }
     }
