@@ -74,17 +74,18 @@ def test_conv2d(case, precision):
 
 
 @pytest.mark.parametrize("slots", [0, 8])
-@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 40)))
+@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 43)))
 def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""
+    halo = cfg in (28, 29, 30, 31, 36, 37, 38, 39)          # 40-42 are implicit-GEMM tiles with 16 waves per workgroup
     monkeypatch.setenv("VC_CONV_CFG", str(cfg))
     if slots:
-        if cfg >= 28:
+        if halo:
             pytest.skip("the halo variants are not persistent")
         monkeypatch.setenv("VC_CONV_SLOTS", str(slots))       # 8 persistent workgroups walk all tiles: the K ring crosses tile boundaries
     cases = [(2, 23, 19, 24, 72, 3, 1, 1, 1, 1), (1, 9, 9, 8, 130, 3, 1, 1, 0, 0), (3, 20, 20, 136, 40, 1, 2, 0, 1, 2)]
-    if cfg >= 28:
+    if halo:
         # halo-staged 3x3 / s1 / p1 variants (bf16 path; Cin a multiple of 32): ragged tiles, patches that cross the batch seam
         # (7x7 and 4x5 maps: one tile spans several images), residual before / after the activation, 2 and 4 channel slices
         cases = [(2, 23, 19, 64, 72, 3, 1, 1, 1, 1), (5, 7, 7, 32, 40, 3, 1, 1, 2, 2), (9, 4, 5, 128, 130, 3, 1, 1, 1, 0),
@@ -99,7 +100,7 @@ def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
         b = rng.standard_normal(Co, dtype=np.float32) * 0.1
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         res = rng.standard_normal((B, Ho, Wo, Co), dtype=np.float32) if rm else None
-        for precision in (("bf16",) if cfg >= 28 else ("bf16", "f32")):
+        for precision in (("bf16",) if halo else ("bf16", "f32")):
             y = E.conv2d(x, w, b, stride=s, pad=p, act=act, res=res, res_mode=rm, precision=precision)
             ref = torch_conv(x, w, b, s, p, act, res, rm, precision)
             if precision == "f32":

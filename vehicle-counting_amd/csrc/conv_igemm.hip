@@ -255,18 +255,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
 template <int BP, int BC, int WP, int WC, int KC, int NS, bool F32>
-__global__ __launch_bounds__(256, 1) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p) {
     constexpr int ES = F32 ? 4 : 2;           // element size
     constexpr int CH = 16 / ES;               // elements per 16-byte chunk
     constexpr int BK = KC * CH;               // K elements per tile
     constexpr int RPI = 64 / KC;              // tile rows covered by one wave-instruction
-    constexpr int PASS = 4 * RPI;             // tile rows covered by one instruction of all four waves
+    constexpr int NW = WP * WC;               // waves per workgroup: 4, or 8 / 16 for the 256-row tiles (configs 40-43)
+    constexpr int PASS = NW * RPI;            // tile rows covered by one instruction of all waves
     constexpr int XI = BP / PASS;             // DMA instructions per thread for the pixel tile
     constexpr int WI = (BC + PASS - 1) / PASS;
     constexpr int WTP = BP / WP, WTC = BC / WC;
     constexpr int PT = WTP / 16, CT = WTC / 16;
     constexpr uint32_t OOB = 0x80000000u;     // beyond every descriptor's num_records -> the load returns 0
-    static_assert(WP * WC == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
     static_assert(BP % PASS == 0 && BC % RPI == 0 && WTP % 16 == 0 && WTC % 16 == 0, "tile shape");
     constexpr int ROWS = BP + WI * PASS;       // rows of one stage: every wave issues the same XI + WI DMA instructions per tile
     constexpr int PER = XI + WI;
@@ -769,21 +770,25 @@ double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * 
 // 64 -> 64 at 25^2 -8 %, 128 -> 128 at 40^2 -10 %; 256 x 64 and 128 x 128 tiles in this arrangement gained nothing)
 #define VC_HALO_CFGS(Y) Y(28, 128, 64, 2, 2, 2) Y(29, 128, 64, 2, 2, 3) Y(30, 128, 128, 2, 2, 2) Y(31, 128, 128, 2, 2, 3) \
                         Y(36, 128, 64, 4, 1, 2) Y(37, 128, 64, 4, 1, 3) Y(38, 256, 128, 4, 1, 2) Y(39, 256, 128, 4, 1, 3)
+// 16-wave workgroups on 256 x 256 tiles: half the staged bytes (and LDS-DMA instructions, ~150 issue cycles each) per MFMA of the
+// 128 x 128 tile and a 3- or 4-deep ring in 96 / 128 KB (measured per 128 frames: 3x3/s2 128->256 at 80^2 213 -> 169 us, 256->512
+// 202 -> 148 us, 1x1 512->512 at 20^2 67 -> 56 us; 256 x 128, 512 x 128 and 512 x 64 tiles with 8 / 16 waves gained nothing)
+#define VC_CONV_BIG_CFGS(X) X(40, 256, 256, 4, 4, 4, 2) X(41, 256, 256, 4, 4, 4, 3) X(42, 256, 256, 4, 4, 4, 4)
 struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
 // weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
 #define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39) and the direct 1x1 (32-35) variants
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 3; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35) and the 16-wave 256 x 256 tiles (40-42)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 template <class K>
-static int resident_workgroups(K kernel) {
+static int resident_workgroups(K kernel, int threads = 256) {
     int per_cu = 0, dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * cus;
 }
 
@@ -802,15 +807,15 @@ static int launch_one(ConvP p, hipStream_t s) {
     // unchanged; 256 free slots cost 9 % of conv time).
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
     if (p.prec == PREC_F32) {
-        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>);
+        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, dim3(grid), dim3(256), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     } else {
-        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>);
+        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, dim3(grid), dim3(256), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     }
     VC_HIP(hipGetLastError());
     return VC_OK;
@@ -890,6 +895,7 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #undef VC_Z
 #define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
         VC_CONV_CFGS(VC_X)
+        VC_CONV_BIG_CFGS(VC_X)
 #undef VC_X
     }
     return VC_ERR_ARG;
