@@ -514,6 +514,7 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
 template <int BP, int BC, int WP, int WC, int NS, int XI>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     constexpr int KC = 4, ES = 2, BK = 32;
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (0)] = wall_clock64(); } while (0);      // diagnostics (VC_CONV_DBG): phase timestamps like conv_igemm_kernel
     constexpr int PASS = 64;                       // weight rows covered by one DMA instruction of all four waves (16 per wave)
     constexpr int WI = (BC + PASS - 1) / PASS;
     constexpr int WROWS = WI * PASS;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
                                                      (int)(ko >= OOB ? OOB : woff[i] + ko), 0, 0, 0);                       \
     }
 
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (1)] = wall_clock64(); } while (0);
     VC_XSTAGE(0, 0);
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) VC_WSTAGE(st, st);
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (2)] = wall_clock64(); } while (0);
     int kt = 0, sbuf = NS - 1;
     uint32_t woffs = wring;                        // LDS address of the weight stage being multiplied
     for (int slice = 0; slice < nslices; ++slice) {
@@ -677,9 +680,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mfma_results_settle<CT * PT>(&acc[0][0]);
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (3)] = wall_clock64(); } while (0);
 #undef VC_XSTAGE
 #undef VC_WSTAGE
     conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (4)] = wall_clock64(); } while (0); }
 }
 
 // ---- 1x1 / stride 1 with the weights in registers (bf16) -------------------------------------------------------------------
