@@ -78,7 +78,6 @@ def main():
     LOOP = math.lcm(CLIP, B)                  # the cycled clip laid out so that every batch is one contiguous run of frames
     if LOOP > CLIP:
         d_frames = d_frames.repeat(LOOP // CLIP, 1, 1, 1)
-    rec = []                                  # (first frame number of the batch, packed rows, frame index per row) per timed step
     ndet_total = [0, 0]
 
     def batch_ptr(i):
@@ -91,13 +90,21 @@ def main():
         rows, fidx, nd = eng.stream_run_packed(trackers, batch_ptr(i), B, H, W)
         if record:
             ndet_total[0] += int(nd.sum()); ndet_total[1] += B
-            rec.append((i * B + 1, rows, fidx))
+            count_rows(i * B + 1, rows, fidx)
+
+    counter = VideoCounting([str(c) for c in range(NC)], ZONE)
+    nrows_total = [0]
+
+    def count_rows(f0, rows, fidx):
+        """VideoCounting's zone filter + per-track lists for one batch, on the host while the GPU works on the next batches."""
+        nrows_total[0] += len(rows)
+        counter.run((f0 + fidx).tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]), finalize=False)
 
     def collect(i, record):
         rows, fidx, nd = eng.stream_collect()
         if record:
             ndet_total[0] += int(nd.sum()); ndet_total[1] += B
-            rec.append((i * B + 1, rows, fidx))
+            count_rows(i * B + 1, rows, fidx)
 
     def run_steps(first, n, record):
         """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker loop of batch
@@ -131,11 +138,8 @@ def main():
     # end of run: per-camera counts (VideoCounting) merged with the one collective of the design
     t_post = time.perf_counter()
     tt = [time.perf_counter()]
-    counter = VideoCounting([str(c) for c in range(NC)], ZONE)
-    all_rows = np.concatenate([r for _, r, _ in rec]) if rec else np.zeros((0, 6), np.int64)
-    all_frames = np.concatenate([f0 + fi for f0, _, fi in rec]) if rec else np.zeros(0, np.int64)
     tt.append(time.perf_counter())
-    td = counter.run(all_frames.tolist(), all_rows[:, 4].tolist(), all_rows[:, 5].tolist(), np.ascontiguousarray(all_rows[:, :4]))
+    td = counter.run([], [], [], np.zeros((0, 4), np.int64))      # every batch was appended as it was collected: directions only
     tt.append(time.perf_counter())
     rows = csv_records(td)
     tt.append(time.perf_counter())
@@ -187,7 +191,7 @@ def main():
             "config": {"workload": "YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])",
                        "frames_per_step": B, "frame_hw": [H, W], "num_classes": NC, "det_per_frame": ndet_total[0] / max(ndet_total[1], 1),
                        "weights": "seeded synthetic (no checkpoints available)", "streams": world,
-                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(len(all_rows)),
+                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(nrows_total[0]),
                        "counting_postpass_ms_total": post_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,

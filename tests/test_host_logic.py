@@ -54,6 +54,31 @@ def test_counting_against_reference_golden(golden_dir, tmp_path):
     assert pc.count_directions(rows, list(g["two_dirs"].keys()), 3) == g["counts"]
 
 
+def test_videocounting_batchwise_equals_one_pass(golden_dir):
+    """VideoCounting.run fed batch by batch (finalize=False, then one finalising call) builds the same track_dict -- keys in the
+    same insertion order, same boxes / frames / directions -- as the reference-style single call over the whole lists."""
+    from vehicle_counting_amd.track import VideoCounting
+    zone = os.path.join(golden_dir, "cam_04_halfres.json")
+    rng = np.random.default_rng(5)
+    n = 600
+    frames = np.sort(rng.integers(1, 60, n)).tolist()
+    tracks = rng.integers(1, 25, n).tolist()
+    labels = rng.integers(0, 3, n).tolist()
+    xy = rng.integers(0, 500, (n, 2))
+    boxes = np.concatenate([xy, xy + rng.integers(5, 80, (n, 2))], 1).astype(np.int64)
+    one = VideoCounting(["a", "b", "c"], zone).run(frames, tracks, labels, boxes)
+    inc = VideoCounting(["a", "b", "c"], zone)
+    for a in range(0, n, 97):
+        inc.run(frames[a:a + 97], tracks[a:a + 97], labels[a:a + 97], boxes[a:a + 97], finalize=False)
+    got = inc.run([], [], [], np.zeros((0, 4), np.int64))
+    assert sum(len(d) for d in one) > 10
+    for d1, d2 in zip(one, got):
+        assert list(d1.keys()) == list(d2.keys())
+        for k in d1:
+            assert d1[k]["frames"] == d2[k]["frames"] and d1[k]["direction"] == d2[k]["direction"]
+            np.testing.assert_array_equal(np.array(d1[k]["boxes"]), np.array(d2[k]["boxes"]))
+
+
 def test_marshal_matches_oracle_and_empty_contract():
     det = np.array([[10.123456789, 20.5, 110.25, 220.125, 0.87654321, 3.0]], np.float32)
     a, b = ImageDetect._marshal(det), oy.marshal_like_reference(det)

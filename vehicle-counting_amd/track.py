@@ -87,13 +87,18 @@ class VideoCounting:
         self.zone_path = zone_path
         self.polygons, self.directions = load_zone_anno(zone_path)
 
-    def run(self, frames, tracks, labels, boxes, output_path=None):
+    def run(self, frames, tracks, labels, boxes, output_path=None, finalize=True):
+        """The reference calls this once per video with the whole lists.  finalize=False only appends the rows (zone filter +
+        per-track lists) so that a stream can be fed batch by batch while the GPU works on the next one; the last call
+        (possibly with empty lists) assigns the directions -- the resulting track_dict is the same as for one call."""
         inside = zone_mask(self.polygons, boxes) if len(boxes) else []
         for keep, frame_id, track_id, label_id, box in zip(inside, frames, tracks, labels, boxes):
             if keep:                                     # check_bbox_intersect_polygon (modules/track.py:104)
                 rec = self.track_dict[label_id].setdefault(track_id, {"boxes": [], "frames": [], "color": ""})
                 rec["boxes"].append(box)
                 rec["frames"].append(frame_id)
+        if not finalize:
+            return self.track_dict
         for label_id in range(self.num_classes):
             for rec in self.track_dict[label_id].values():
                 fb, lb = rec["boxes"][0], rec["boxes"][-1]
