@@ -168,6 +168,7 @@ def main():
     # the stream the kernel is launched on and resolved after the region (the launches overlap with the other two streams, as in
     # the rocprofv3 trace of this command).  The per-stage split comes from two extra steps with blocking events.
     conv_timed = eng.profile_read(L.PROF_CONV)
+    conv_union_ms, conv_span_ms = eng.profile_conv_busy()
     eng.profile(0)
     step(args.warmup + args.steps, False, prefetch=False)       # drain the submission left in flight
     eng.profile(True); eng.profile_reset()
@@ -207,6 +208,7 @@ def main():
                          "achieved_isolated": isolated,
                          "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
                          "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
+                         "conv_running_frac_of_timed_window": conv_union_ms / conv_span_ms if conv_span_ms > 0 else None,
                          "launches_per_step": conv["launches"] / 2.0,
                          "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of 16384 event pairs
                          "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),

@@ -166,6 +166,9 @@ int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int*
 int vc_profile_enable(vc_engine* e, int on);   /* 0 off; 1 blocking events around every launch (serialises the streams);
                                                   2 in-flight event pairs around conv launches only, resolved by vc_profile_read */   /* brackets every launch with hipEvents on its own stream; disables graphs */
 int vc_profile_read(vc_engine* e, int category, double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* After vc_profile_read(VC_PROF_CONV) resolved an in-flight (mode 2) region: milliseconds during which at least one conv kernel was
+ * running, and the window from the first conv start to the last conv stop. */
+int vc_profile_conv_busy(vc_engine* e, double* union_ms, double* span_ms);
 int vc_profile_reset(vc_engine* e);
 int vc_profile_ops(vc_engine* e, char* buf, size_t cap);   /* per-conv-launch lines "conv M= N= K= ... ms= tflops=" recorded while profiling */
 int vc_engine_sync(vc_engine* e);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],
     "vc_profile_enable": [_vp, _i],
+    "vc_profile_conv_busy": [_vp, _pd, _pd],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
     "vc_profile_reset": [_vp],
     "vc_profile_ops": [_vp, C.c_char_p, C.c_size_t],

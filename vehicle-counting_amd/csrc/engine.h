@@ -175,6 +175,7 @@ struct vc_engine {
     struct ProfPair { hipEvent_t a, b; double flops, bytes; };
     std::vector<ProfPair> prof_pairs;
     size_t prof_used = 0;
+    double prof_conv_union_ms = 0, prof_conv_span_ms = 0;     // set when the in-flight pairs are resolved (vc_profile_read)
     vc::ProfCat prof[VC_PROF_NCAT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, int> tuned;            // conv autotune cache: shape signature -> tile config (engine.hip::tune_key)

@@ -964,11 +964,28 @@ int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double
     VC_CHECK(e && cat >= 0 && cat < VC_PROF_NCAT, VC_ERR_ARG, "bad category");
     if (cat == VC_PROF_CONV && e->prof_used > 0) {          // resolve the in-flight pairs into the conv category
         VC_HIP(hipStreamSynchronize(e->dstream)); VC_HIP(hipStreamSynchronize(e->rstream)); VC_HIP(hipStreamSynchronize(e->stream));
+        std::vector<std::pair<float, float>> iv;           // (start, stop) of every launch relative to the first one's start
+        iv.reserve(e->prof_used);
         for (size_t i = 0; i < e->prof_used; ++i) {
-            float t = 0.f;
+            float t = 0.f, t0 = 0.f;
             if (hipEventElapsedTime(&t, e->prof_pairs[i].a, e->prof_pairs[i].b) != hipSuccess) continue;
             ProfCat& c = e->prof[VC_PROF_CONV];
             c.ms += t; c.flops += e->prof_pairs[i].flops; c.bytes += e->prof_pairs[i].bytes; c.launches += 1;
+            if (hipEventElapsedTime(&t0, e->prof_pairs[0].a, e->prof_pairs[i].a) == hipSuccess) iv.emplace_back(t0, t0 + t);
+        }
+        // how much of the wall-clock window between the first start and the last stop had at least one conv kernel running
+        e->prof_conv_union_ms = e->prof_conv_span_ms = 0;
+        if (!iv.empty()) {
+            std::sort(iv.begin(), iv.end());
+            float lo = iv[0].first, hi = iv[0].second, cs = iv[0].first, ce = iv[0].second;
+            double uni = 0;
+            for (size_t i = 1; i < iv.size(); ++i) {
+                lo = std::min(lo, iv[i].first); hi = std::max(hi, iv[i].second);
+                if (iv[i].first > ce) { uni += ce - cs; cs = iv[i].first; ce = iv[i].second; }
+                else ce = std::max(ce, iv[i].second);
+            }
+            uni += ce - cs;
+            e->prof_conv_union_ms = uni; e->prof_conv_span_ms = hi - lo;
         }
         e->prof_used = 0;
     }
@@ -976,6 +993,12 @@ int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double
     if (launches) *launches = e->prof[cat].launches;
     if (flops) *flops = e->prof[cat].flops;
     if (bytes) *bytes = e->prof[cat].bytes;
+    return VC_OK;
+}
+
+int vc_profile_conv_busy(vc_engine* e, double* union_ms, double* span_ms) {
+    VC_CHECK(e && union_ms && span_ms, VC_ERR_ARG, "null argument");
+    *union_ms = e->prof_conv_union_ms; *span_ms = e->prof_conv_span_ms;
     return VC_OK;
 }
 

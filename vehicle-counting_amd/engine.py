@@ -256,6 +256,12 @@ class Engine:
         L.check(L.lib().vc_profile_ops(self._h, buf, len(buf)))
         return buf.value.decode()
 
+    def profile_conv_busy(self):
+        """(union_ms, span_ms) of the conv launches of the last resolved in-flight profiling region."""
+        u, sp = C.c_double(), C.c_double()
+        L.check(L.lib().vc_profile_conv_busy(self._h, C.byref(u), C.byref(sp)))
+        return u.value, sp.value
+
     def profile_read(self, cat):
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         L.check(L.lib().vc_profile_read(self._h, cat, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
