@@ -35,10 +35,11 @@ B = int(os.environ.get("VC_BENCH_B", 128))  # frames per step (one batch of the 
 H = W = 640
 NC = 80
 N_OBJ = 12
-CLIP = 128             # distinct synthetic frames per stream (cycled)
+CLIP = int(os.environ.get("VC_BENCH_CLIP", 512))   # distinct synthetic frames per stream (F = 512), cycled
 ASYNC = os.environ.get("VC_BENCH_ASYNC", "1") != "0"     # tracker loop on the engine's worker thread (vc_stream_run_async)
 TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # HBM3E (MI355X_MICROARCH.md)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
 
 
@@ -56,6 +57,25 @@ def cpu_baseline(ysd, rsd, frames, n_frames):
                       f"NumPy/SciPy DeepSORT), {int(np.mean(nd))} det/frame, {dt:.1f} s"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command under torch.distributed.run with one rank per GPU
+    (127.0.0.1 rendezvous, free port), exactly what the driver's `python -m torch.distributed.run --nproc-per-node N` does.
+    Fails loudly when fewer than N GPUs are visible -- a silent single-rank run would print a meaningless scaling point."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {ndev}; refusing to run fewer ranks", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +85,14 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))            # `python bench.py --gpus N`: become N ranks (one per GPU) over RCCL
     rank, world, local = parallel.init_from_env("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU")
+    ndev = torch.cuda.device_count()
+    if ndev < max(local + 1, 1) or (world > 1 and ndev < world):
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} of {world}, but only {ndev} device(s) are visible (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -180,15 +207,46 @@ def main():
                                                 ("reid_aux", L.PROF_REID_AUX), ("track", L.PROF_TRACK))}
     eng.profile(False)
     isolated = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-    achieved = conv_timed["flops"] / (conv_timed["ms"] * 1e-3) / 1e12 if conv_timed["ms"] > 0 else 0.0
 
     # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
     # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp):
-        with open(tp) as f:
-            traffic = json.load(f)["conv_all"]["hbm_bytes_per_launch"]
+    traffic, traffic_src = None, None
+    for rnd in ("r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                traffic, traffic_src = json.load(f)["conv_all"]["hbm_bytes_per_launch"], f"profiles/{rnd}_pmc_traffic.json"
+            break
+
+    # Roofline of the dominant kernels (all conv launches of a step), SURVEY.md 8(d): bound = whichever of
+    # flops / peak_mfma and bytes / peak_hbm is larger.  Time base = the wall clock of the timed region (ms_per_step): conv
+    # launches of the detector and ReID streams overlap each other, so a sum of per-launch durations counts that time twice
+    # (kept below as achieved_sum_of_overlapped_durations); flops-per-step / ms_per_step can be re-derived from the driver's own
+    # clock and from profiles/ (launches per step x rocprofv3 average duration is <= ms_per_step).
+    step_s = dt / args.steps
+    n_meas_steps = max(conv_timed["launches"] / max(conv["launches"] / 2.0, 1.0), 1e-9)      # timed steps covered by the event pool
+    flops_step, bytes_step = conv_timed["flops"] / n_meas_steps, conv_timed["bytes"] / n_meas_steps
+    mfma_tflops, hbm_gbs = flops_step / step_s / 1e12, bytes_step / step_s / 1e9
+    mfma_frac, hbm_frac = mfma_tflops / PEAK_BF16_TFLOPS, hbm_gbs / PEAK_HBM_GBS
+    overlapped = conv_timed["flops"] / (conv_timed["ms"] * 1e-3) / 1e12 if conv_timed["ms"] > 0 else 0.0
+    hbm_bound = hbm_frac > mfma_frac
+    roofline = {
+        "bound": "hbm" if hbm_bound else "mfma",
+        "achieved": hbm_gbs if hbm_bound else mfma_tflops, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": max(hbm_frac, mfma_frac), "traffic": traffic,
+        "mfma_frac": mfma_frac, "mfma_tflops": mfma_tflops, "hbm_frac": hbm_frac, "hbm_gbs": hbm_gbs,
+        "time_base": "wall clock of the timed region: algorithmic conv work per step / ms_per_step",
+        "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
+        "launches_per_step": conv["launches"] / 2.0,
+        "algorithmic_gflop_per_step": flops_step / 1e9, "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
+        "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),
+        "avg_launch_note": "HIP start/stop timestamps of every conv dispatch of the timed steps (hipExtLaunchKernel); launches of the detector and ReID streams overlap, so launches_per_step x avg_launch_us may exceed ms_per_step",
+        "achieved_sum_of_overlapped_durations_tflops": overlapped, "frac_sum_of_overlapped_durations": overlapped / PEAK_BF16_TFLOPS,
+        "achieved_isolated_tflops": isolated,
+        "conv_running_frac_of_timed_window": conv_union_ms / conv_span_ms if conv_span_ms > 0 else None,
+        "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of event pairs
+        "traffic_note": "HBM bytes per conv launch from %s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes of this command)" % traffic_src,
+    }
 
     if rank == 0:
         out = {
@@ -201,18 +259,7 @@ def main():
                        "weights": "seeded synthetic (no checkpoints available)", "streams": world,
                        "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(nrows_total[0]),
                        "counting_postpass_ms_total": post_ms},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "traffic_note": "bytes per conv launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-                         "achieved_note": "sum of conv FLOPs / sum of conv launch durations over the timed steps (HIP event pairs on the launch stream, kernels of three streams overlapping)",
-                         "achieved_isolated": isolated,
-                         "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
-                         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
-                         "conv_running_frac_of_timed_window": conv_union_ms / conv_span_ms if conv_span_ms > 0 else None,
-                         "launches_per_step": conv["launches"] / 2.0,
-                         "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of 16384 event pairs
-                         "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),
-                         "algorithmic_gflop_per_step": conv["flops"] / 2.0 / 1e9},
+            "roofline": roofline,
             "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

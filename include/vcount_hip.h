@@ -83,6 +83,9 @@ int vc_engine_destroy(vc_engine* e);
 int vc_engine_param_count(const vc_engine* e, int net, int* n);
 int vc_engine_param_info(const vc_engine* e, int net, int index, char* name, int name_cap, int dims[4] /* O,I,kh,kw */);
 int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w_oihw, const float* bias);
+/* Detect anchors in pixels, 3 levels x 3 anchors x (w, h) = `model.24.anchors * stride` of an ultralytics checkpoint (custom
+ * weights loaded by /root/reference/networks/yolo.py:58 may carry autoanchor values).  Default: the COCO set of yolov5{s,m,l}.yaml. */
+int vc_engine_set_anchors(vc_engine* e, const float* anchors18);
 int vc_engine_finalize(vc_engine* e); /* packs + uploads weights; detector/ReID calls are valid afterwards */
 
 /* ---- detect: ImageDetect.run ------------------------------------------------------------------ */

@@ -89,3 +89,53 @@ def test_reid_ckpt_t7(tmp_path):
     assert set(got) == set(sd)
     for k in sd:
         np.testing.assert_array_equal(got[k], sd[k].float().numpy())
+
+
+def test_detect_anchors_travel_with_the_checkpoint(tmp_path):
+    """Custom (autoanchor) checkpoints carry their own Detect anchors: `model.24.anchors` is in stride units."""
+    nc = 8
+    model, _ = _build_fake_upstream_model(nc, 4)
+    det = model._modules["model"]._modules["24"]
+    anchors_px = np.array([[9, 11, 21, 19, 17, 41], [43, 32, 39, 70, 86, 64], [65, 131, 134, 130, 300, 290]], np.float32)
+    det.register_buffer("anchors", torch.from_numpy(anchors_px.reshape(3, 3, 2) / np.array([8, 16, 32], np.float32)[:, None, None]))
+    path = tmp_path / "custom.pt"
+    torch.save({"model": model}, path)
+    for m in ("models", "models.common", "models.yolo"):
+        sys.modules.pop(m)
+    sd = load_yolov5_checkpoint(path, "yolov5s")
+    np.testing.assert_allclose(sd["model.24.anchors_px"], anchors_px, rtol=1e-6)
+
+
+class _Hostile:
+    def __reduce__(self):
+        import builtins
+        return (builtins.eval, ("__import__('os').environ.__setitem__('VC_PWNED', '1')",))
+
+
+def test_hostile_pickle_does_not_execute(tmp_path):
+    """builtins.eval / exec / getattr, os.system, torch.hub.load are not on the allowlist: they resolve to inert stubs."""
+    import os
+    import pickle
+    from vehicle_counting_amd.checkpoint import _StubUnpickler, _allowed
+    for mod, name in (("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("os", "system"), ("posix", "system"),
+                      ("torch.hub", "load"), ("subprocess", "Popen"), ("torch", "load"), ("numpy", "load")):
+        assert not _allowed(mod, name), (mod, name)
+    for mod, name in (("collections", "OrderedDict"), ("torch._utils", "_rebuild_tensor_v2"), ("torch", "HalfStorage"),
+                      ("torch", "float16"), ("torch.nn.modules.conv", "Conv2d"), ("builtins", "set")):
+        assert _allowed(mod, name), (mod, name)
+    path = tmp_path / "evil.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"model": _Hostile()}, f)
+    os.environ.pop("VC_PWNED", None)
+    with open(path, "rb") as f:
+        obj = _StubUnpickler(f).load()
+    assert "VC_PWNED" not in os.environ
+    assert isinstance(obj["model"], torch.nn.Module)             # the eval call became the construction of a stub module
+
+
+def test_imagedetect_refuses_to_run_without_weights():
+    import types
+    from vehicle_counting_amd.detect import ImageDetect
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    with pytest.raises(ValueError, match="no --weight"):
+        ImageDetect(types.SimpleNamespace(weight=None, mapping=None), cfg)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vc_engine_param_count": [_vp, _i, _pi],
     "vc_engine_param_info": [_vp, _i, _i, C.c_char_p, _i, _pi],
     "vc_engine_set_param": [_vp, _i, C.c_char_p, _pf, _pf],
+    "vc_engine_set_anchors": [_vp, _pf],
     "vc_engine_finalize": [_vp],
     "vc_engine_sync": [_vp],
     "vc_detect": [_vp, _P(_vp), _pi, _pi, _i, _pf, _pi],

@@ -17,17 +17,48 @@ import torch
 
 from .weights import fold_yolo_state_dict, yolo_conv_table
 
-_SAFE_PREFIXES = ("torch", "collections", "numpy", "builtins", "__builtin__", "_codecs", "copy_reg", "copyreg")
+# Exact globals a tensor / state_dict / nn.Module pickle needs.  Everything else -- including builtins.eval / exec / getattr,
+# torch.hub.load, os.system ... -- is NOT resolved: it becomes an inert stub class, so a crafted checkpoint cannot run code.
+_BUILTIN_OK = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice",
+               "range", "object"}
+_EXACT_OK = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("_codecs", "encode"),
+    ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"),
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch", "Tensor"), ("torch", "Size"), ("torch", "device"),
+    ("torch.serialization", "_get_layout"), ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"),
+    ("torch.storage", "TypedStorage"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+}
+
+
+def _allowed(module, name):
+    if module in ("builtins", "__builtin__"):
+        return name in _BUILTIN_OK
+    if (module, name) in _EXACT_OK:
+        return True
+    if module == "torch":                                   # dtypes (torch.float16, ...) and the legacy typed storages
+        return name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)
+    if module.startswith("torch.nn.modules."):             # plain layers (Conv2d, BatchNorm2d, SiLU, Sequential, ...): classes only
+        import importlib
+        try:
+            obj = getattr(importlib.import_module(module), name, None)
+        except ImportError:
+            return False
+        return isinstance(obj, type) and issubclass(obj, torch.nn.Module)
+    return False
 
 
 class _StubUnpickler(pickle.Unpickler):
-    """Resolves torch / numpy / stdlib globals normally; anything else (models.yolo.Model, models.common.Conv, ...) becomes
-    an attribute-bag nn.Module subclass named after the original class."""
+    """Resolves only the allowlisted torch / numpy / stdlib globals above; anything else (models.yolo.Model,
+    models.common.Conv, ... and anything hostile) becomes an attribute-bag nn.Module subclass named after the original."""
 
     _made = {}
 
     def find_class(self, module, name):
-        if module.split(".")[0] in _SAFE_PREFIXES:
+        if _allowed(module, name):
             return super().find_class(module, name)          # incl. the protocol-2 names (__builtin__.set, copy_reg, ...)
         key = (module, name)
         if key not in self._made:
@@ -58,7 +89,15 @@ def load_yolov5_checkpoint(path, variant="yolov5s", nc=None):
     ck = torch.load(path, map_location="cpu", pickle_module=_StubPickle, weights_only=False)
     if isinstance(ck, dict) and ("model" in ck or "ema" in ck):
         ck = ck.get("ema") or ck["model"]
-    sd = fold_yolo_state_dict(_state_dict_of(ck))
+    raw = _state_dict_of(ck)
+    sd = fold_yolo_state_dict(raw)
+    # Detect anchors: `anchors` is stored in stride units (models/yolo.py::Detect divides by the stride at build time); v6.0 also
+    # keeps `anchor_grid` in pixels.  Custom (autoanchor) checkpoints differ from the COCO defaults, so they travel with the weights.
+    if "model.24.anchor_grid" in raw and np.asarray(raw["model.24.anchor_grid"]).size == 18:
+        sd["model.24.anchors_px"] = np.asarray(raw["model.24.anchor_grid"], np.float32).reshape(3, 6)
+    elif "model.24.anchors" in raw:
+        sd["model.24.anchors_px"] = (np.asarray(raw["model.24.anchors"], np.float32).reshape(3, 3, 2) *
+                                     np.array([8.0, 16.0, 32.0], np.float32)[:, None, None]).reshape(3, 6)
     if nc is None:
         nc = sd["model.24.m.0.weight"].shape[0] // 3 - 5
     for name, ci, co, k in yolo_conv_table(variant, nc):

@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int max_det
         for (int w = (i >> 6) + lane; w < nw; w += blockDim.x) removed[w] |= mrow[w];
         __syncthreads();
     }
-    if (lane == 0) pb.det_count[b] = kept;
+    // more candidates passed the confidence test than max_candidates holds: which ones reached NMS depended on atomicAdd arrival
+    // order, so the frame's result is not the reference's -- reported as a negative count (the host turns it into VC_ERR_CAPACITY)
+    if (lane == 0) pb.det_count[b] = pb.overflow[b] ? -1 : kept;
 }
 
 int launch_decode(const DecodeLevel* lv, int nlv, int B, int nc, float conf, int max_cand, DetectPostBuffers& pb, float* pred_debug,

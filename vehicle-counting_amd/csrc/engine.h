@@ -90,6 +90,7 @@ struct vc_engine {
     uint8_t* d_frames = nullptr;                 // staging for host images / stream frames
     size_t d_frames_bytes = 0;
     float* d_logits[3] = {nullptr, nullptr, nullptr};
+    float anchors[3][6];                         // Detect anchors in pixels (default: the COCO set of yolov5{s,m,l}.yaml)
     vc::DetectPostBuffers post{};
     float* d_geom = nullptr;                     // [max_batch][5] gain, padw, padh, src_w, src_h
     float* d_pred_debug = nullptr;

@@ -484,7 +484,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     for (int i = 0; i < 3; ++i) {
         lv[i].logits = e->d_logits[i]; lv[i].bf16 = e->prec == PREC_F32 ? 0 : 1; lv[i].ny = nh / strides[i]; lv[i].nx = nw / strides[i]; lv[i].cs = lcs;
         lv[i].stride = (float)strides[i];
-        for (int a = 0; a < 3; ++a) { lv[i].anchor_w[a] = kAnchors[i][2 * a]; lv[i].anchor_h[a] = kAnchors[i][2 * a + 1]; }
+        for (int a = 0; a < 3; ++a) { lv[i].anchor_w[a] = e->anchors[i][2 * a]; lv[i].anchor_h[a] = e->anchors[i][2 * a + 1]; }
         lv[i].base = base;
         base += 3 * lv[i].ny * lv[i].nx;
     }
@@ -650,6 +650,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     vc_engine* e = new vc_engine();
     e->cfg = *cfg;
     e->prec = cfg->precision;
+    memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
     do {
         // the tracker's kernels are tiny and latency-critical (the host waits on them every frame): highest priority,
@@ -760,6 +761,15 @@ int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w,
     return VC_OK;
 }
 
+// Detect anchors in pixels, [level P3,P4,P5][anchor][w,h] (ultralytics `model.24.anchors * stride`).  Custom-trained checkpoints
+// (the reference loads 'custom' weights, /root/reference/networks/yolo.py:58) may carry autoanchor-evolved values.
+int vc_engine_set_anchors(vc_engine* e, const float* anchors18) {
+    VC_CHECK(e && anchors18, VC_ERR_ARG, "null argument");
+    for (int i = 0; i < 18; ++i) VC_CHECK(anchors18[i] > 0.f && anchors18[i] < 1e5f, VC_ERR_ARG, "anchor %d = %g is not a positive pixel size", i, (double)anchors18[i]);
+    memcpy(e->anchors, anchors18, 18 * sizeof(float));
+    return VC_OK;
+}
+
 int vc_engine_finalize(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_CHECK(!e->finalized, VC_ERR_STATE, "engine already finalized");
@@ -831,6 +841,9 @@ int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* 
     VC_HIP(hipMemcpyAsync(e->h_det, e->post.det, (size_t)n * md * 6 * sizeof(float), hipMemcpyDeviceToHost, e->dstream));
     VC_HIP(hipMemcpyAsync(e->h_det_count, e->post.det_count, n * sizeof(int), hipMemcpyDeviceToHost, e->dstream));
     VC_HIP(hipStreamSynchronize(e->dstream));
+    for (int i = 0; i < n; ++i)
+        VC_CHECK(e->h_det_count[i] >= 0, VC_ERR_CAPACITY, "image %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates "
+                 "(upstream keeps up to max_nms = 30000)", i, e->cfg.max_candidates);
     memcpy(out_det, e->h_det, (size_t)n * md * 6 * sizeof(float));
     memcpy(out_count, e->h_det_count, n * sizeof(int));
     return VC_OK;

@@ -102,6 +102,8 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
     pd.fd.assign(b, FrameDets{});
     pd.row0.assign(b, 0);
     for (int f = 0; f < b; ++f) {
+        VC_CHECK(h_cnt[f] >= 0, VC_ERR_CAPACITY, "frame %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates", f,
+                 e->cfg.max_candidates);
         if (e->inject_b > 0) {
             const int fi = f % e->inject_b;
             marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], pd.fd[f]);
@@ -452,7 +454,7 @@ int vc_nms_host(const float* boxes4, const float* conf, const int* cls, int n, f
     if (st == VC_OK) st = launch_nms(1, max_cand, max_det, iou, geom, pb, nullptr);
     if (st == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("nms kernels failed: %s", hipGetErrorString(hipGetLastError())); st = VC_ERR_HIP; }
     if (st == VC_OK) {
-        if (hipMemcpy(out_n, pb.det_count, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        if (hipMemcpy(out_n, pb.det_count, 4, hipMemcpyDeviceToHost) != hipSuccess || *out_n < 0 ||
             hipMemcpy(out6, pb.det, (size_t)std::min(*out_n, max_det) * 24, hipMemcpyDeviceToHost) != hipSuccess) { set_error("download failed"); st = VC_ERR_HIP; }
     }
     for (void* q : tmp.allocs) (void)hipFree(q);

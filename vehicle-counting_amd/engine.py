@@ -35,6 +35,9 @@ class Engine:
         L.check(lib.vc_engine_create(C.byref(cfg), C.byref(self._h)))
         if yolo_sd is not None:
             self._upload(L.NET_YOLO, lambda n: (yolo_sd[n + ".weight"], yolo_sd[n + ".bias"]))
+            if "model.24.anchors_px" in yolo_sd:             # checkpoint.load_yolov5_checkpoint: Detect anchors x stride (pixels)
+                a = L.f32(yolo_sd["model.24.anchors_px"]).reshape(18)
+                L.check(lib.vc_engine_set_anchors(self._h, L.ptr(a, C.c_float)))
         if reid_sd is not None:
             folded = fold_reid(reid_sd)
             self._upload(L.NET_REID, lambda n: folded[n])

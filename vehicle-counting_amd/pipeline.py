@@ -38,8 +38,11 @@ class FrameSource:
 
 
 class CountingPipeline:
-    def __init__(self, args, config, cam_config, engine=None, class_names=None):
-        self.detector = ImageDetect(args, config, engine=engine, class_names=class_names)
+    def __init__(self, args, config, cam_config, engine=None, class_names=None, synthetic=False):
+        # the ReID checkpoint of the reference's cam_configs.yaml (`checkpoint: .../ckpt.t7`, handed to every DeepSort at
+        # modules/__init__.py:36) becomes the engine's ReID parameters -- one engine owns both networks
+        ck = cam_config.get("checkpoint") if isinstance(cam_config, dict) else getattr(cam_config, "checkpoint", None)
+        self.detector = ImageDetect(args, config, engine=engine, class_names=class_names, synthetic=synthetic, reid_checkpoint=ck)
         self.engine = self.detector.engine
         self.class_names = self.detector.class_names
         self.saved_path = getattr(args, "output_path", None)
