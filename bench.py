@@ -102,7 +102,7 @@ def main():
                    max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
     eng.pretune((32, 64, 128, 256, 512, 1024, 2048, 4096))                      # conv autotune for every ReID size bucket
     trackers = [eng.tracker_create(**TRACK) for _ in range(NC)]
-    frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank)          # one camera stream per rank
+    frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank, bounce=True)          # one camera stream per rank
     d_frames = torch.from_numpy(frames).to(dev)                                 # resident in HBM before the timed region
     LOOP = math.lcm(CLIP, B)                  # the cycled clip laid out so that every batch is one contiguous run of frames
     if LOOP > CLIP:

@@ -1,0 +1,352 @@
+// Control logic of one DeepSORT tracker step, written once for the device (track_kernels.hip: executed by wavefront 0 of the
+// tracker's workgroup, data in LDS) and for the host build the CPU tests compile (tests/native/track_core_host.cpp, one "lane").
+//
+// Reference (paths relative to /root/reference/networks/deepsort/sort/):
+//   linear_assignment.py:13-77   min_cost_matching  (clamp > max to max + 1e-5, rectangular LSA, reject > max)
+//   linear_assignment.py:80-145  matching_cascade   (levels = time_since_update - 1; gate already folded into the cost rows)
+//   tracker.py:93-131            Tracker._match     (cascade on confirmed tracks, IoU stage on the rest)
+//   tracker.py:58-91             Tracker.update     (update / mark_missed / _initiate_track, drop deleted, gallery bookkeeping)
+//   track.py:112-153             Track.predict counters, update, mark_missed (the FSM)
+//   scipy.optimize.linear_sum_assignment (third-party: Crouse's rectangular shortest augmenting path, restated in lsap_core with
+//   its tie-breaking -- pinned by tests/test_cabi.py::test_lap_matches_scipy_including_ties on 1500 matrices)
+//
+// Execution model: every lane of the cooperating group runs the same control flow on the same (uniform) values -- scalars live in
+// registers, lists in LDS -- and only the loops marked "parallel" split their index range over the lanes.  A store of a uniform
+// value by all lanes is harmless; read-modify-write of shared words is done by lane 0.  wave_sync() orders one parallel section
+// against the next.  On the host there is one lane and every helper degenerates to the plain serial loop.
+#pragma once
+#include <limits.h>
+
+#include "track_math.h"
+
+namespace vc {
+namespace tc {
+
+enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
+enum { TERR_NONE = 0, TERR_TRACK_CAP = 1, TERR_POOL = 2, TERR_ROWS = 3, TERR_LAP = 4 };
+
+struct TrackRecD { long long id; int state, hits, age, tsu, gal_count, gal_head; };                       // per pool slot, 32 B
+struct TrackerHdr { double max_dist, max_iou_distance; long long next_id; int max_age, n_init, nn_budget, n_tracks, err, pad; };   // 48 B
+
+struct Lanes { int lane, n; };
+
+VC_HD void wave_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+VC_HD int imin(int a, int b) { return a < b ? a : b; }
+VC_HD int imax(int a, int b) { return a > b ? a : b; }
+
+VC_HD int wave_max(Lanes L, int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 1; o < 64; o <<= 1) x = imax(x, __shfl_xor(x, o));
+#endif
+    (void)L;
+    return x;
+}
+
+// out positions of the indices i in [0, n) with flag(i), ascending: store(position, i) is called once per kept index; returns the
+// count.  Device: ballot + popcount prefix per 64 indices (the group is one full wavefront).
+template <class F, class S>
+VC_HD int compact(Lanes L, int n, F flag, S store) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + L.lane;
+        const bool f = i < n && flag(i);
+        const unsigned long long m = __ballot(f);
+        if (f) store(base + __popcll(m & ((1ull << L.lane) - 1ull)), i);
+        base += __popcll(m);
+    }
+    return base;
+#else
+    (void)L;
+    int c = 0;
+    for (int i = 0; i < n; ++i)
+        if (flag(i)) store(c++, i);
+    return c;
+#endif
+}
+
+// ---- rectangular linear sum assignment -----------------------------------------------------------------------------------
+// The inner scan of SciPy's augmenting-path search picks, over the remaining columns in list order,
+//     if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+// i.e. the minimum; among equal minima the LAST unassigned column of the list if there is one, else the FIRST column.  That is
+// the maximum of a total order on (value, unassigned, list position), so the scan can be split over lanes and merged in any order.
+struct Best { double v; int un; int it; };
+VC_HD bool better(const Best& a, const Best& b) {
+    if (a.v < b.v) return true;
+    if (a.v > b.v) return false;
+    if (a.un != b.un) return a.un > b.un;
+    return a.un ? a.it > b.it : a.it < b.it;
+}
+VC_HD Best wave_best(Lanes L, Best x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 1; o < 64; o <<= 1) {
+        Best y;
+        y.v = __shfl_xor(x.v, o); y.un = __shfl_xor(x.un, o); y.it = __shfl_xor(x.it, o);
+        if (better(y, x)) x = y;
+    }
+#endif
+    (void)L;
+    return x;
+}
+
+struct LapWork { double *u, *v, *spc; int *path, *row4col, *remaining, *col4row; unsigned char *SR, *SC; };
+
+// nr <= nc.  cost row-major [nr][nc].  Result in w.col4row[0..nr).  Returns 0, or -1 for an infeasible matrix.
+VC_HD int lsap_core(Lanes L, int nr, int nc, const double* cost, const LapWork& w) {
+    const double INF = (double)INFINITY;
+    for (int i = L.lane; i < nr; i += L.n) { w.u[i] = 0.0; w.col4row[i] = -1; }
+    for (int j = L.lane; j < nc; j += L.n) { w.v[j] = 0.0; w.path[j] = -1; w.row4col[j] = -1; }
+    wave_sync();
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0;
+        int i = cur, num_remaining = nc, sink = -1;
+        for (int it = L.lane; it < nc; it += L.n) { w.remaining[it] = nc - it - 1; w.SC[it] = 0; w.spc[it] = INF; }
+        for (int r = L.lane; r < nr; r += L.n) w.SR[r] = 0;
+        wave_sync();
+        while (sink == -1) {
+            w.SR[i] = 1;
+            const double ui = w.u[i];
+            Best b = {INF, 0, INT_MAX};
+            for (int it = L.lane; it < num_remaining; it += L.n) {               // parallel
+                const int j = w.remaining[it];
+                const double r = minVal + cost[(size_t)i * nc + j] - ui - w.v[j];
+                double s = w.spc[j];
+                if (r < s) { w.path[j] = i; w.spc[j] = r; s = r; }
+                const Best c = {s, w.row4col[j] == -1 ? 1 : 0, it};
+                if (better(c, b)) b = c;
+            }
+            b = wave_best(L, b);
+            wave_sync();
+            minVal = b.v;
+            if (minVal == INF) return -1;
+            const int index = b.it;
+            const int j = w.remaining[index];
+            const int rj = w.row4col[j];
+            const int last = w.remaining[num_remaining - 1];
+            --num_remaining;
+            wave_sync();                                   // every lane has read remaining[index] and the tail entry
+            if (rj == -1) sink = j; else i = rj;
+            w.SC[j] = 1;
+            w.remaining[index] = last;
+            wave_sync();
+        }
+        if (L.lane == 0) w.u[cur] += minVal;
+        for (int r = L.lane; r < nr; r += L.n)
+            if (w.SR[r] && r != cur) w.u[r] += minVal - w.spc[w.col4row[r]];
+        for (int j = L.lane; j < nc; j += L.n)
+            if (w.SC[j]) w.v[j] -= minVal - w.spc[j];
+        wave_sync();
+        int j = sink;                                      // augment along the alternating path (uniform, serial)
+        while (true) {
+            const int r = w.path[j];
+            const int prev = w.col4row[r];
+            wave_sync();
+            if (L.lane == 0) { w.row4col[j] = r; w.col4row[r] = j; }
+            j = prev;
+            if (r == cur) break;
+        }
+        wave_sync();
+    }
+    return 0;
+}
+
+// per-step work arrays (LDS on the device), each with room for `cap` entries
+struct StepWork {
+    int cap;
+    int *slot, *state, *tsu, *galc, *galh;                        // per live track (list position t)
+    int *confirmed, *unconfirmed, *left, *rows, *un_rows, *un_cols, *un_tracks, *match_t, *match_d, *ri, *ci, *newslot;
+    unsigned char *row_used, *col_used, *matched;
+    LapWork lap;
+};
+
+// bytes of one StepWork with capacity cap (all arrays 8-byte aligned: cap is a multiple of 8)
+VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (5 + 12 + 4) + 8 * 3 + 5); }
+
+VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
+    char* p = (char*)base;
+    w.cap = cap;
+    auto D = [&](double*& q) { q = (double*)p; p += (size_t)cap * 8; };
+    auto I = [&](int*& q) { q = (int*)p; p += (size_t)cap * 4; };
+    auto B = [&](unsigned char*& q) { q = (unsigned char*)p; p += (size_t)cap; };
+    D(w.lap.u); D(w.lap.v); D(w.lap.spc);
+    I(w.lap.path); I(w.lap.row4col); I(w.lap.remaining); I(w.lap.col4row);
+    I(w.slot); I(w.state); I(w.tsu); I(w.galc); I(w.galh);
+    I(w.confirmed); I(w.unconfirmed); I(w.left); I(w.rows); I(w.un_rows); I(w.un_cols); I(w.un_tracks); I(w.match_t); I(w.match_d);
+    I(w.ri); I(w.ci); I(w.newslot);
+    B(w.lap.SR); B(w.lap.SC); B(w.row_used); B(w.col_used); B(w.matched);
+}
+
+// scipy.optimize.linear_sum_assignment on c [nr][nc]: pairs (ri[k], ci[k]) sorted by row; returns their number (min(nr, nc)).
+VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc, double* tbuf, int& err) {
+    if (nc < nr) {                                           // SciPy transposes so that rows <= columns
+        for (int e = L.lane; e < nr * nc; e += L.n) {       // parallel
+            const int i = e / nc, j = e - i * nc;
+            tbuf[(size_t)j * nr + i] = c[e];
+        }
+        wave_sync();
+        if (lsap_core(L, nc, nr, tbuf, w.lap) != 0) { err = TERR_LAP; return 0; }
+        int* r2c = w.lap.path;                               // free again after the solve: original row -> original column
+        for (int i = L.lane; i < nr; i += L.n) r2c[i] = -1;
+        wave_sync();
+        for (int v = L.lane; v < nc; v += L.n) r2c[w.lap.col4row[v]] = v;
+        wave_sync();
+        const int np = compact(L, nr, [&](int i) { return r2c[i] >= 0; }, [&](int pos, int i) { w.ri[pos] = i; w.ci[pos] = r2c[i]; });
+        wave_sync();
+        return np;
+    }
+    if (lsap_core(L, nr, nc, c, w.lap) != 0) { err = TERR_LAP; return 0; }
+    for (int i = L.lane; i < nr; i += L.n) { w.ri[i] = i; w.ci[i] = w.lap.col4row[i]; }
+    wave_sync();
+    return nr;
+}
+
+// linear_assignment.py:52-77 on the sub-matrix cost[rows[i] * ld + cols[j]].  Accepted pairs are appended to match_t / match_d
+// (n_match advances); unmatched rows / columns go to un_rows / un_cols in the reference's list order (unassigned ones first,
+// in index order, then the rejected pairs in row order).
+VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr, const int* cols, int nc, const double* cost, int ld,
+                             double max_cost, double* cbuf, double* tbuf, int& n_match, int* un_rows, int& n_ur, int* un_cols, int& n_uc,
+                             int& err) {
+    if (nr == 0 || nc == 0) {
+        for (int i = L.lane; i < nr; i += L.n) un_rows[i] = rows[i];
+        for (int j = L.lane; j < nc; j += L.n) un_cols[j] = cols[j];
+        n_ur = nr; n_uc = nc;
+        wave_sync();
+        return;
+    }
+    for (int e = L.lane; e < nr * nc; e += L.n) {           // parallel gather + clamp
+        const int i = e / nc, j = e - i * nc;
+        const double v = cost[(size_t)rows[i] * ld + cols[j]];
+        cbuf[e] = v > max_cost ? max_cost + 1e-5 : v;
+    }
+    for (int i = L.lane; i < nr; i += L.n) w.row_used[i] = 0;
+    for (int j = L.lane; j < nc; j += L.n) w.col_used[j] = 0;
+    wave_sync();
+    const int np = lap_solve(L, w, cbuf, nr, nc, tbuf, err);
+    for (int k = L.lane; k < np; k += L.n) { w.row_used[w.ri[k]] = 1; w.col_used[w.ci[k]] = 1; }
+    wave_sync();
+    n_uc = compact(L, nc, [&](int j) { return !w.col_used[j]; }, [&](int pos, int j) { un_cols[pos] = cols[j]; });
+    n_ur = compact(L, nr, [&](int i) { return !w.row_used[i]; }, [&](int pos, int i) { un_rows[pos] = rows[i]; });
+    auto rejected = [&](int k) { return cbuf[(size_t)w.ri[k] * nc + w.ci[k]] > max_cost; };
+    const int nrej = compact(L, np, rejected, [&](int pos, int k) { un_rows[n_ur + pos] = rows[w.ri[k]]; un_cols[n_uc + pos] = cols[w.ci[k]]; });
+    const int nacc = compact(L, np, [&](int k) { return !rejected(k); },
+                             [&](int pos, int k) { w.match_t[n_match + pos] = rows[w.ri[k]]; w.match_d[n_match + pos] = cols[w.ci[k]]; });
+    n_ur += nrej; n_uc += nrej; n_match += nacc;
+    wave_sync();
+}
+
+// Tracker._match on the step's cost rows (cost_app: gated appearance rows of the confirmed tracks, cost_iou: IoU rows of the IoU
+// candidates; both [T][D], rows of other tracks are never read).  Outputs: matches in w.match_t / w.match_d, missed tracks in
+// w.un_tracks, the detections that start new tracks in *newdets (one of w.left / w.un_cols), all in the reference's list order.
+VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, int D, const double* cost_app, const double* cost_iou,
+                      double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err) {
+    const int n_conf = compact(L, T, [&](int t) { return w.state[t] == CONFIRMED; }, [&](int pos, int t) { w.confirmed[pos] = t; });
+    const int n_unconf = compact(L, T, [&](int t) { return w.state[t] != CONFIRMED; }, [&](int pos, int t) { w.unconfirmed[pos] = t; });
+    int mt = 0;
+    for (int t = L.lane; t < T; t += L.n) { w.matched[t] = 0; if (w.state[t] == CONFIRMED) mt = imax(mt, w.tsu[t]); }
+    const int max_tsu = wave_max(L, mt);
+    for (int d = L.lane; d < D; d += L.n) w.left[d] = d;
+    wave_sync();
+    int* left = w.left;
+    int* other = w.un_cols;
+    int n_left = D;
+    n_match = 0;
+    // matching_cascade: level = time_since_update - 1, most recently seen tracks first (levels above the oldest track are empty)
+    for (int level = 0; level < h.max_age && level < max_tsu; ++level) {
+        if (n_left == 0) break;
+        const int nl = compact(L, n_conf, [&](int q) { return w.tsu[w.confirmed[q]] == 1 + level; }, [&](int pos, int q) { w.rows[pos] = w.confirmed[q]; });
+        if (nl == 0) continue;
+        wave_sync();
+        const int m0 = n_match;
+        int n_ur = 0, n_uc = 0;
+        min_cost_matching(L, w, w.rows, nl, left, n_left, cost_app, D, h.max_dist, cbuf, tbuf, n_match, w.un_rows, n_ur, other, n_uc, err);
+        for (int k = m0 + L.lane; k < n_match; k += L.n) w.matched[w.match_t[k]] = 1;
+        int* sw = left; left = other; other = sw;
+        n_left = n_uc;
+        wave_sync();
+    }
+    // IoU stage (tracker.py:118-127): unconfirmed tracks + confirmed tracks that were missed for exactly one frame
+    for (int q = L.lane; q < n_unconf; q += L.n) w.rows[q] = w.unconfirmed[q];
+    const int n_recent = compact(L, n_conf, [&](int q) { const int t = w.confirmed[q]; return !w.matched[t] && w.tsu[t] == 1; },
+                                 [&](int pos, int q) { w.rows[n_unconf + pos] = w.confirmed[q]; });
+    n_un = compact(L, n_conf, [&](int q) { const int t = w.confirmed[q]; return !w.matched[t] && w.tsu[t] != 1; },
+                   [&](int pos, int q) { w.un_tracks[pos] = w.confirmed[q]; });
+    wave_sync();
+    int n_ur = 0, n_uc = 0;
+    min_cost_matching(L, w, w.rows, n_unconf + n_recent, left, n_left, cost_iou, D, h.max_iou_distance, cbuf, tbuf, n_match, w.un_rows, n_ur, other,
+                      n_uc, err);
+    for (int k = L.lane; k < n_ur; k += L.n) w.un_tracks[n_un + k] = w.un_rows[k];
+    n_un += n_ur;
+    newdets = other;
+    n_new = n_uc;
+    wave_sync();
+}
+
+// Track.update / mark_missed / _initiate_track bookkeeping + Tracker.update's list maintenance, after the Kalman and gallery
+// writes of the step have been applied to the pool.  Survivors keep their order, new tracks are appended in `newdets` order with
+// consecutive ids.  Deleted slots are handed to free_slot(slot).  Returns the number of live tracks.
+template <class FreeSlot>
+VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, TrackRecD* recs, int T, int n_match, int n_un, int n_new,
+                      FreeSlot free_slot) {
+    const TrackerHdr h = *hdr;
+    for (int k = L.lane; k < n_match; k += L.n) {            // Track.update (track.py:126-145); a track is matched at most once
+        const int t = w.match_t[k];
+        TrackRecD& r = recs[w.slot[t]];
+        r.hits += 1;
+        w.tsu[t] = 0;
+        w.galh[t] = (w.galh[t] + 1) % h.nn_budget;
+        w.galc[t] = imin(w.galc[t] + 1, h.nn_budget);
+        if (w.state[t] == TENTATIVE && r.hits >= h.n_init) w.state[t] = CONFIRMED;
+    }
+    for (int k = L.lane; k < n_un; k += L.n) {               // Track.mark_missed (track.py:147-153)
+        const int t = w.un_tracks[k];
+        if (w.state[t] == TENTATIVE) w.state[t] = DELETED;
+        else if (w.tsu[t] > h.max_age) w.state[t] = DELETED;
+    }
+    wave_sync();
+    for (int t = L.lane; t < T; t += L.n) {                  // write the counters back (age and time_since_update were advanced at load)
+        TrackRecD& r = recs[w.slot[t]];
+        r.state = w.state[t]; r.tsu = w.tsu[t]; r.gal_count = w.galc[t]; r.gal_head = w.galh[t];
+    }
+    const int n_surv = compact(L, T, [&](int t) { return w.state[t] != DELETED; }, [&](int pos, int t) { list[pos] = w.slot[t]; });
+    for (int t = 0; t < T; ++t)                              // uniform: deletions are rare
+        if (w.state[t] == DELETED) free_slot(w.slot[t]);
+    for (int i = L.lane; i < n_new; i += L.n) {              // _initiate_track (tracker.py:133-139)
+        TrackRecD r;
+        r.id = h.next_id + i; r.state = TENTATIVE; r.hits = 1; r.age = 1; r.tsu = 0; r.gal_count = 1; r.gal_head = 1 % h.nn_budget;
+        recs[w.newslot[i]] = r;
+        list[n_surv + i] = w.newslot[i];
+    }
+    if (L.lane == 0) { hdr->n_tracks = n_surv + n_new; hdr->next_id = h.next_id + n_new; }
+    wave_sync();
+    return n_surv + n_new;
+}
+
+// deep_sort.py:46-58 + 97-108: rows [x1, y1, x2, y2, id, label] of the confirmed tracks seen within the last frame (box = Kalman
+// posterior, int() truncation, clamped to the frame), in list order.  emit(position, row6) receives them; returns the count.
+template <class Emit>
+VC_HD int emit_rows(Lanes L, const int* list, const TrackRecD* recs, const double* mean_pool, int n_tracks, int W, int H, int label, Emit emit) {
+    return compact(L, n_tracks, [&](int t) { const TrackRecD& r = recs[list[t]]; return r.state == CONFIRMED && r.tsu <= 1; },
+                   [&](int pos, int t) {
+                       const int slot = list[t];
+                       const double* m = mean_pool + (size_t)slot * 8;
+                       const double w = m[2] * m[3], h = m[3];                       // track.py:82-96 to_tlwh
+                       const double x = m[0] - w / 2, y = m[1] - h / 2;
+                       long long row[6];
+                       const long long x1 = (long long)x, y1 = (long long)y, x2 = (long long)(x + w), y2 = (long long)(y + h);
+                       row[0] = x1 > 0 ? x1 : 0; row[1] = y1 > 0 ? y1 : 0;
+                       row[2] = x2 < W - 1 ? x2 : W - 1; row[3] = y2 < H - 1 ? y2 : H - 1;
+                       row[4] = recs[slot].id; row[5] = label;
+                       emit(pos, row);
+                   });
+}
+
+}  // namespace tc
+}  // namespace vc

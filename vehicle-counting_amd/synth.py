@@ -17,13 +17,24 @@ def _objects(n_obj, H, W, seed):
     return rng, pos, vel, wh, tex, label
 
 
-def synth_tracks(n_frames, H, W, n_obj=8, seed=SEED):
-    """Ground-truth boxes per frame: (xywh top-left float64 (n,4), labels int64 (n,), scores float64 (n,))."""
+def _reflect(x, lo, hi):
+    """Fold a coordinate back into [lo, hi] (objects bounce off the frame border instead of leaving a long clip)."""
+    span = hi - lo
+    y = np.mod(x - lo, 2 * span)
+    return lo + np.where(y > span, 2 * span - y, y)
+
+
+def synth_tracks(n_frames, H, W, n_obj=8, seed=SEED, bounce=False):
+    """Ground-truth boxes per frame: (xywh top-left float64 (n,4), labels int64 (n,), scores float64 (n,)).
+    bounce=True keeps the objects inside the frame for clips of any length (bench.py's 512-frame streams)."""
     rng, pos, vel, wh, tex, label = _objects(n_obj, H, W, seed)
     jrng = np.random.default_rng(seed + 1)
     out = []
     for t in range(n_frames):
-        c = pos + vel * t + jrng.normal(0, 0.5, pos.shape)
+        c = pos + vel * t
+        if bounce:
+            c = np.stack([_reflect(c[:, 0], wh[:, 0] / 2 + 1, W - wh[:, 0] / 2 - 3), _reflect(c[:, 1], wh[:, 1] / 2 + 1, H - wh[:, 1] / 2 - 3)], 1)
+        c = c + jrng.normal(0, 0.5, pos.shape)
         tl = c - wh / 2
         boxes = np.concatenate([tl, wh], 1)
         boxes[:, 0] = np.clip(boxes[:, 0], 0, W - wh[:, 0] - 2)
@@ -32,13 +43,13 @@ def synth_tracks(n_frames, H, W, n_obj=8, seed=SEED):
     return out
 
 
-def synth_frames(n_frames, H, W, n_obj=8, seed=SEED):
+def synth_frames(n_frames, H, W, n_obj=8, seed=SEED, bounce=False):
     """(n_frames, H, W, 3) uint8 BGR frames with the rectangles of synth_tracks() drawn in."""
     rng, pos, vel, wh, tex, label = _objects(n_obj, H, W, seed)
     yy, xx = np.mgrid[0:H, 0:W]
     bg = (96 + 40 * np.sin(xx / 97.0) * np.cos(yy / 61.0))[..., None] + np.array([0, 8, 16])
     frames = np.empty((n_frames, H, W, 3), np.uint8)
-    tracks = synth_tracks(n_frames, H, W, n_obj, seed)
+    tracks = synth_tracks(n_frames, H, W, n_obj, seed, bounce)
     for t in range(n_frames):
         f = bg.copy()
         for i, b in enumerate(tracks[t][0]):
