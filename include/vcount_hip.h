@@ -70,6 +70,8 @@ typedef struct vc_engine_config {
     int nn_budget_cap;     /* largest NN_BUDGET any tracker will ask for */
     int with_detector;     /* 0: skip building the YOLO plan (track-only users) */
     int with_reid;         /* 0: skip building the ReID plan */
+    int max_trackers;      /* (camera, class) trackers the engine can hold (device-resident headers + track lists) */
+    int tracks_per_tracker;/* live tracks one tracker may hold (<= 512: the device step keeps its work arrays in LDS) */
 } vc_engine_config;
 
 int vc_engine_config_default(vc_engine_config* cfg);
@@ -125,6 +127,11 @@ int vc_tracker_step(vc_engine* e, int tracker_id, const double* tlwh, const doub
 int vc_tracker_count(vc_engine* e, int tracker_id, int* n);
 int vc_tracker_state(vc_engine* e, int tracker_id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu,
                      double* mean8, double* cov64, int* gallery_count);
+/* Cost matrices of the last blocking step that stepped exactly ONE tracker (vc_tracker_step, vc_deepsort_update), as the tracker
+ * kernel computed them: app[t*D + d] = gated min-cosine cost (sort/nn_matching.py:160-177 + linear_assignment.py:148-192) of list
+ * position t, valid for the tracks that were confirmed when the step began; iou[t*D + d] = 1 - IoU (sort/iou_matching.py:40-81), valid
+ * for the IoU candidates.  T = live tracks before the step, D = detections of the step.  Parity tests read the HOT kernel's numbers. */
+int vc_tracker_debug_costs(vc_engine* e, int cap_entries, double* app, double* iou, int* T, int* D);
 /* Tracker state for stream migration (the reference keeps it in Python objects, sort/tracker.py:40-60 and
  * sort/track.py:64-80, and cannot move a stream): parameters, id counter, per track the FSM counters, fp64 Kalman mean and
  * covariance and the valid gallery rows.  vc_tracker_snapshot with buf == NULL only reports the size.  vc_tracker_restore

@@ -121,7 +121,7 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
         kalman_initiate_dev(&h.mean[(size_t)slot * 8], &h.cov[(size_t)slot * 64], &xyah[(size_t)d * 4]);
         gallery_store(&h.gallery[((size_t)slot * S + 0) * FEAT], feat + (size_t)d * FEAT);
     }
-    const int n = finish_step(L, w, &h.hdr, h.list.data(), h.recs.data(), T, n_match, n_un, n_new, [&](int slot) { h.free_stack.push_back(slot); });
+    const int n = finish_step(L, w, &h.hdr, h.list.data(), h.recs.data(), T, n_match, n_un, n_new, [&](const int* slots, int nd) { for (int i = 0; i < nd; ++i) h.free_stack.push_back(slots[i]); });
     h.n_rows = emit_rows(L, h.list.data(), h.recs.data(), h.mean.data(), n, W, H, label,
                          [&](int pos, const long long* row) { memcpy(&h.rows[(size_t)pos * 6], row, 6 * sizeof(long long)); });
     return 0;

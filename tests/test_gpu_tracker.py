@@ -114,3 +114,39 @@ def test_deepsort_update_and_videotracker(eng):
         r2 = eng.deepsort_update(ds_t, xyxy, scores, frames[t])
         np.testing.assert_array_equal(r2, np.asarray(r1, dtype=np.int64).reshape(-1, 7))
     assert n_rows > 20
+
+
+@pytest.mark.parametrize("name", ["crossing", "occlusion", "gated_twin", "stress"])
+def test_hot_kernel_cost_rows_match_the_oracle(eng, name):
+    """The numbers the tracker kernel itself matched on (track_batch_kernel's appearance + gate rows and IoU rows, read back
+    with vc_tracker_debug_costs) against the oracle's cost matrices of the same step: gate decisions identical, min-cosine costs
+    within 2e-6 (fp32 dot products in a different summation order), IoU costs to the last bit or two."""
+    p, frames = scenarios.build(name)
+    ref = od.TrackerState(p["max_dist"], p["budget"], max_iou_distance=p["max_iou_distance"], max_age=p["max_age"], n_init=p["n_init"])
+    tid = eng.tracker_create(max_dist=p["max_dist"], max_iou_distance=p["max_iou_distance"], max_age=p["max_age"], n_init=p["n_init"],
+                             nn_budget=p["budget"])
+    n_app = n_iou = n_gated = 0
+    for t, dets in enumerate(frames):
+        ref.predict()
+        conf = [i for i, k in enumerate(ref.tracks) if k.state == od.CONFIRMED]
+        cand = [i for i, k in enumerate(ref.tracks) if not (k.state == od.CONFIRMED and k.tsu != 1)]
+        cols = list(range(len(dets)))
+        app_ref = ref._appearance_cost(dets, conf, cols) if dets and conf else np.zeros((0, len(dets)))
+        iou_ref = ref._iou_cost(dets, cand, cols) if dets and cand else np.zeros((0, len(dets)))
+        n_before = len(ref.tracks)
+        ref.update(dets)
+        eng.tracker_step(tid, np.array([d["tlwh"] for d in dets]).reshape(-1, 4), np.array([d["conf"] for d in dets]),
+                         np.array([d["feature"] for d in dets], dtype=np.float32).reshape(-1, 512))
+        app, iou = eng.tracker_debug_costs()
+        assert app.shape == (n_before, len(dets)), (t, app.shape)
+        if len(dets) and conf:
+            got = app[conf]
+            np.testing.assert_array_equal(got == od.GATED_COST, app_ref == od.GATED_COST, err_msg=f"gate, frame {t}")
+            open_ = app_ref != od.GATED_COST
+            np.testing.assert_allclose(got[open_], app_ref[open_], rtol=0, atol=2e-6, err_msg=f"cosine, frame {t}")
+            n_app += int(open_.sum()); n_gated += int((~open_).sum())
+        if len(dets) and cand:
+            np.testing.assert_allclose(iou[cand], iou_ref, rtol=0, atol=1e-14, err_msg=f"iou, frame {t}")
+            n_iou += iou_ref.size
+    assert n_app > 20 and n_iou > 20 and n_gated > 20, (n_app, n_iou, n_gated)
+    eng.tracker_reset(tid)

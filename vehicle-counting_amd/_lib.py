@@ -28,7 +28,7 @@ class EngineConfig(C.Structure):
                 ("img_size", C.c_int), ("max_batch", C.c_int), ("max_frame_h", C.c_int), ("max_frame_w", C.c_int),
                 ("conf_thres", C.c_float), ("iou_thres", C.c_float), ("max_det", C.c_int), ("max_candidates", C.c_int),
                 ("max_crops", C.c_int), ("max_tracks", C.c_int), ("nn_budget_cap", C.c_int),
-                ("with_detector", C.c_int), ("with_reid", C.c_int)]
+                ("with_detector", C.c_int), ("with_reid", C.c_int), ("max_trackers", C.c_int), ("tracks_per_tracker", C.c_int)]
 
 
 class TrackerParams(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "vc_tracker_step": [_vp, _i, _pd, _pd, _pf, _i],
     "vc_tracker_count": [_vp, _i, _pi],
     "vc_tracker_state": [_vp, _i, _i, _pl, _pi, _pi, _pi, _pi, _pd, _pd, _pi],
+    "vc_tracker_debug_costs": [_vp, _i, _pd, _pd, _pi, _pi],
     "vc_tracker_snapshot": [_vp, _i, _vp, C.c_size_t, _P(C.c_size_t)],
     "vc_tracker_restore": [_vp, _i, _vp, C.c_size_t],
     "vc_deepsort_update": [_vp, _i, _pu8, _i, _i, _pd, _pd, _i, _pl, _i, _pi],

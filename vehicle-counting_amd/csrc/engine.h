@@ -5,7 +5,6 @@
 #include <deque>
 #include <map>
 #include <mutex>
-#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -53,19 +52,30 @@ struct ProfCat {
     int64_t launches = 0;
 };
 
-// host-side tracker record (tracker.hip)
-struct TrackRec {
-    int64_t id;
-    int state, hits, age, tsu;
-    int slot;                        // index into the device TrackPool
-    int gal_count, gal_head;         // ring of the last `budget` features
-    double last_conf;
-};
-
+// host-side view of one tracker (tracker.hip): parameters the host needs to prepare detections, and bounds on its size
 struct Tracker {
     vc_tracker_params p;
-    std::vector<TrackRec> tracks;
-    int64_t next_id = 1;
+    int known_tracks = 0;            // live tracks reported by the last completed batch
+    int pending_dets = 0;            // detections of batches still in flight (each may start a track)
+};
+
+// one (frame, class) step of a batch as the host sees it
+struct TrackTaskHost { int tracker, label, frame, det_off, det_n; };
+
+// Staging of one tracker batch: inputs (tasks, plans, detections) in one pinned block mirrored on the device by a single copy;
+// outputs (rows, per-task counts, status) written by the kernel straight into pinned host memory.
+struct TrackStage {
+    char* h_in = nullptr; char* d_in = nullptr; size_t in_cap = 0;
+    char* h_out = nullptr; char* hd_out = nullptr; size_t out_cap = 0;
+    int* d_cursor = nullptr;                 // [0] row cursor
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    // layout of the current batch
+    int n_tasks = 0, n_wg = 0, n_dets = 0, rows_cap = 0, b = 0, W = 0, H = 0, step_cap = 0;
+    std::vector<TrackTaskHost> tasks;        // (frame, class) order = output order
+    std::vector<int> dev_index;              // tasks[i] is the device's task dev_index[i]
+    std::vector<std::pair<int, int>> tracker_dets;   // (tracker, detections enqueued) for the pending_dets bookkeeping
+    std::vector<int> last_task_of;           // per entry of tracker_dets: device index of the tracker's last task
 };
 
 }  // namespace vc
@@ -122,22 +132,10 @@ struct vc_engine {
         std::vector<int> row0;           // first feature row of each frame
     };
     std::vector<Pending> pending;
-    // asynchronous tracking (vc_stream_run_async / vc_stream_collect): the tracker loop of a batch runs on a worker thread
-    struct AsyncJob {
-        Pending pd;
-        std::vector<int> trackers;
-        int num_classes = 0, b = 0, h = 0, w = 0, cap = 0;
-        std::vector<int64_t> rows6;
-        std::vector<int> m, ndet;
-        int status = 0;
-        std::string err;
-        bool done = false;
-    };
-    std::thread worker;
-    std::mutex jmu;
-    std::condition_variable jcv;
-    std::deque<std::unique_ptr<AsyncJob>> jobs;      // submission order; front = next to collect
-    bool worker_quit = false;
+    // asynchronous tracking (vc_stream_run_async / vc_stream_collect): a batch's tracker work is one kernel on the tracker stream;
+    // the job remembers which staging slot its rows will land in
+    struct AsyncJob { int stage = 0, b = 0, cap = 0; std::vector<int> ndet; };
+    std::deque<AsyncJob> jobs;                   // submission order; front = next to collect
 
     // ---- ReID ---------------------------------------------------------------------------------------
     vc::Net reid;
@@ -148,24 +146,19 @@ struct vc_engine {
     float* h_feat = nullptr;
     float* d_reid_in_nchw = nullptr;
 
-    // ---- tracker pool ---------------------------------------------------------------------------------
+    // ---- tracker (device-resident, tracker.hip / track_kernels.hip) --------------------------------------------
     vc::TrackPool pool{};
-    std::vector<int> free_slots;
+    vc::tc::TrackerHdr* d_hdrs = nullptr;         // [max_trackers]
+    int* d_lists = nullptr;                      // [max_trackers][list_cap]
+    vc::tc::TrackRecD* d_recs = nullptr;          // [max_tracks]
+    int* d_free = nullptr;                       // [0] free_top, [1] freed_count
+    int* d_free_stack = nullptr; int* d_freed = nullptr;
+    int max_trackers = 0, list_cap = 0;
     std::vector<std::unique_ptr<vc::Tracker>> trackers;
-    // per-step scratch: one pinned staging block mirrored on the device, cost matrices, posterior means
-    // pinned + device-mapped (hd_* = device alias): phase A block, phase B block, cost rows, posterior means
-    char* h_stage = nullptr; char* hd_stage = nullptr; size_t stage_cap = 0;
-    char* h_stage2 = nullptr; char* hd_stage2 = nullptr;
-    double* h_cost = nullptr; double* hd_cost = nullptr;
-    double* h_mean = nullptr; double* hd_mean = nullptr;
+    vc::TrackStage tstage[4];                    // 0..2: batches of the stream path in flight, 3: the blocking entry points
+    unsigned tstage_seq = 0;
+    double* d_track_scratch = nullptr; size_t track_scratch_bytes = 0;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
-    std::vector<int> slot_chain;                 // scratch of track_launch: slot -> chain index, -1 outside a call
-    unsigned* d_track_counter = nullptr;         // workgroups of the running tracker kernel that have finished
-    unsigned* h_track_flag = nullptr; unsigned* hd_track_flag = nullptr;   // pinned completion word (sequence number)
-    unsigned track_seq = 0;
-    bool track_inflight = false;
-    std::vector<vc::TrackChainRec> chain_scratch;
-    size_t cost_cap = 0;
     int det_cap = 0;
 
     // ---- measurement ----------------------------------------------------------------------------------
@@ -207,37 +200,18 @@ struct ProfScope {
 // tracker.hip
 int tracker_init_pool(vc_engine* e);
 struct Prepared { std::vector<double> tlwh, conf; std::vector<int> feat_rows; };   // filtered + NMS'ed detections of one tracker
-struct StepCtx {
-    std::vector<int> ids, labels;          // trackers stepped together (the classes of one frame) and their labels
-    std::vector<Prepared> prep;
-    int W = 0, H = 0;
-    bool all_means = false;
-    // phase A products
-    int n_dets = 0, n_app = 0, n_iou = 0;
-    size_t out = 0;
-    std::vector<int> det_base, featrow;
-    std::vector<std::vector<int>> app_job, iou_job;
-    std::vector<double> det_xyah;
-    int n_jobs = 0;                        // cost jobs staged in e->h_stage (+ their device aliases)
-    const TrackJobA* h_jobs = nullptr; const TrackJobA* d_jobs = nullptr;
-    const int* d_featrow = nullptr; const double* d_xyah = nullptr; const double* d_tlwh = nullptr;
-    // phase B products
-    std::vector<TrackOpB> ops;             // pending device operations (carried by the next track_launch)
-    struct Emit { int row; int64_t id; int label; };
-    std::vector<Emit> emit;
-    std::vector<int> mean_offsets;
-};
-int track_prepare_a(vc_engine* e, StepCtx& c);
-int track_host_b(vc_engine* e, StepCtx& c);
-int track_launch(vc_engine* e, const StepCtx* cb, const float* feat_b, const StepCtx* ca, const float* feat_a);
-int track_wait(vc_engine* e);
-int async_wait_all(vc_engine* e);          // stream.hip: block until the worker thread has finished every queued batch
-void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6);
-void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
-               const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0);
+void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k, const vc_tracker_params& p, Prepared& out);
+void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep);
+// Build + enqueue one tracker batch on the tracker stream (after `wait`, if given, has fired on the GPU).  frame_groups[f] lists
+// (class label, tracker id, prepared detections) of frame f in class order.  Rows land in stage `st`; track_collect waits for them.
+struct FrameClassDets { int label, tracker; Prepared dets; };
+int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClassDets>>& frames, const float* d_feat, int W, int H,
+                  int rows_cap, hipEvent_t wait);
+// rows6 per frame: out_rows6[f * cap_rows_per_frame * 6 ...], out_m[f]
+int track_collect(vc_engine* e, int st, int64_t* out_rows6, int cap_rows_per_frame, int* out_m);
+int track_idle(vc_engine* e);              // wait until no tracker batch is in flight (stream path included)
+int async_wait_all(vc_engine* e);          // stream.hip: the same, named as the blocking entry points call it
 int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int H, int W, const std::vector<int>& tracker_ids,
                 const std::vector<int>& labels, const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf,
                 int n, std::vector<int64_t>& rows6);
-int lap_solve(const double* cost, int nr, int nc, std::vector<int>& row_of_col_rows, std::vector<int>& cols);
-void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep);
 }  // namespace vc

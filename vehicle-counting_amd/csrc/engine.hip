@@ -633,6 +633,7 @@ int vc_engine_config_default(vc_engine_config* c) {
     c->max_batch = 16; c->max_frame_h = 720; c->max_frame_w = 1280;
     c->conf_thres = 0.25f; c->iou_thres = 0.45f; c->max_det = 300; c->max_candidates = 4096;
     c->max_crops = 1024; c->max_tracks = 4096; c->nn_budget_cap = 100; c->with_detector = 1; c->with_reid = 1;
+    c->max_trackers = 256; c->tracks_per_tracker = 512;
     return VC_OK;
 }
 
@@ -694,11 +695,6 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
 
 int vc_engine_destroy(vc_engine* e) {
     if (!e) return VC_OK;
-    if (e->worker.joinable()) {                         // asynchronous tracker thread (stream.hip)
-        { std::lock_guard<std::mutex> lk(e->jmu); e->worker_quit = true; }
-        e->jcv.notify_all();
-        e->worker.join();
-    }
     tune_cache_save(e);
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
@@ -714,6 +710,7 @@ int vc_engine_destroy(vc_engine* e) {
     if (e->rstream) hipStreamDestroy(e->rstream);
     for (hipEvent_t ev : e->ev_det) if (ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_reid) if (ev) hipEventDestroy(ev);
+    for (vc::TrackStage& ts : e->tstage) if (ts.done) hipEventDestroy(ts.done);
     delete e;
     return VC_OK;
 }

@@ -70,46 +70,66 @@ int launch_maxpool3s2(const View& src, const View& dst, int prec, hipStream_t s)
 int launch_avgpool_l2norm(const View& src, float* out, int prec, hipStream_t s);
 
 // ---- track side (track_kernels.hip) ---------------------------------------------------------------------
+namespace tc { struct TrackerHdr; struct TrackRecD; }   // track_core.h (included where the definitions are needed: it must be
+                                                        // compiled with floating-point contraction off, unlike this header's users)
 struct TrackPool {
     double* mean;     // [max_tracks][8]
     double* cov;      // [max_tracks][64]
     float* gallery;   // [max_tracks][budget_cap][512]
     int max_tracks, budget_cap;
 };
-// slots: pool indices.  All kernels are batched over an index list living in device memory.
-int launch_kalman_predict(TrackPool& tp, const int* slots, int n, hipStream_t s);
-// initiate: meas xyah per new track
-int launch_kalman_initiate(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s);
-int launch_kalman_update(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s);
-// gating distances: for pair list job j: track slot ts[j] against measurements zs[zoff[j] .. zoff[j]+zn[j]) -> out[ooff[j] + i]
+// one confirmed track against a contiguous range of detections (appearance_row_dev)
 struct CostJob {
     int slot;        // track slot
-    int gal_count;   // valid gallery rows of that slot (0: skip appearance)
-    int det_off;     // first detection (index into the frame's detection arrays)
+    int gal_count;   // valid gallery rows of that slot
+    int det_off;     // first detection (index into the batch's detection arrays)
     int det_n;       // detections
     int out_off;     // offset into the output cost array
-    int tsu;         // time since update (IoU rows with tsu > 1 are filled with 1e5)
+    int tsu;         // time since update
 };
-// fused per-frame tracker kernels (one launch per phase; descriptors and results may live in host-mapped pinned memory)
-struct TrackJobA { int slot, gal_count, det_off, det_n, app_off, iou_off, tsu, pad; };          // app_off / iou_off < 0: no such row
-struct TrackOpB { int slot, kind, gal_pos, feat_row, out_row, pad0, pad1, pad2; double z[4]; }; // kind 0 none, 1 update, 2 initiate
-struct TrackChainRec { TrackOpB op; TrackJobA job; };   // per touched slot: op.kind < 0 = no operation, job.slot < 0 = no cost job (96 B)
-int launch_track_step(const TrackPool& tp, const TrackChainRec* recs, int nchains, const float* feat_ops, const float* feat_jobs,
-                      double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh, double* out,
-                      unsigned* counter, unsigned* done_flag, unsigned seq, hipStream_t s);
-// appearance cost (min cosine distance over the gallery) with Mahalanobis gating folded in:
-//   out[out_off + i] = gate(slot, det i) > 9.4877 ? 1e5 : min_s (1 - <g_s/|g_s|, f_i/|f_i|>)
-// feature of detection g (global index det_off + i) is feat[det_feat_row[g]]
+// One tracker step = (tracker, frame): Tracker.predict() + Tracker.update(detections) on the prepared (confidence-filtered,
+// DeepSORT-NMS'ed, deep_sort.py:31-41) detections [det_off, det_off + det_n) of the batch's detection arrays.
+struct TrackTask { int tracker, det_off, det_n, frame, label, pad0, pad1, pad2; };
+// workgroup b of the batch kernel owns one tracker and runs its tasks [task_begin, task_end) in order
+struct TrackWgPlan { int tracker, task_begin, task_end, pad; };
+struct TrackBatchArgs {
+    TrackPool pool;
+    tc::TrackerHdr* hdrs;            // [max_trackers]
+    int* lists;                      // [max_trackers][list_cap]: pool slots of the live tracks in list order (tracker.py: self.tracks)
+    int list_cap;
+    tc::TrackRecD* recs;             // [max_tracks] per-slot record
+    int* free_top;                   // free slots: stack [0, *free_top), only popped inside a kernel
+    int* free_stack;
+    int* freed_count;                // slots freed by the running kernel (appended; merged into the stack after it)
+    int* freed;
+    const TrackWgPlan* plans;
+    const TrackTask* tasks;
+    const double* det_tlwh;          // [n_det][4]
+    const double* det_xyah;          // [n_det][4]
+    const int* det_featrow;          // [n_det] row of `feat`
+    const float* feat;               // [rows][512] embeddings of the batch
+    long long* rows;                 // [rows_cap][6] output arena: x1,y1,x2,y2,id,label
+    int rows_cap;
+    int* row_cursor;
+    int* task_row_off;               // [n_tasks] first row of the task in the arena
+    int* task_row_n;                 // [n_tasks] rows of the task
+    int* task_ntracks;               // [n_tasks] live tracks after the step
+    int* task_T;                     // [n_tasks] live tracks before the step (rows of the step's cost matrices)
+    int* status;                     // [0] first error (tc::TERR_*), [1] tracker, [2] task
+    double* scratch;                 // per workgroup 4 x cap x cap doubles: appearance rows, IoU rows, gathered sub-matrix, transpose
+    int cap;                         // per-step capacity (tracks + detections), a multiple of 8
+    int frame_w, frame_h;
+};
+int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s);
+// test entry points: the batch kernel's own device functions on caller-supplied state
+int launch_kat_kalman(TrackPool& tp, int which /* 0 initiate, 1 predict, 2 update */, const double* z, int n, hipStream_t s);
+int launch_kat_lap(const double* cost, int nr, int nc, double* tbuf, int* out_rows, int* out_cols, int* out_n, hipStream_t s);
+//   out[out_off + i] = gate(slot, det i) > 9.4877 ? 1e5 : min_s (1 - <g_s/|g_s|, f_i/|f_i|>); feature of detection g is feat[det_feat_row[g]]
 int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const float* feat /* [rows][512] */,
                            const int* det_feat_row /* [nd] */, const double* det_xyah /* [nd][4] */, double* out, hipStream_t s);
-// test twins: raw squared Mahalanobis distances of one track; IoU between two box lists (tlwh)
 int launch_gating_values(const TrackPool& tp, int slot, const double* z, int n, double* out, hipStream_t s);
 int launch_iou_boxes(const double* a, int t, const double* b, int d, double* out, hipStream_t s);
-//   out[out_off + i] = tsu > 1 ? 1e5 : 1 - IoU(track tlwh, det tlwh)
-int launch_iou_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const double* det_tlwh, double* out, hipStream_t s);
-// out[i][0:8] = mean[slots[i]]
-int launch_gather_means(const TrackPool& tp, const int* slots, int n, double* out, hipStream_t s);
-// gallery append: copy feat[src[i]] into gallery[slot[i]][pos[i]]
+// gallery append: normalised copy of feat[src[i]] into gallery[slot[i]][pos[i]]
 int launch_gallery_write(TrackPool& tp, const int* slot_pos_src /* n x 3 */, int n, const float* feat, hipStream_t s);
 
 }  // namespace vc

@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "engine.h"
 
@@ -29,7 +30,7 @@ struct Tm {
     }
     void report() {
         if (!on || ++calls % 10) return;
-        fprintf(stderr, "[vc timing, us per call] wait_det %.0f marshal %.0f reid_issue %.0f build %.0f phaseA_issue %.0f sync %.0f emit %.0f phaseB %.0f\n",
+        fprintf(stderr, "[vc timing, us per call] wait_det+reid_issue %.0f prepare %.0f enqueue %.0f - %.0f %.0f %.0f %.0f %.0f\n",
                 acc[0] / 10, acc[1] / 10, acc[2] / 10, acc[3] / 10, acc[4] / 10, acc[5] / 10, acc[6] / 10, acc[7] / 10);
         for (double& a : acc) a = 0;                   // windowed: the last 10 calls
     }
@@ -150,7 +151,7 @@ int try_issue_next(vc_engine* e) {
         ++embedded;
     }
     if (!next) return VC_OK;
-    { std::lock_guard<std::mutex> lk(e->jmu); embedded += (int)e->jobs.size(); }
+    embedded += (int)e->jobs.size();
     if (embedded >= 3) return VC_OK;
     if (hipEventQuery(e->ev_det[next->slot]) != hipSuccess) return VC_OK;
     return issue_reid(e, *next);
@@ -160,87 +161,42 @@ int try_issue_next(vc_engine* e) {
 
 extern "C" {
 
-// The tracker loop of one batch whose ReID has been enqueued (pd.stage == 1): per-class DeepSORT steps frame by frame, rows
-// [x1,y1,x2,y2,id,label] per frame.  Runs on the caller's thread (vc_stream_run) or on the worker thread
-// (vc_stream_run_async); it only touches the tracker stream and the tracker's own state.
-static int track_batch(vc_engine* e, vc_engine::Pending& pd, const int* trackers, int num_classes, int b, int h, int w,
-                       int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, bool poll_next) {
-    // the tracker stream waits (on the GPU) for this batch's features
-    VC_HIP(hipStreamWaitEvent(e->stream, e->ev_reid[pd.fslot], 0));
-    const float* d_feat = e->d_feat2[pd.fslot];
-    std::vector<FrameDets>& fd = pd.fd;
+// The tracker work of one batch whose ReID has been enqueued (pd.stage == 1): per frame, in class order, the detections
+// VideoTracker.run would hand to that class's DeepSort.update (modules/track.py:50-59; frames without boxes are skipped,
+// modules/__init__.py:68-69, Q1), prepared on the host (confidence filter + DeepSORT NMS do not depend on tracker state), then ONE
+// kernel on the tracker stream that steps every tracker through the whole batch (track_kernels.hip).  No host round trip per frame.
+static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const int* trackers, int num_classes, int stage, int cap_rows_per_frame,
+                                  std::vector<int>& ndet) {
+    const int b = pd.b;
+    ndet.assign(b, 0);
+    std::vector<std::vector<FrameClassDets>> frames(b);
+    std::vector<std::vector<int>> by_class(num_classes);
     for (int f = 0; f < b; ++f) {
-        if (out_ndet) out_ndet[f] = (int)fd[f].conf.size();
-        out_m[f] = 0;
-    }
-    g_tm.lap(1);
-    // Tracker pipeline: the operations of frame f and the cost jobs of the next non-empty frame are one launch; the host
-    // preparation of the next frame (class grouping, confidence filter, DeepSORT NMS: independent of tracker state) runs while
-    // the launch is in flight.
-    struct FramePlan { int f; std::vector<int> ids, labs; std::vector<std::vector<int>> groups; };
-    std::vector<FramePlan> plan;
-    {
-        std::vector<std::vector<int>> by_class(num_classes);
-        for (int f = 0; f < b; ++f) {
-            FrameDets& d = fd[f];
-            if (d.conf.empty()) continue;                                            // modules/__init__.py:68-69 (Q1)
-            FramePlan pl;
-            pl.f = f;
-            for (size_t i = 0; i < d.label.size(); ++i)                              // modules/track.py:50-59, one pass
-                if (d.label[i] >= 0 && d.label[i] < num_classes) by_class[d.label[i]].push_back((int)i);
-            for (int c = 0; c < num_classes; ++c) {
-                if (by_class[c].empty()) continue;
-                pl.ids.push_back(trackers[c]); pl.labs.push_back(c); pl.groups.push_back(std::move(by_class[c]));
-                by_class[c].clear();
+        FrameDets& d = pd.fd[f];
+        ndet[f] = (int)d.conf.size();
+        if (d.conf.empty()) continue;                                                // Q1
+        for (size_t i = 0; i < d.label.size(); ++i)
+            if (d.label[i] >= 0 && d.label[i] < num_classes) by_class[d.label[i]].push_back((int)i);
+        for (int c = 0; c < num_classes; ++c) {
+            std::vector<int>& g = by_class[c];
+            if (g.empty()) continue;
+            VC_CHECK(trackers[c] >= 0 && trackers[c] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            std::vector<double> bx(g.size() * 4), cf(g.size());
+            std::vector<int> rows(g.size());
+            for (size_t i = 0; i < g.size(); ++i) {
+                memcpy(&bx[i * 4], &d.xyxy[(size_t)g[i] * 4], 4 * sizeof(double));
+                cf[i] = d.conf[g[i]];
+                rows[i] = pd.row0[f] + g[i];
             }
-            if (!pl.ids.empty()) plan.push_back(std::move(pl));
+            FrameClassDets fc{c, trackers[c], {}};
+            prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[trackers[c]]->p, fc.dets);
+            frames[f].push_back(std::move(fc));
+            g.clear();
         }
     }
-    StepCtx ctx[3];
-    int prev_f = -1;
-    auto flush_prev = [&](int which) -> int {             // rows of the previously stepped frame (its means have landed)
-        if (prev_f < 0) return VC_OK;
-        std::vector<int64_t> rows6;
-        emit_rows(ctx[which], e->h_mean, rows6);
-        const int m = (int)(rows6.size() / 6);
-        VC_CHECK(m <= cap_rows_per_frame, VC_ERR_CAPACITY, "frame %d needs room for %d rows", prev_f, m);
-        memcpy(out_rows6 + (size_t)prev_f * cap_rows_per_frame * 6, rows6.data(), rows6.size() * sizeof(int64_t));
-        out_m[prev_f] = m;
-        prev_f = -1;
-        return VC_OK;
-    };
-    auto build = [&](size_t j) {
-        const FramePlan& pl = plan[j];
-        FrameDets& d = fd[pl.f];
-        build_ctx(e, ctx[j % 3], h, w, pl.ids, pl.labs, pl.groups, d.xyxy.data(), d.conf.data(), pd.row0[pl.f]);
-    };
+    g_tm.lap(1);
+    VC_TRY(track_enqueue(e, stage, frames, e->d_feat2[pd.fslot], pd.w, pd.h, b * cap_rows_per_frame, e->ev_reid[pd.fslot]));
     g_tm.lap(2);
-    if (!plan.empty()) build(0);
-    for (size_t j = 0; j < plan.size(); ++j) {
-        const int cur = (int)(j % 3), prv = (int)((j + 2) % 3);
-        g_tm.lap(3);
-        VC_TRY(track_prepare_a(e, ctx[cur]));
-        // one launch: the pending operations of the previous frame + the cost jobs of this one
-        VC_TRY(track_launch(e, prev_f >= 0 ? &ctx[prv] : nullptr, d_feat, &ctx[cur], d_feat));
-        g_tm.lap(4);
-        if (j + 1 < plan.size()) build(j + 1);            // overlapped with the launch in flight
-        if (poll_next) VC_TRY(try_issue_next(e));
-        VC_TRY(track_wait(e));                            // cost rows of f are here; so are the means of the previous frame
-        g_tm.lap(5);
-        VC_TRY(flush_prev(prv));
-        g_tm.lap(6);
-        VC_TRY(track_host_b(e, ctx[cur]));
-        g_tm.lap(7);
-        prev_f = plan[j].f;
-    }
-    if (prev_f >= 0) {
-        const int last = (int)((plan.size() - 1) % 3);
-        VC_TRY(track_launch(e, &ctx[last], d_feat, nullptr, nullptr));
-        VC_TRY(track_wait(e));
-        g_tm.lap(5);
-        VC_TRY(flush_prev(last));
-        g_tm.lap(6);
-    }
     return VC_OK;
 }
 
@@ -263,119 +219,60 @@ static int take_front(vc_engine* e, const void* frames_dev, int b, int h, int w,
     return VC_OK;
 }
 
-static void async_worker(vc_engine* e) {
-    hipSetDevice(e->cfg.device);
-    for (;;) {
-        vc_engine::AsyncJob* job = nullptr;
-        {
-            std::unique_lock<std::mutex> lk(e->jmu);
-            e->jcv.wait(lk, [&] {
-                if (e->worker_quit) return true;
-                for (auto& j : e->jobs) if (!j->done) return true;
-                return false;
-            });
-            if (e->worker_quit) return;
-            for (auto& j : e->jobs) if (!j->done) { job = j.get(); break; }
-        }
-        g_tm.start();
-        const int st = track_batch(e, job->pd, job->trackers.data(), job->num_classes, job->b, job->h, job->w, job->rows6.data(), job->cap,
-                                   job->m.data(), job->ndet.data(), /*poll_next=*/false);
-        g_tm.report();
-        {
-            std::lock_guard<std::mutex> lk(e->jmu);
-            job->status = st;
-            if (st != VC_OK) job->err = vc::last_error();
-            job->done = true;
-        }
-        e->jcv.notify_all();
-    }
-}
-
 }  // extern "C" (helpers above have internal linkage)
 
 namespace vc {
-int async_wait_all(vc_engine* e) {
-    std::unique_lock<std::mutex> lk(e->jmu);
-    e->jcv.wait(lk, [&] { for (auto& j : e->jobs) if (!j->done) return false; return true; });
-    return VC_OK;
-}
+// Blocking entry points that touch tracker state wait for every tracker batch in flight (their rows stay in pinned memory until
+// vc_stream_collect picks them up).
+int async_wait_all(vc_engine* e) { return track_idle(e); }
 }  // namespace vc
 
 extern "C" {
 
-int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
-                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
-    VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
-    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
-    VC_CHECK(e->jobs.empty(), VC_ERR_STATE, "asynchronous batches are outstanding: vc_stream_collect them first");
-    VC_HIP(hipSetDevice(e->cfg.device));
-    vc_engine::Pending pd;
-    VC_TRY(take_front(e, frames_dev, b, h, w, pd));
-    VC_TRY(try_issue_next(e));
-    VC_TRY(track_batch(e, pd, trackers, num_classes, b, h, w, out_rows6, cap_rows_per_frame, out_m, out_ndet, /*poll_next=*/true));
-    VC_TRY(try_issue_next(e));
-    g_tm.report();
-    return VC_OK;
-}
-
-// Asynchronous form: the tracker loop of the batch (a chain of per-frame GPU round trips, ~70 us each) runs on the
-// engine's worker thread while the caller goes on to submit / embed the following batches; results are picked up in order
-// with vc_stream_collect.  Tracker state is only touched by the worker while jobs are outstanding.
+// Asynchronous form: the batch's tracker work is enqueued on the tracker stream (it starts on the GPU when the batch's ReID has
+// finished) and the call returns; the caller goes on to submit / embed the following batches; rows are picked up in order with
+// vc_stream_collect.  At most two batches may be outstanding.
 int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                         int cap_rows_per_frame) {
     VC_CHECK(e && trackers && frames_dev && cap_rows_per_frame > 0, VC_ERR_ARG, "bad argument");
     VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
     VC_HIP(hipSetDevice(e->cfg.device));
-    {
-        std::lock_guard<std::mutex> lk(e->jmu);
-        VC_CHECK(e->jobs.size() < 2, VC_ERR_STATE, "two asynchronous batches are already outstanding: call vc_stream_collect");
-    }
-    std::unique_ptr<vc_engine::AsyncJob> job(new vc_engine::AsyncJob());
-    VC_TRY(take_front(e, frames_dev, b, h, w, job->pd));
-    job->trackers.assign(trackers, trackers + num_classes);
-    job->num_classes = num_classes; job->b = b; job->h = h; job->w = w; job->cap = cap_rows_per_frame;
-    job->rows6.resize((size_t)b * cap_rows_per_frame * 6);
-    job->m.assign(b, 0);
-    job->ndet.assign(b, 0);
-    if (e->profiling) {                                   // profiling brackets launches with events on shared state: run inline
-        job->status = track_batch(e, job->pd, job->trackers.data(), num_classes, b, h, w, job->rows6.data(), cap_rows_per_frame,
-                                  job->m.data(), job->ndet.data(), true);
-        if (job->status != VC_OK) job->err = vc::last_error();
-        job->done = true;
-    }
-    {
-        std::lock_guard<std::mutex> lk(e->jmu);
-        e->jobs.push_back(std::move(job));
-        if (!e->worker.joinable()) e->worker = std::thread(async_worker, e);
-    }
-    e->jcv.notify_all();
+    VC_CHECK(e->jobs.size() < 2, VC_ERR_STATE, "two asynchronous batches are already outstanding: call vc_stream_collect");
+    vc_engine::Pending pd;
+    VC_TRY(take_front(e, frames_dev, b, h, w, pd));
+    vc_engine::AsyncJob job;
+    job.stage = (int)(e->tstage_seq++ % 3); job.b = b; job.cap = cap_rows_per_frame;
+    VC_TRY(enqueue_batch_tracking(e, pd, trackers, num_classes, job.stage, cap_rows_per_frame, job.ndet));
+    e->jobs.push_back(std::move(job));
+    g_tm.report();
     return try_issue_next(e);
 }
 
-// Results of the oldest asynchronous batch (blocks until its tracker loop has finished).  While waiting, the ReID of the
+// Results of the oldest asynchronous batch (blocks until its tracker kernel has finished).  While waiting, the ReID of the
 // next submission is started as soon as its detector has finished.
 int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b) {
     VC_CHECK(e && out_rows6 && out_m, VC_ERR_ARG, "null argument");
     VC_HIP(hipSetDevice(e->cfg.device));
-    std::unique_ptr<vc_engine::AsyncJob> job;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(e->jmu);
-            VC_CHECK(!e->jobs.empty(), VC_ERR_STATE, "no asynchronous batch is outstanding");
-            if (e->jcv.wait_for(lk, std::chrono::microseconds(100), [&] { return e->jobs.front()->done; })) {
-                job = std::move(e->jobs.front());
-                e->jobs.pop_front();
-                break;
-            }
-        }
+    VC_CHECK(!e->jobs.empty(), VC_ERR_STATE, "no asynchronous batch is outstanding");
+    const vc_engine::AsyncJob& front = e->jobs.front();
+    VC_CHECK(front.b == b && front.cap == cap_rows_per_frame, VC_ERR_ARG, "collect: batch of %d frames x %d rows expected", front.b, front.cap);
+    while (hipEventQuery(e->tstage[front.stage].done) == hipErrorNotReady) {
         VC_TRY(try_issue_next(e));
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
-    if (job->status != VC_OK) { vc::set_error("%s", job->err.c_str()); return job->status; }
-    VC_CHECK(job->b == b && job->cap == cap_rows_per_frame, VC_ERR_ARG, "collect: batch of %d frames x %d rows expected", job->b, job->cap);
-    memcpy(out_rows6, job->rows6.data(), job->rows6.size() * sizeof(int64_t));
-    memcpy(out_m, job->m.data(), (size_t)b * sizeof(int));
-    if (out_ndet) memcpy(out_ndet, job->ndet.data(), (size_t)b * sizeof(int));
+    vc_engine::AsyncJob job = std::move(e->jobs.front());
+    e->jobs.pop_front();
+    VC_TRY(track_collect(e, job.stage, out_rows6, cap_rows_per_frame, out_m));
+    if (out_ndet) memcpy(out_ndet, job.ndet.data(), (size_t)b * sizeof(int));
     return try_issue_next(e);
+}
+
+int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
+                  int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet) {
+    VC_CHECK(e && trackers && frames_dev && out_rows6 && out_m, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->jobs.empty(), VC_ERR_STATE, "asynchronous batches are outstanding: vc_stream_collect them first");
+    VC_TRY(vc_stream_run_async(e, trackers, num_classes, frames_dev, b, h, w, cap_rows_per_frame));
+    return vc_stream_collect(e, out_rows6, cap_rows_per_frame, out_m, out_ndet, b);
 }
 
 // Zone filter of VideoCounting.run (/root/reference/modules/track.py:102-104 -> utilities/counting/bb_polygon.py:14-114):

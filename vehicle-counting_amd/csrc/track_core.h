@@ -291,10 +291,10 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
 
 // Track.update / mark_missed / _initiate_track bookkeeping + Tracker.update's list maintenance, after the Kalman and gallery
 // writes of the step have been applied to the pool.  Survivors keep their order, new tracks are appended in `newdets` order with
-// consecutive ids.  Deleted slots are handed to free_slot(slot).  Returns the number of live tracks.
-template <class FreeSlot>
+// consecutive ids.  The slots of deleted tracks are handed to free_slots(slots, n).  Returns the number of live tracks.
+template <class FreeSlots>
 VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, TrackRecD* recs, int T, int n_match, int n_un, int n_new,
-                      FreeSlot free_slot) {
+                      FreeSlots free_slots) {
     const TrackerHdr h = *hdr;
     for (int k = L.lane; k < n_match; k += L.n) {            // Track.update (track.py:126-145); a track is matched at most once
         const int t = w.match_t[k];
@@ -316,8 +316,9 @@ VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, Tr
         r.state = w.state[t]; r.tsu = w.tsu[t]; r.gal_count = w.galc[t]; r.gal_head = w.galh[t];
     }
     const int n_surv = compact(L, T, [&](int t) { return w.state[t] != DELETED; }, [&](int pos, int t) { list[pos] = w.slot[t]; });
-    for (int t = 0; t < T; ++t)                              // uniform: deletions are rare
-        if (w.state[t] == DELETED) free_slot(w.slot[t]);
+    const int n_del = compact(L, T, [&](int t) { return w.state[t] == DELETED; }, [&](int pos, int t) { w.rows[pos] = w.slot[t]; });
+    wave_sync();
+    if (n_del > 0) free_slots(w.rows, n_del);
     for (int i = L.lane; i < n_new; i += L.n) {              // _initiate_track (tracker.py:133-139)
         TrackRecD r;
         r.id = h.next_id + i; r.state = TENTATIVE; r.hits = 1; r.age = 1; r.tsu = 0; r.gal_count = 1; r.gal_head = 1 % h.nn_budget;

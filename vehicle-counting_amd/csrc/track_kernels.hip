@@ -1,138 +1,40 @@
-// Batched DeepSORT numerics on the device: Kalman predict / initiate / update, Mahalanobis gating folded into the
-// appearance (gallery cosine) cost, and the IoU cost.  fp64 where the reference is fp64, fp32 where it is fp32.
+// DeepSORT on the device, one workgroup per (camera, class) tracker for a whole batch of frames: no host in the per-frame loop.
+//
+// track_batch_kernel: workgroup b owns tracker plans[b].tracker and walks its tasks (= the frames of the batch in which the
+// class has detections, modules/track.py:50-59) in order.  Per task:
+//   P0  all 4 waves   Track.predict counters + Kalman predict (one wave per track, one covariance element per lane),
+//                     gated appearance rows of the confirmed tracks (fp32 matrix cores) and IoU rows of the IoU candidates
+//   P1  wave 0        Tracker._match: cascade + IoU stage on exact rectangular assignments (track_core.h), slots for new tracks
+//   P2  all 4 waves   Kalman update / initiate + gallery ring writes, one wave per matched / new track
+//   P3  wave 0        Track FSM, list maintenance, rows [x1,y1,x2,y2,id,label] of the confirmed tracks (deep_sort.py:46-58)
+// Tracker state (header, ordered slot list, per-slot records, fp64 Kalman pool, gallery rings) lives in device memory between
+// batches; detections and tasks arrive in one host-to-device copy per batch, rows leave in one copy back.
 //
 // Reference (paths relative to /root/reference/networks/deepsort/sort/):
-//   kalman_filter.py:55-85   initiate            -> kalman_initiate_kernel
-//   kalman_filter.py:87-121  predict             -> kalman_predict_kernel   (F P F^T is exact: F is 0/1)
-//   kalman_filter.py:123-152 project             -> project4()
-//   kalman_filter.py:154-186 update              -> kalman_update_kernel    (4x4 Cholesky of S, K = P H^T S^-1)
-//   kalman_filter.py:188-229 gating_distance     -> maha4()
-//   nn_matching.py:31-54,78-96,160-177 distance  -> appearance_cost_kernel  (re-normalise, 1 - a.b, min over samples)
-//   linear_assignment.py:148-192 gate_cost_matrix-> appearance_cost_kernel  (chi2inv95[4] = 9.4877 -> 1e5)
-//   iou_matching.py:7-81     iou / iou_cost      -> iou_cost_kernel
-//   track.py:82-96           to_tlwh             -> mean_to_tlwh()
-// One wavefront owns one (track, detection) dot-product stream; reductions are wave shuffles, no atomics.
+//   kalman_filter.py:55-229  initiate / predict / project / update / gating_distance   -> kalman_*_wave, project4/chol4/maha4
+//   nn_matching.py:31-54,78-96,160-177 distance  -> appearance_row_dev (re-normalise, 1 - a.b, min over samples)
+//   linear_assignment.py:148-192 gate_cost_matrix-> appearance_row_dev (chi2inv95[4] = 9.4877 -> 1e5)
+//   iou_matching.py:7-81     iou / iou_cost      -> iou rows;  track.py:82-96 to_tlwh -> mean_to_tlwh
+//   tracker.py / linear_assignment.py / track.py -> track_core.h
+// The single-function entry points of the parity tests (vc_kalman_*_host, vc_cosine_cost_host, ...) launch kat_* kernels that
+// call exactly the __device__ functions the batch kernel calls.
+#include <algorithm>
+
 #include "kernels.h"
 
 #pragma clang fp contract(off)
 
+#include "track_core.h"
+
 namespace vc {
 
-#define VC_W_POS (1.0 / 20)
-#define VC_W_VEL (1.0 / 160)
-#define VC_CHI2_95_4 9.4877
-#define VC_GATED 1e5
-
-__device__ __forceinline__ void kalman_initiate_dev(double* m, double* P, const double* z) {
-    const double h = z[3];
-    for (int k = 0; k < 4; ++k) { m[k] = z[k]; m[4 + k] = 0.0; }
-    const double sp = (2 * VC_W_POS) * h, sv = (10 * VC_W_VEL) * h;
-    const double sd[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) P[r * 8 + c] = r == c ? sd[r] * sd[r] : 0.0;
-}
-
-__global__ __launch_bounds__(64) void kalman_initiate_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    kalman_initiate_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64, xyah + (size_t)i * 4);
-}
-
-__device__ __forceinline__ void kalman_predict_dev(double* m, double* P) {
-    const double h = m[3];
-    const double sp = VC_W_POS * h, sv = VC_W_VEL * h;
-    const double sd[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
-    double T[64];
-    // T = P F^T : column j < 4 gains column j+4
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) T[r * 8 + c] = c < 4 ? P[r * 8 + c] + P[r * 8 + c + 4] : P[r * 8 + c];
-    // P' = F T + Q : row r < 4 gains row r+4
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) {
-            double v = r < 4 ? T[r * 8 + c] + T[(r + 4) * 8 + c] : T[r * 8 + c];
-            if (r == c) v += sd[r] * sd[r];
-            P[r * 8 + c] = v;
-        }
-    for (int k = 0; k < 4; ++k) m[k] = m[k] + m[k + 4];
-}
-
-__global__ __launch_bounds__(64) void kalman_predict_kernel(TrackPool tp, const int* slots, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    kalman_predict_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64);
-}
-
-// S = H P H^T + R (4x4), projected mean = mean[:4]
-__device__ __forceinline__ void project4(const double* m, const double* P, double S[16]) {
-    const double sp = VC_W_POS * m[3];
-    const double sd[4] = {sp, sp, 1e-1, sp};
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) S[r * 4 + c] = P[r * 8 + c] + (r == c ? sd[r] * sd[r] : 0.0);
-}
-
-__device__ __forceinline__ void chol4(const double S[16], double L[16]) {
-    for (int i = 0; i < 16; ++i) L[i] = 0.0;
-    for (int j = 0; j < 4; ++j) {
-        double d = S[j * 4 + j];
-        for (int k = 0; k < j; ++k) d -= L[j * 4 + k] * L[j * 4 + k];
-        d = sqrt(d);
-        L[j * 4 + j] = d;
-        for (int i = j + 1; i < 4; ++i) {
-            double v = S[i * 4 + j];
-            for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
-            L[i * 4 + j] = v / d;
-        }
-    }
-}
-
-__device__ __forceinline__ void kalman_update_dev(double* m, double* P, const double* z) {
-    double S[16], L[16], K[32];
-    project4(m, P, S);
-    chol4(S, L);
-    // K^T = S^-1 (P H^T)^T : for each state row r solve S k = P[r, 0:4]
-    for (int r = 0; r < 8; ++r) {
-        double y[4];
-        for (int a = 0; a < 4; ++a) {            // L y = b
-            double v = P[r * 8 + a];
-            for (int k = 0; k < a; ++k) v -= L[a * 4 + k] * y[k];
-            y[a] = v / L[a * 4 + a];
-        }
-        for (int a = 3; a >= 0; --a) {           // L^T x = y
-            double v = y[a];
-            for (int k = a + 1; k < 4; ++k) v -= L[k * 4 + a] * K[r * 4 + k];
-            K[r * 4 + a] = v / L[a * 4 + a];
-        }
-    }
-    double innov[4];
-    for (int a = 0; a < 4; ++a) innov[a] = z[a] - m[a];
-    double nm[8];
-    for (int r = 0; r < 8; ++r) {
-        double v = 0.0;
-        for (int a = 0; a < 4; ++a) v += innov[a] * K[r * 4 + a];
-        nm[r] = m[r] + v;
-    }
-    // P' = P - K (S K^T)
-    double SKt[32];                               // 4 x 8
-    for (int a = 0; a < 4; ++a)
-        for (int c = 0; c < 8; ++c) {
-            double v = 0.0;
-            for (int k = 0; k < 4; ++k) v += S[a * 4 + k] * K[c * 4 + k];
-            SKt[a * 8 + c] = v;
-        }
-    for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c) {
-            double v = 0.0;
-            for (int a = 0; a < 4; ++a) v += K[r * 4 + a] * SKt[a * 8 + c];
-            P[r * 8 + c] = P[r * 8 + c] - v;
-        }
-    for (int r = 0; r < 8; ++r) m[r] = nm[r];
-}
+using namespace tc;
 
 // ---- one-wavefront forms of initiate / predict / update (lane = covariance element (r, c) = (lane >> 3, lane & 7)) ---
-// Every output element is produced by exactly the operation sequence of the single-thread forms above (same operands,
+// Every output element is produced by exactly the operation sequence of the single-thread forms of track_math.h (same operands,
 // same order, no cross-lane reductions), so the results are bit-identical; what changes is that the ~70 dependent fp64
 // divisions / square roots of an update are spread over the lanes.  Call with the 64 threads of ONE wave; kbuf is 32
-// doubles of LDS.
+// doubles of LDS private to that wave.
 __device__ __forceinline__ void kalman_initiate_wave(double* m, double* P, const double* z, int lane) {
     const int r = lane >> 3, c = lane & 7;
     const double h = z[3];
@@ -197,48 +99,19 @@ __device__ __forceinline__ void kalman_update_wave(double* m, double* P, const d
     if (lane < 8) m[lane] = nm;
 }
 
-__global__ __launch_bounds__(64) void kalman_update_kernel(TrackPool tp, const int* slots, const double* xyah, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    kalman_update_dev(tp.mean + (size_t)slots[i] * 8, tp.cov + (size_t)slots[i] * 64, xyah + (size_t)i * 4);
-}
-
-__device__ __forceinline__ double maha4(const double* m, const double L[16], const double* z) {
-    double y[4], acc = 0.0;
-    for (int a = 0; a < 4; ++a) {
-        double v = z[a] - m[a];
-        for (int k = 0; k < a; ++k) v -= L[a * 4 + k] * y[k];
-        y[a] = v / L[a * 4 + a];
-        acc += y[a] * y[a];
-    }
-    return acc;
-}
-
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-// store to host-mapped pinned memory: system-scope write-through, complete once the wave's vmcnt drains
-__device__ __forceinline__ void host_store(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// Descriptor loads (pinned host memory, or device memory in the KAT entry points).  Plain vector loads: a kernel lives for
-// one step, so nothing it reads from pinned memory can be stale, and neighbouring lanes coalesce into a few PCIe reads
-// (per-lane system-scope atomic loads do not coalesce: 16k read transactions per step, +10 us).
-__device__ __forceinline__ unsigned long long sys_load_u64(const void* p) { return *(const volatile unsigned long long*)p; }
-__device__ __forceinline__ unsigned sys_load_u32(const void* p) { return *(const volatile unsigned*)p; }
-__device__ __forceinline__ double sys_load_f64(const double* p) { return *(const volatile double*)p; }
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
     float smax[4][16];
-    float red[2];
     int featrow[16];                 // feature rows / xyah of the 16 detections being scored
     double xyah[16][4];
-    unsigned long long rec[12];      // the chain record being executed
-    double kbuf[32];                 // Kalman gain rows (kalman_update_wave)
+    double kbuf[4][32];              // Kalman gain rows, one block per wave (kalman_update_wave)
+    int ctl[8];                      // P1 -> P2/P3 hand-over: n_match, n_un, n_new, newdets is w.left, error
 };
 
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
-// cost[d] = min_s (1 - <g_s, f_d/|f_d|>) with the gallery rows g_s stored already normalised (store_gallery_row):
+// cost[d] = min_s (1 - <g_s, f_d/|f_d|>) with the gallery rows g_s stored already normalised (gallery_store_wave):
 // a (S x 512) x (512 x D) product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, an exact fmaf chain), one 16-sample
 // tile per wave against 16 detections at a time; |f_d|^2 falls out of the same operand loads.  The Mahalanobis gate of
 // linear_assignment.py:148-192 is folded in (lane d of wave 0).
@@ -250,13 +123,12 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
     const double* m = tp.mean + (size_t)jb.slot * 8;
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
-        // the chunk's descriptors -> LDS (one round trip to pinned memory for all 16 detections)
         if (threadIdx.x < 16) {
             const int d = jb.det_off + min(d0 + (int)threadIdx.x, D - 1);
-            sh.featrow[threadIdx.x] = (int)sys_load_u32(det_feat_row + d);
+            sh.featrow[threadIdx.x] = det_feat_row[d];
         } else if (threadIdx.x < 80) {
             const int t = threadIdx.x - 16, d = jb.det_off + min(d0 + (t >> 2), D - 1);
-            sh.xyah[t >> 2][t & 3] = sys_load_f64(det_xyah + (size_t)d * 4 + (t & 3));
+            sh.xyah[t >> 2][t & 3] = det_xyah[(size_t)d * 4 + (t & 3)];
         }
         __syncthreads();
         const float* fptr = feat + (size_t)sh.featrow[col] * VC_FEAT_DIM + kq * 4;
@@ -294,152 +166,238 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
             project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
             chol4(Sg, L);
             const double g2 = maha4(m, L, sh.xyah[lane]);
-            host_store(out + jb.out_off + d0 + lane, g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv));
+            out[jb.out_off + d0 + lane] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
         }
         __syncthreads();
     }
 }
 
-// gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector)
-__device__ __forceinline__ void store_gallery_row(float* dst, const float* src, int t /* threads 0..127 work */, float* red /* [2] */) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < 128) v = ((const float4*)src)[t];
-    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+// gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector).
+// One wave: lane l holds elements [4l, 4l+4) and [256 + 4l, 256 + 4l + 4).
+__device__ __forceinline__ void gallery_store_wave(float* dst, const float* src, int lane) {
+    const float4 a = ((const float4*)src)[lane], b = ((const float4*)src)[64 + lane];
+    float ss = (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (t < 128 && (t & 63) == 0) red[t >> 6] = ss;
-    __syncthreads();
-    const float nrm = sqrtf(red[0] + red[1]);
-    if (t < 128) ((float4*)dst)[t] = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+    const float nrm = sqrtf(ss);
+    ((float4*)dst)[lane] = make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm);
+    ((float4*)dst)[64 + lane] = make_float4(b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm);
 }
 
-__global__ __launch_bounds__(256) void appearance_cost_kernel(TrackPool tp, const CostJob* jobs, const float* feat, const int* det_feat_row,
-                                                              const double* det_xyah, double* out) {
+// ---- slot pool: during a kernel slots are only TAKEN from the free stack (filled before the launch) and freed slots are only
+// APPENDED to a separate list; merge_free_kernel moves them over between batches.  A slot therefore never changes owner inside
+// a kernel: the XCDs' L2s are not coherent with each other, and a slot freed by a workgroup on one XCD and re-initialised by a
+// workgroup on another would end with whichever dirty line is written back last.
+__device__ __forceinline__ bool pool_take(const TrackBatchArgs& a, int n, int* out, int lane) {
+    int base = 0;
+    if (lane == 0) {
+        const int t = __hip_atomic_fetch_sub(a.free_top, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < n) { __hip_atomic_fetch_add(a.free_top, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); base = -1; }
+        else base = t - n;
+    }
+    base = __shfl(base, 0);
+    if (base < 0) return false;
+    for (int i = lane; i < n; i += 64) out[i] = a.free_stack[base + i];
+    return true;
+}
+
+__device__ __forceinline__ void report_error(const TrackBatchArgs& a, TrackerHdr* hdr, int code, int tracker, int task) {
+    hdr->err = code;
+    if (__hip_atomic_exchange(a.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { a.status[1] = tracker; a.status[2] = task; }
+}
+
+extern __shared__ __attribute__((aligned(16))) char track_dyn_lds[];
+
+__global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a) {
     __shared__ TrackShared sh;
-    appearance_row_dev(tp, jobs[blockIdx.x], feat, det_feat_row, det_xyah, out, sh);
-}
+    StepWork w;
+    step_work_carve(w, track_dyn_lds, a.cap);
+    const TrackWgPlan plan = a.plans[blockIdx.x];
+    TrackerHdr* hdr = a.hdrs + plan.tracker;
+    int* list = a.lists + (size_t)plan.tracker * a.list_cap;
+    const size_t mat = (size_t)a.cap * a.cap;
+    double* cost_app = a.scratch + (size_t)blockIdx.x * 4 * mat;
+    double* cost_iou = cost_app + mat;
+    double* cbuf = cost_iou + mat;
+    double* tbuf = cbuf + mat;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Lanes L{lane, 64};
+    const TrackPool& tp = a.pool;
 
-__device__ __forceinline__ double iou_tlwh(const double* b, const double* c);
-__device__ __forceinline__ void mean_to_tlwh(const double* m, double t[4]) {
-    t[2] = m[2] * m[3];
-    t[3] = m[3];
-    t[0] = m[0] - t[2] / 2;
-    t[1] = m[1] - t[3] / 2;
-}
-
-__global__ __launch_bounds__(64) void iou_cost_kernel(TrackPool tp, const CostJob* jobs, const double* __restrict__ det_tlwh,
-                                                      double* __restrict__ out) {
-    const CostJob jb = jobs[blockIdx.x];
-    double b[4];
-    mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
-    for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x) {
-        if (jb.tsu > 1) { out[jb.out_off + d] = VC_GATED; continue; }
-        out[jb.out_off + d] = 1.0 - iou_tlwh(b, det_tlwh + (size_t)(jb.det_off + d) * 4);
-    }
-}
-
-__global__ __launch_bounds__(128) void gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
-    __shared__ float red[2];
-    const int* e = sps + (size_t)blockIdx.x * 3;
-    store_gallery_row(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x, red);
-}
-
-// ---- per-frame tracker work (tracker.hip: track_launch) -------------------------------------------------------------
-// A "chain" is everything one track slot needs between two host matching steps: first the slot's pending operation of
-// frame f -- Kalman update (kind 1) / initiate (kind 2) / nothing (kind 0), the gallery ring write of the matched feature
-// and the posterior mean of output-eligible tracks to the host -- then the slot's cost job of frame f+1: Kalman predict in
-// place, (confirmed tracks) the appearance + gate row and (IoU candidates) the IoU row against its tracker's detections.
-// A slot belongs to exactly one chain per step, so chains never wait for each other.  Records, detections and results
-// live in host-mapped pinned memory: no copy operations.
-__device__ __forceinline__ void run_chain(const TrackPool& tp, const TrackChainRec* rec_ptr, const float* feat_ops, const float* feat_jobs,
-                                          double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh,
-                                          double* out, TrackShared& sh) {
-    if (threadIdx.x < 12) sh.rec[threadIdx.x] = sys_load_u64((const unsigned long long*)rec_ptr + threadIdx.x);
-    __syncthreads();
-    const TrackChainRec& rec = *(const TrackChainRec*)sh.rec;
-    const TrackOpB op = rec.op;
-    const TrackJobA jb = rec.job;
-    __syncthreads();                       // sh.rec is free again
-    if (op.kind >= 0) {
-        double* m = tp.mean + (size_t)op.slot * 8;
-        if (threadIdx.x < 64) {            // wave 0
-            if (op.kind == 1) kalman_update_wave(m, tp.cov + (size_t)op.slot * 64, op.z, threadIdx.x, sh.kbuf);
-            else if (op.kind == 2) kalman_initiate_wave(m, tp.cov + (size_t)op.slot * 64, op.z, threadIdx.x);
+    for (int task = plan.task_begin; task < plan.task_end; ++task) {
+        const TrackTask tk = a.tasks[task];
+        const int T = hdr->n_tracks, D = tk.det_n;
+        const int prior = hdr->err;
+        // every capacity check comes before anything is mutated: a refused step leaves the tracker exactly as it was
+        if (prior != TERR_NONE || T + D > a.cap || T + D > a.list_cap) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (prior == TERR_NONE) report_error(a, hdr, TERR_TRACK_CAP, plan.tracker, task);
+                a.task_row_n[task] = 0; a.task_row_off[task] = 0; a.task_ntracks[task] = T; a.task_T[task] = T;
+            }
+            __syncthreads();
+            continue;
         }
-        if (op.feat_row >= 0)              // block-uniform
-            store_gallery_row(tp.gallery + ((size_t)op.slot * tp.budget_cap + op.gal_pos) * VC_FEAT_DIM,
-                              feat_ops + (size_t)op.feat_row * VC_FEAT_DIM, threadIdx.x, sh.red);
-        __syncthreads();
-        if (op.out_row >= 0 && threadIdx.x < 8) host_store(mean_out + (size_t)op.out_row * 8 + threadIdx.x, m[threadIdx.x]);
-        __syncthreads();
-    }
-    if (jb.slot >= 0) {
-        if (threadIdx.x < 64) kalman_predict_wave(tp.mean + (size_t)jb.slot * 8, tp.cov + (size_t)jb.slot * 64, threadIdx.x);
-        __syncthreads();
-        if (jb.app_off >= 0) {
-            const CostJob cj{jb.slot, jb.gal_count, jb.det_off, jb.det_n, jb.app_off, jb.tsu};
-            appearance_row_dev(tp, cj, feat_jobs, det_feat_row, det_xyah, out, sh);
+        // ---- P0: Track.predict (track.py:112-124) + cost rows -------------------------------------------------------------
+        for (int t = wave; t < T; t += 4) {
+            const int slot = list[t];
+            if (lane == 0) {
+                TrackRecD& r = a.recs[slot];
+                const int age = r.age + 1, tsu = r.tsu + 1;
+                r.age = age; r.tsu = tsu;
+                w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head;
+            }
+            kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane);
         }
-        if (jb.iou_off >= 0) {
-            double b[4];
-            mean_to_tlwh(tp.mean + (size_t)jb.slot * 8, b);
-            for (int d = threadIdx.x; d < jb.det_n; d += blockDim.x) {
-                double c[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) c[k] = sys_load_f64(det_tlwh + (size_t)(jb.det_off + d) * 4 + k);
-                host_store(out + jb.iou_off + d, jb.tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, c));
+        __syncthreads();
+        if (D > 0) {
+            for (int t = 0; t < T; ++t) {                               // block-uniform
+                const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
+                if (st == CONFIRMED) {
+                    const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
+                    appearance_row_dev(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, sh);
+                }
+                if (!(st == CONFIRMED && tsu != 1)) {                   // IoU candidates only (tracker.py:118-120)
+                    double b[4];
+                    mean_to_tlwh(tp.mean + (size_t)slot * 8, b);
+                    for (int d = threadIdx.x; d < D; d += blockDim.x)
+                        cost_iou[(size_t)t * D + d] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + d) * 4);
+                }
             }
         }
-    }
-}
-
-// One launch per step (the blocking entry points and the profiling mode): one workgroup per chain; the last workgroup to
-// finish publishes `seq` to a pinned word, which the host polls instead of paying a stream synchronisation.
-__global__ __launch_bounds__(256) void track_step_kernel(TrackPool tp, const TrackChainRec* recs, const float* feat_ops,
-                                                         const float* feat_jobs, double* mean_out, const int* det_feat_row,
-                                                         const double* det_xyah, const double* det_tlwh, double* out,
-                                                         unsigned* counter, unsigned* done_flag, unsigned seq) {
-    __shared__ TrackShared sh;
-    run_chain(tp, recs + blockIdx.x, feat_ops, feat_jobs, mean_out, det_feat_row, det_xyah, det_tlwh, out, sh);
-    // completion: results went to pinned memory as system-scope write-through stores (host_store), so a workgroup only
-    // has to wait for its own stores to be acknowledged
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // relaxed on purpose: an agent/system RELEASE here is a write-back of the XCD's whole L2 (full of the detector's
-        // dirty output lines) per workgroup; the results are already write-through and acknowledged (vmcnt(0) above)
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        // ---- P1: matching (wave 0) --------------------------------------------------------------------------------------------
+        if (wave == 0) {
+            int n_match = 0, n_un = 0, n_new = 0, err = TERR_NONE;
+            int* newdets = nullptr;
+            match_step(L, w, *hdr, T, D, cost_app, cost_iou, cbuf, tbuf, n_match, n_un, newdets, n_new, err);
+            if (err == TERR_NONE && n_new > 0 && !pool_take(a, n_new, w.newslot, lane)) err = TERR_POOL;
+            if (lane == 0) { sh.ctl[0] = n_match; sh.ctl[1] = n_un; sh.ctl[2] = n_new; sh.ctl[3] = newdets == w.left ? 1 : 0; sh.ctl[4] = err; }
         }
+        __syncthreads();
+        const int n_match = sh.ctl[0], n_un = sh.ctl[1], n_new = sh.ctl[2], err = sh.ctl[4];
+        const int* newdets = sh.ctl[3] ? w.left : w.un_cols;
+        if (err != TERR_NONE) {                                          // pool exhausted / infeasible assignment: the tracker stops here
+            if (threadIdx.x == 0) {
+                report_error(a, hdr, err, plan.tracker, task);
+                a.task_row_n[task] = 0; a.task_row_off[task] = 0; a.task_ntracks[task] = T; a.task_T[task] = T;
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---- P2: Kalman update / initiate + gallery ring writes, one wave per operation ------------------------------------------
+        for (int k = wave; k < n_match + n_new; k += 4) {
+            if (k < n_match) {                                           // Track.update (track.py:126-145)
+                const int t = w.match_t[k], g = tk.det_off + w.match_d[k], slot = w.slot[t];
+                kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave]);
+                gallery_store_wave(tp.gallery + ((size_t)slot * tp.budget_cap + w.galh[t]) * VC_FEAT_DIM, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+            } else {                                                     // _initiate_track (tracker.py:133-139)
+                const int i = k - n_match, g = tk.det_off + newdets[i], slot = w.newslot[i];
+                kalman_initiate_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane);
+                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+            }
+        }
+        __syncthreads();
+        // ---- P3: FSM, list maintenance, rows (wave 0) -----------------------------------------------------------------------------
+        if (wave == 0) {
+            const int n = finish_step(L, w, hdr, list, a.recs, T, n_match, n_un, n_new, [&](const int* slots, int nd) {
+                int pos = 0;
+                if (lane == 0) pos = __hip_atomic_fetch_add(a.freed_count, nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pos = __shfl(pos, 0);
+                for (int i = lane; i < nd; i += 64) a.freed[pos + i] = slots[i];
+            });
+            const int m = compact(L, n, [&](int t) { const TrackRecD& r = a.recs[list[t]]; return r.state == CONFIRMED && r.tsu <= 1; }, [](int, int) {});
+            int base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add(a.row_cursor, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = __shfl(base, 0);
+            if (base + m > a.rows_cap) {
+                if (lane == 0) { report_error(a, hdr, TERR_ROWS, plan.tracker, task); a.task_row_n[task] = 0; a.task_row_off[task] = 0; }
+            } else {
+                emit_rows(L, list, a.recs, tp.mean, n, a.frame_w, a.frame_h, tk.label, [&](int pos, const long long* row) {
+                    long long* o = a.rows + (size_t)(base + pos) * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) o[c] = row[c];
+                });
+                if (lane == 0) { a.task_row_n[task] = m; a.task_row_off[task] = base; }
+            }
+            if (lane == 0) { a.task_ntracks[task] = n; a.task_T[task] = T; }
+        }
+        __syncthreads();
     }
 }
 
-int launch_track_step(const TrackPool& tp, const TrackChainRec* recs, int nchains, const float* feat_ops, const float* feat_jobs,
-                      double* mean_out, const int* det_feat_row, const double* det_xyah, const double* det_tlwh, double* out,
-                      unsigned* counter, unsigned* done_flag, unsigned seq, hipStream_t s) {
-    if (nchains <= 0) return VC_OK;
-    hipLaunchKernelGGL(track_step_kernel, dim3(nchains), dim3(256), 0, s, tp, recs, feat_ops, feat_jobs, mean_out, det_feat_row,
-                       det_xyah, det_tlwh, out, counter, done_flag, seq);
+// freed slots of the last batch -> free stack (between batches, one workgroup)
+__global__ __launch_bounds__(256) void merge_free_kernel(int* free_top, int* free_stack, int* freed_count, const int* freed) {
+    const int n = *freed_count, top = *free_top;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) free_stack[top + i] = freed[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { *free_top = top + n; *freed_count = 0; }
+}
+
+int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
+    if (n_wg <= 0) return VC_OK;
+    const size_t lds = step_work_bytes(a.cap);
+    VC_CHECK(a.cap % 8 == 0 && lds <= 64 * 1024 - 4096, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
+    hipLaunchKernelGGL(track_batch_kernel, dim3(n_wg), dim3(256), lds, s, a);
+    VC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(merge_free_kernel, dim3(1), dim3(256), 0, s, a.free_top, a.free_stack, a.freed_count, a.freed);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
 
-__device__ __forceinline__ double iou_tlwh(const double* b, const double* c) {
-    const double tlx = fmax(b[0], c[0]), tly = fmax(b[1], c[1]);
-    const double brx = fmin(b[0] + b[2], c[0] + c[2]), bry = fmin(b[1] + b[3], c[1] + c[3]);
-    const double w = fmax(0.0, brx - tlx), h = fmax(0.0, bry - tly);
-    const double inter = w * h;
-    return inter / (b[2] * b[3] + c[2] * c[3] - inter);
+// ---- single-function kernels of the parity tests: the batch kernel's own __device__ functions on caller-supplied state --------
+template <int WHICH>      // 0 initiate, 1 predict, 2 update
+__global__ __launch_bounds__(64) void kat_kalman_kernel(TrackPool tp, const double* z, int n) {
+    __shared__ double kbuf[32];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    double* m = tp.mean + (size_t)i * 8;
+    double* P = tp.cov + (size_t)i * 64;
+    if (WHICH == 0) kalman_initiate_wave(m, P, z + (size_t)i * 4, lane);
+    else if (WHICH == 1) kalman_predict_wave(m, P, lane);
+    else kalman_update_wave(m, P, z + (size_t)i * 4, lane, kbuf);
 }
 
-__global__ __launch_bounds__(64) void iou_boxes_kernel(const double* a, int t, const double* b, int d, double* out) {
+int launch_kat_kalman(TrackPool& tp, int which, const double* z, int n, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    if (which == 0) hipLaunchKernelGGL(kat_kalman_kernel<0>, dim3(n), dim3(64), 0, s, tp, z, n);
+    else if (which == 1) hipLaunchKernelGGL(kat_kalman_kernel<1>, dim3(n), dim3(64), 0, s, tp, z, n);
+    else hipLaunchKernelGGL(kat_kalman_kernel<2>, dim3(n), dim3(64), 0, s, tp, z, n);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+__global__ __launch_bounds__(256) void kat_appearance_kernel(TrackPool tp, const CostJob* jobs, const float* feat, const int* det_feat_row,
+                                                            const double* det_xyah, double* out) {
+    __shared__ TrackShared sh;
+    appearance_row_dev(tp, jobs[blockIdx.x], feat, det_feat_row, det_xyah, out, sh);
+}
+
+int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const float* feat, const int* det_feat_row,
+                           const double* det_xyah, double* out, hipStream_t s) {
+    if (njobs <= 0) return VC_OK;
+    hipLaunchKernelGGL(kat_appearance_kernel, dim3(njobs), dim3(256), 0, s, tp, jobs, feat, det_feat_row, det_xyah, out);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+__global__ __launch_bounds__(64) void kat_gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
+    const int* e = sps + (size_t)blockIdx.x * 3;
+    gallery_store_wave(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x);
+}
+
+int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {
+    if (n <= 0) return VC_OK;
+    hipLaunchKernelGGL(kat_gallery_write_kernel, dim3(n), dim3(64), 0, s, tp, slot_pos_src, feat);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+__global__ __launch_bounds__(64) void kat_iou_boxes_kernel(const double* a, int t, const double* b, int d, double* out) {
     const int i = blockIdx.x;
     for (int j = threadIdx.x; j < d; j += blockDim.x) out[(size_t)i * d + j] = iou_tlwh(a + (size_t)i * 4, b + (size_t)j * 4);
 }
 
-__global__ __launch_bounds__(64) void gating_values_kernel(TrackPool tp, int slot, const double* z, int n, double* out) {
+__global__ __launch_bounds__(64) void kat_gating_kernel(TrackPool tp, int slot, const double* z, int n, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* m = tp.mean + (size_t)slot * 8;
@@ -449,61 +407,32 @@ __global__ __launch_bounds__(64) void gating_values_kernel(TrackPool tp, int slo
     out[i] = maha4(m, L, z + (size_t)i * 4);
 }
 
-int launch_gating_values(const TrackPool& tp, int slot, const double* z, int n, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(gating_values_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slot, z, n, out);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
+// scipy.optimize.linear_sum_assignment through the batch kernel's own solver (one wave, work arrays in LDS)
+__global__ __launch_bounds__(64) void kat_lap_kernel(const double* cost, int nr, int nc, int cap, double* tbuf, int* out_rows, int* out_cols, int* out_n) {
+    StepWork w;
+    step_work_carve(w, track_dyn_lds, cap);
+    const Lanes L{(int)threadIdx.x, 64};
+    int err = TERR_NONE;
+    const int np = lap_solve(L, w, cost, nr, nc, tbuf, err);
+    for (int k = L.lane; k < np; k += 64) { out_rows[k] = w.ri[k]; out_cols[k] = w.ci[k]; }
+    if (L.lane == 0) *out_n = err == TERR_NONE ? np : -1;
 }
-int launch_iou_boxes(const double* a, int t, const double* b, int d, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(iou_boxes_kernel, dim3(t), dim3(64), 0, s, a, t, b, d, out);
+
+int launch_kat_lap(const double* cost, int nr, int nc, double* tbuf, int* out_rows, int* out_cols, int* out_n, hipStream_t s) {
+    const int cap = (std::max(nr, nc) + 7) / 8 * 8;
+    VC_CHECK(step_work_bytes(cap) <= 60 * 1024, VC_ERR_CAPACITY, "lap: at most 512 rows / columns");
+    hipLaunchKernelGGL(kat_lap_kernel, dim3(1), dim3(64), step_work_bytes(cap), s, cost, nr, nc, cap, tbuf, out_rows, out_cols, out_n);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
 
-int launch_kalman_predict(TrackPool& tp, const int* slots, int n, hipStream_t s) {
-    if (n <= 0) return VC_OK;
-    hipLaunchKernelGGL(kalman_predict_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, n);
+int launch_gating_values(const TrackPool& tp, int slot, const double* z, int n, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(kat_gating_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slot, z, n, out);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
-int launch_kalman_initiate(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s) {
-    if (n <= 0) return VC_OK;
-    hipLaunchKernelGGL(kalman_initiate_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, xyah, n);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-int launch_kalman_update(TrackPool& tp, const int* slots, const double* xyah, int n, hipStream_t s) {
-    if (n <= 0) return VC_OK;
-    hipLaunchKernelGGL(kalman_update_kernel, dim3((n + 63) / 64), dim3(64), 0, s, tp, slots, xyah, n);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const float* feat, const int* det_feat_row,
-                           const double* det_xyah, double* out, hipStream_t s) {
-    if (njobs <= 0) return VC_OK;
-    hipLaunchKernelGGL(appearance_cost_kernel, dim3(njobs), dim3(256), 0, s, tp, jobs, feat, det_feat_row, det_xyah, out);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-int launch_iou_cost(const TrackPool& tp, const CostJob* jobs, int njobs, const double* det_tlwh, double* out, hipStream_t s) {
-    if (njobs <= 0) return VC_OK;
-    hipLaunchKernelGGL(iou_cost_kernel, dim3(njobs), dim3(64), 0, s, tp, jobs, det_tlwh, out);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-__global__ __launch_bounds__(256) void gather_means_kernel(TrackPool tp, const int* __restrict__ slots, int n, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n * 8) out[i] = tp.mean[(size_t)slots[i >> 3] * 8 + (i & 7)];
-}
-int launch_gather_means(const TrackPool& tp, const int* slots, int n, double* out, hipStream_t s) {
-    if (n <= 0) return VC_OK;
-    hipLaunchKernelGGL(gather_means_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, s, tp, slots, n, out);
-    VC_HIP(hipGetLastError());
-    return VC_OK;
-}
-int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {
-    if (n <= 0) return VC_OK;
-    hipLaunchKernelGGL(gallery_write_kernel, dim3(n), dim3(128), 0, s, tp, slot_pos_src, feat);
+int launch_iou_boxes(const double* a, int t, const double* b, int d, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(kat_iou_boxes_kernel, dim3(t), dim3(64), 0, s, a, t, b, d, out);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

@@ -1,128 +1,26 @@
-// DeepSORT tracker: host-side track lifecycle + assignment around the batched device numerics of
-// track_kernels.hip.  One Tracker per (camera, class) like the reference (modules/track.py:16); all of a frame's
-// trackers are stepped together so a frame costs two host<->device round trips regardless of the class count.
+// DeepSORT tracker, host side: the tracker state is device-resident and every step runs inside track_batch_kernel
+// (track_kernels.hip); the host only prepares a batch's detections -- confidence filter and DeepSORT NMS, which do not depend
+// on tracker state -- packs them with the (frame, class) task list into one host-to-device copy, launches ONE kernel per batch
+// and reads the rows the kernel wrote into pinned memory.  One tracker per (camera, class) like the reference
+// (modules/track.py:16).
 //
 // Reference (paths relative to /root/reference/networks/deepsort/):
-//   sort/tracker.py:40-139        Tracker.predict / update / _match / _initiate_track
-//   sort/track.py:4-175           Track state machine (Tentative -> Confirmed -> Deleted), counters
-//   sort/linear_assignment.py     min_cost_matching :13-77, matching_cascade :80-145 (gate folded into the kernel)
-//   sort/nn_matching.py:137-154   partial_fit: per-target sample lists trimmed to `budget` (device ring buffer here)
-//   sort/preprocessing.py:6-73    non_max_suppression (quirk Q6)
-//   deep_sort.py:25-59            DeepSort.update; modules/track.py:30-70 VideoTracker.run
-//   scipy.optimize.linear_sum_assignment (third-party; Crouse's shortest augmenting path, restated in lap_solve)
+//   deep_sort.py:25-59            DeepSort.update (confidence filter :31, tlwh :68-87, NMS :37-41, predict/update :44-45, rows :46-58)
+//   sort/preprocessing.py:6-73    non_max_suppression (quirk Q6)                      -> dsort_nms (host: state-independent)
+//   sort/tracker.py, sort/track.py, sort/linear_assignment.py, sort/nn_matching.py, sort/kalman_filter.py, sort/iou_matching.py
+//                                 -> track_core.h + track_kernels.hip (device)
+//   modules/track.py:30-70        VideoTracker.run (one DeepSORT per class, classes without boxes are not stepped)
 #include <algorithm>
 #include <cstring>
-#include <atomic>
-#include <chrono>
 #include <cmath>
-#include <limits>
-#include <map>
 #include <numeric>
 
 #include "engine.h"
+#include "track_core.h"
 
 namespace vc {
 
-enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
-
-// ------------------------------------------------------------------------------------------------ LSAP
-// Rectangular linear sum assignment, same algorithm and tie-breaking as SciPy's rectangular_lsap
-// (D. F. Crouse, "On implementing 2D rectangular assignment algorithms", 2016): returns pairs sorted by row.
-static int lsap_core(int nr, int nc, const double* cost, std::vector<int>& col4row) {
-    const double INF = std::numeric_limits<double>::infinity();
-    // scratch reused across calls (a frame makes 10-20 small assignments; the heap traffic was a third of the host step)
-    static thread_local std::vector<double> u, v, spc;
-    static thread_local std::vector<int> path, row4col, remaining;
-    static thread_local std::vector<char> SR, SC;
-    u.assign(nr, 0.0); v.assign(nc, 0.0); spc.resize(nc);
-    path.assign(nc, -1); row4col.assign(nc, -1); remaining.resize(nc);
-    SR.resize(nr); SC.resize(nc);
-    col4row.assign(nr, -1);
-    for (int cur = 0; cur < nr; ++cur) {
-        double minVal = 0;
-        int i = cur, num_remaining = nc, sink = -1;
-        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
-        std::fill(SR.begin(), SR.end(), 0);
-        std::fill(SC.begin(), SC.end(), 0);
-        std::fill(spc.begin(), spc.end(), INF);
-        while (sink == -1) {
-            int index = -1;
-            double lowest = INF;
-            SR[i] = 1;
-            for (int it = 0; it < num_remaining; ++it) {
-                const int j = remaining[it];
-                const double r = minVal + cost[(size_t)i * nc + j] - u[i] - v[j];
-                if (r < spc[j]) { path[j] = i; spc[j] = r; }
-                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
-            }
-            minVal = lowest;
-            if (minVal == INF) return -1;
-            const int j = remaining[index];
-            if (row4col[j] == -1) sink = j; else i = row4col[j];
-            SC[j] = 1;
-            remaining[index] = remaining[--num_remaining];
-        }
-        u[cur] += minVal;
-        for (int r = 0; r < nr; ++r) if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
-        for (int j = 0; j < nc; ++j) if (SC[j]) v[j] -= minVal - spc[j];
-        int j = sink;
-        while (true) {
-            const int r = path[j];
-            row4col[j] = r;
-            std::swap(col4row[r], j);
-            if (r == cur) break;
-        }
-    }
-    return 0;
-}
-
-int lap_solve(const double* cost, int nr, int nc, std::vector<int>& rows, std::vector<int>& cols) {
-    rows.clear(); cols.clear();
-    if (nr == 0 || nc == 0) return VC_OK;
-    static thread_local std::vector<int> c4r;
-    static thread_local std::vector<double> t;
-    if (nc < nr) {                       // SciPy transposes so that rows <= cols
-        t.resize((size_t)nr * nc);
-        for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) t[(size_t)j * nr + i] = cost[(size_t)i * nc + j];
-        VC_CHECK(lsap_core(nc, nr, t.data(), c4r) == 0, VC_ERR_ARG, "lap: infeasible cost matrix");
-        std::vector<int> order(nc);
-        std::iota(order.begin(), order.end(), 0);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return c4r[a] < c4r[b]; });
-        for (int v : order) { rows.push_back(c4r[v]); cols.push_back(v); }
-    } else {
-        VC_CHECK(lsap_core(nr, nc, cost, c4r) == 0, VC_ERR_ARG, "lap: infeasible cost matrix");
-        for (int i = 0; i < nr; ++i) { rows.push_back(i); cols.push_back(c4r[i]); }
-    }
-    return VC_OK;
-}
-
-// sort/linear_assignment.py:52-77 on a dense sub-matrix given as full rows + selected columns
-struct MatchOut { std::vector<std::pair<int, int>> matches; std::vector<int> un_rows, un_cols; };
-static int min_cost_matching(const std::vector<const double*>& row_ptr, const std::vector<int>& rows, const std::vector<int>& cols,
-                             double max_cost, MatchOut& out) {
-    out.matches.clear(); out.un_rows.clear(); out.un_cols.clear();
-    const int nr = (int)rows.size(), nc = (int)cols.size();
-    if (nr == 0 || nc == 0) { out.un_rows = rows; out.un_cols = cols; return VC_OK; }
-    static thread_local std::vector<double> c;
-    static thread_local std::vector<int> ri, ci;
-    static thread_local std::vector<char> col_used, row_used;
-    c.resize((size_t)nr * nc);
-    for (int i = 0; i < nr; ++i)
-        for (int j = 0; j < nc; ++j) {
-            const double v = row_ptr[i][cols[j]];
-            c[(size_t)i * nc + j] = v > max_cost ? max_cost + 1e-5 : v;
-        }
-    VC_TRY(lap_solve(c.data(), nr, nc, ri, ci));
-    col_used.assign(nc, 0); row_used.assign(nr, 0);
-    for (size_t k = 0; k < ri.size(); ++k) { row_used[ri[k]] = 1; col_used[ci[k]] = 1; }
-    for (int j = 0; j < nc; ++j) if (!col_used[j]) out.un_cols.push_back(cols[j]);
-    for (int i = 0; i < nr; ++i) if (!row_used[i]) out.un_rows.push_back(rows[i]);
-    for (size_t k = 0; k < ri.size(); ++k) {
-        if (c[(size_t)ri[k] * nc + ci[k]] > max_cost) { out.un_rows.push_back(rows[ri[k]]); out.un_cols.push_back(cols[ci[k]]); }
-        else out.matches.emplace_back(rows[ri[k]], cols[ci[k]]);
-    }
-    return VC_OK;
-}
+using namespace tc;
 
 // sort/preprocessing.py:6-73 (overlap = inter / area(other), +1 pixel, '>' threshold; quirk Q6)
 void dsort_nms(const double* tlwh, const double* scores, int n, double max_overlap, std::vector<int>& keep) {
@@ -150,340 +48,6 @@ void dsort_nms(const double* tlwh, const double* scores, int n, double max_overl
     }
 }
 
-// ------------------------------------------------------------------------------------------------ pool
-static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-int tracker_init_pool(vc_engine* e) {
-    const size_t T = e->cfg.max_tracks, S = e->cfg.nn_budget_cap;
-    VC_CHECK(T >= 1 && S >= 1, VC_ERR_ARG, "max_tracks and nn_budget_cap must be positive");
-    e->pool.max_tracks = (int)T; e->pool.budget_cap = (int)S;
-    VC_TRY(dev_alloc(e, (void**)&e->pool.mean, T * 8 * sizeof(double)));
-    VC_TRY(dev_alloc(e, (void**)&e->pool.cov, T * 64 * sizeof(double)));
-    VC_TRY(dev_alloc(e, (void**)&e->pool.gallery, T * S * VC_FEAT_DIM * sizeof(float)));
-    e->free_slots.resize(T);
-    for (size_t i = 0; i < T; ++i) e->free_slots[i] = (int)(T - 1 - i);
-    e->det_cap = std::max(e->cfg.max_det * 2, 1024);
-    e->cost_cap = (size_t)2 * T * 512;
-    const size_t D = e->det_cap;
-    // one pinned staging block per phase, mirrored on the device: a phase costs ONE host->device copy
-    e->stage_cap = align16((T + D) * 4) + 2 * align16(D * 32) + align16(2 * T * sizeof(CostJob)) +      // phase A
-                   2 * align16(T * 4) + 2 * align16((T + D) * 32) + align16((T + D) * 12) + 256;          // phase B (superset)
-    e->stage_cap = std::max(e->stage_cap, (T + D) * sizeof(TrackChainRec) + 256);
-    e->slot_chain.assign(T, -1);
-    VC_TRY(dev_alloc(e, (void**)&e->d_track_counter, 64));
-    VC_HIP(hipMemset(e->d_track_counter, 0, 64));
-    VC_TRY(host_alloc(e, (void**)&e->h_track_flag, 64));
-    memset(e->h_track_flag, 0, 64);
-    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_track_flag, e->h_track_flag, 0));
-    // pinned + device-mapped: the per-frame kernels read their descriptors from and write their results to host memory
-    VC_TRY(host_alloc(e, (void**)&e->h_stage, e->stage_cap));
-    VC_TRY(host_alloc(e, (void**)&e->h_stage2, e->stage_cap));
-    VC_TRY(host_alloc(e, (void**)&e->h_cost, e->cost_cap * sizeof(double)));
-    VC_TRY(host_alloc(e, (void**)&e->h_mean, T * 8 * sizeof(double)));
-    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_stage, e->h_stage, 0));
-    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_stage2, e->h_stage2, 0));
-    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_cost, e->h_cost, 0));
-    VC_HIP(hipHostGetDevicePointer((void**)&e->hd_mean, e->h_mean, 0));
-    VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, D * VC_FEAT_DIM * sizeof(float)));
-    return VC_OK;
-}
-
-static int slot_alloc(vc_engine* e) {
-    if (e->free_slots.empty()) return -1;
-    const int slot = e->free_slots.back();
-    e->free_slots.pop_back();
-    return slot;
-}
-static void slot_free(vc_engine* e, int slot) { e->free_slots.push_back(slot); }
-
-static void tlwh_to_xyah(const double* t, double* o) {      // sort/detection.py:42-50
-    o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
-}
-
-// bump allocator over the pinned staging block; device addresses mirror host offsets
-struct Stage {
-    char* h; char* d; size_t cap, off = 0;
-    template <class T> T* take(size_t n, T** dev) {
-        T* p = (T*)(h + off);
-        *dev = (T*)(d + off);
-        off = align16(off + n * sizeof(T));
-        return p;
-    }
-};
-
-// One tracker step for a set of trackers (all classes of one frame), split at its only data dependency on the device:
-//   track_prepare_a  (host)    Tracker.predict bookkeeping, one cost job per live track (predict + appearance/gate + IoU rows)
-//   track_launch     (device)  the pending operations of the PREVIOUS frame and the cost jobs of this one, one kernel
-//   track_wait       (host)    poll the completion word; the cost rows (and the previous frame's posterior means) are in
-//                              pinned memory
-//   track_host_b     (host)    matching cascade + IoU matching (exact LSAP), Track.update / mark_missed / _initiate_track:
-//                              the Kalman update / initiate / gallery writes become the pending operations of this frame
-// so a frame costs ONE launch and ONE round trip (vc_stream_run); the blocking entry points flush the pending
-// operations with a second launch.
-int track_prepare_a(vc_engine* e, StepCtx& c) {
-    const int njobs = (int)c.ids.size();
-    int n_tracks = 0;
-    c.n_dets = 0;
-    c.det_base.assign(njobs, 0);
-    for (int j = 0; j < njobs; ++j) {
-        VC_CHECK(c.ids[j] >= 0 && c.ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", c.ids[j]);
-        n_tracks += (int)e->trackers[c.ids[j]]->tracks.size();
-        c.det_base[j] = c.n_dets;
-        c.n_dets += (int)c.prep[j].conf.size();
-    }
-    const int n_dets = c.n_dets;
-    VC_CHECK(n_dets <= e->det_cap, VC_ERR_CAPACITY, "%d detections in one step exceed capacity %d", n_dets, e->det_cap);
-    // descriptors + detections go into the pinned, device-mapped staging block: the kernel reads them over the host link
-    // (a few hundred bytes) and writes the cost rows straight into pinned memory -- no copy operations in the phase
-    Stage st{e->h_stage, e->hd_stage, e->stage_cap};
-    int* d_featrow; double *d_xyah, *d_tlwh; TrackJobA* d_jobs;
-    int* h_featrow = st.take<int>(n_dets, &d_featrow);
-    double* h_xyah = st.take<double>((size_t)n_dets * 4, &d_xyah);
-    double* h_tlwh = st.take<double>((size_t)n_dets * 4, &d_tlwh);
-    TrackJobA* h_jobs = st.take<TrackJobA>(n_tracks, &d_jobs);
-    VC_CHECK(st.off <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
-    for (int j = 0; j < njobs; ++j) {
-        const Prepared& p = c.prep[j];
-        for (size_t i = 0; i < p.conf.size(); ++i) {
-            const int g = c.det_base[j] + (int)i;
-            memcpy(h_tlwh + (size_t)g * 4, &p.tlwh[i * 4], 4 * sizeof(double));
-            tlwh_to_xyah(&p.tlwh[i * 4], h_xyah + (size_t)g * 4);
-            h_featrow[g] = p.feat_rows[i];
-        }
-    }
-    // one job per live track: Kalman predict + (confirmed) appearance row + (IoU candidate) IoU row over its tracker's dets
-    c.out = 0;
-    c.app_job.assign(njobs, {});
-    c.iou_job.assign(njobs, {});
-    int q = 0;
-    for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[c.ids[j]];
-        const int k = (int)c.prep[j].conf.size();
-        c.app_job[j].assign(tk.tracks.size(), -1);
-        c.iou_job[j].assign(tk.tracks.size(), -1);
-        for (size_t t = 0; t < tk.tracks.size(); ++t) {
-            TrackRec& tr = tk.tracks[t];
-            tr.age += 1; tr.tsu += 1;                                      // sort/track.py:112-124
-            TrackJobA jb{tr.slot, tr.gal_count, c.det_base[j], k, -1, -1, tr.tsu, 0};
-            if (k > 0 && tr.state == CONFIRMED) { jb.app_off = (int)c.out; c.app_job[j][t] = jb.app_off; c.out += k; }
-            if (k > 0 && !(tr.state == CONFIRMED && tr.tsu != 1)) {         // IoU candidates only (sort/tracker.py:118-120)
-                jb.iou_off = (int)c.out; c.iou_job[j][t] = jb.iou_off; c.out += k;
-            }
-            h_jobs[q++] = jb;
-        }
-    }
-    VC_CHECK(c.out <= e->cost_cap, VC_ERR_CAPACITY, "cost matrices (%zu entries) exceed capacity %zu", c.out, e->cost_cap);
-    c.det_xyah.assign(h_xyah, h_xyah + (size_t)n_dets * 4);
-    c.featrow.assign(h_featrow, h_featrow + n_dets);
-    c.n_jobs = n_tracks;
-    c.h_jobs = h_jobs; c.d_jobs = d_jobs; c.d_featrow = d_featrow; c.d_xyah = d_xyah; c.d_tlwh = d_tlwh;
-    return VC_OK;
-}
-
-// Chain records of one step: the pending operations of `cb` (may be null) merged with the cost jobs of `ca` (may be
-// null), one record per touched slot, written to the second pinned staging block.
-static int build_chain_recs(vc_engine* e, const StepCtx* cb, const StepCtx* ca, const TrackChainRec** d_recs, int* n_out) {
-    const int nops = cb ? (int)cb->ops.size() : 0, njobs = ca ? ca->n_jobs : 0;
-    std::vector<TrackChainRec>& tmp = e->chain_scratch;
-    tmp.clear();
-    TrackChainRec blank{};
-    blank.op.kind = -1; blank.op.slot = -1; blank.op.feat_row = -1; blank.op.out_row = -1;
-    blank.job.slot = -1; blank.job.app_off = -1; blank.job.iou_off = -1;
-    for (int i = 0; i < nops; ++i) {
-        e->slot_chain[cb->ops[i].slot] = (int)tmp.size();
-        tmp.push_back(blank);
-        tmp.back().op = cb->ops[i];
-    }
-    for (int q = 0; q < njobs; ++q) {
-        const int slot = ca->h_jobs[q].slot, at = e->slot_chain[slot];
-        if (at >= 0) tmp[at].job = ca->h_jobs[q];
-        else { tmp.push_back(blank); tmp.back().job = ca->h_jobs[q]; }
-    }
-    for (int i = 0; i < nops; ++i) e->slot_chain[cb->ops[i].slot] = -1;
-    const int n = (int)tmp.size();
-    VC_CHECK((size_t)n * sizeof(TrackChainRec) <= e->stage_cap, VC_ERR_CAPACITY, "tracker staging block too small");
-    TrackChainRec* h = (TrackChainRec*)e->h_stage2;
-    if (n) memcpy(h, tmp.data(), (size_t)n * sizeof(TrackChainRec));
-    *d_recs = (const TrackChainRec*)e->hd_stage2;
-    *n_out = n;
-    return VC_OK;
-}
-
-// Launch the pending operations of `cb` (may be null) and the cost jobs of `ca` (may be null) as one kernel, one
-// workgroup per touched slot.
-int track_launch(vc_engine* e, const StepCtx* cb, const float* feat_b, const StepCtx* ca, const float* feat_a) {
-    const TrackChainRec* d_recs; int nch;
-    VC_TRY(build_chain_recs(e, cb, ca, &d_recs, &nch));
-    if (nch == 0) { e->track_inflight = false; return VC_OK; }
-    e->track_seq += 1;
-    ProfScope ps(e, VC_PROF_TRACK);
-    VC_TRY(launch_track_step(e->pool, d_recs, nch, feat_b, feat_a, e->hd_mean, ca ? ca->d_featrow : nullptr, ca ? ca->d_xyah : nullptr,
-                             ca ? ca->d_tlwh : nullptr, e->hd_cost, e->d_track_counter, e->hd_track_flag, e->track_seq, e->stream));
-    e->track_inflight = true;
-    return VC_OK;
-}
-
-// Wait for the last track_launch: poll the completion word the kernel publishes to pinned memory (a stream
-// synchronisation costs several times the kernel itself); fall back to the stream if it does not arrive.
-int track_wait(vc_engine* e) {
-    if (!e->track_inflight) return VC_OK;
-    e->track_inflight = false;
-    if (!e->profiling) {
-        volatile unsigned* flag = (volatile unsigned*)e->h_track_flag;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int spin = 0;; ++spin) {
-            if (*flag == e->track_seq) { std::atomic_thread_fence(std::memory_order_acquire); return VC_OK; }
-            __builtin_ia32_pause();
-            if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-        }
-    }
-    VC_HIP(hipStreamSynchronize(e->stream));
-    VC_CHECK(*(volatile unsigned*)e->h_track_flag == e->track_seq, VC_ERR_HIP, "tracker kernel did not publish its completion word");
-    return VC_OK;
-}
-
-int track_host_b(vc_engine* e, StepCtx& c) {
-    const int njobs = (int)c.ids.size();
-    std::vector<TrackOpB>& ops = c.ops;              // one per updated / initiated / output-only track
-    ops.clear();
-    auto add_op = [&](int slot, int kind, const double* z, int gal_pos, int feat_row) {
-        TrackOpB op{};
-        op.slot = slot; op.kind = kind; op.gal_pos = gal_pos; op.feat_row = feat_row; op.out_row = -1;
-        if (z) memcpy(op.z, z, 4 * sizeof(double));
-        ops.push_back(op);
-    };
-    for (int j = 0; j < njobs; ++j) {
-        Tracker& tk = *e->trackers[c.ids[j]];
-        const Prepared& pr = c.prep[j];
-        const int k = (int)pr.conf.size();
-        const int nt = (int)tk.tracks.size();
-        // scratch reused across trackers and frames (no heap traffic in the per-frame step)
-        static thread_local std::vector<int> confirmed, unconfirmed, left, lvl, un_a, cand, un_tracks;
-        static thread_local std::vector<std::pair<int, int>> matches;
-        static thread_local std::vector<char> matched_track;
-        static thread_local std::vector<const double*> rp;
-        static thread_local MatchOut mo;
-        confirmed.clear(); unconfirmed.clear(); matches.clear();
-        for (int t = 0; t < nt; ++t) (tk.tracks[t].state == CONFIRMED ? confirmed : unconfirmed).push_back(t);
-        left.resize(k);
-        std::iota(left.begin(), left.end(), 0);
-        // matching_cascade, sort/linear_assignment.py:124-145
-        matched_track.assign(nt, 0);
-        int max_tsu = 0;
-        for (int t : confirmed) max_tsu = std::max(max_tsu, tk.tracks[t].tsu);
-        for (int level = 0; level < tk.p.max_age && level < max_tsu; ++level) {      // levels above the oldest track are empty
-            if (left.empty()) break;
-            lvl.clear();
-            for (int t : confirmed) if (tk.tracks[t].tsu == 1 + level) lvl.push_back(t);
-            if (lvl.empty()) continue;
-            rp.clear();
-            for (int t : lvl) rp.push_back(e->h_cost + c.app_job[j][t]);
-            VC_TRY(min_cost_matching(rp, lvl, left, tk.p.max_dist, mo));
-            for (auto& m : mo.matches) { matches.push_back(m); matched_track[m.first] = 1; }
-            left = mo.un_cols;
-        }
-        un_a.clear();                                            // set(confirmed) - matched, ascending ("set order")
-        for (int t : confirmed) if (!matched_track[t]) un_a.push_back(t);
-        // IoU stage, sort/tracker.py:118-127
-        cand = unconfirmed; un_tracks.clear();
-        for (int t : un_a) (tk.tracks[t].tsu == 1 ? cand : un_tracks).push_back(t);
-        {
-            rp.clear();
-            if (k > 0) for (int t : cand) rp.push_back(e->h_cost + c.iou_job[j][t]);
-            else rp.assign(cand.size(), nullptr);
-            VC_TRY(min_cost_matching(rp, cand, left, tk.p.max_iou_distance, mo));
-        }
-        for (auto& m : mo.matches) matches.push_back(m);
-        for (int t : mo.un_rows) un_tracks.push_back(t);
-        const std::vector<int>& un_dets = mo.un_cols;
-
-        // Track.update, sort/track.py:126-145
-        for (auto& m : matches) {
-            TrackRec& tr = tk.tracks[m.first];
-            const int g = c.det_base[j] + m.second;
-            add_op(tr.slot, 1, &c.det_xyah[(size_t)g * 4], tr.gal_head, c.featrow[g]);
-            tr.gal_head = (tr.gal_head + 1) % tk.p.nn_budget;
-            tr.gal_count = std::min(tr.gal_count + 1, tk.p.nn_budget);
-            tr.last_conf = pr.conf[m.second];
-            tr.hits += 1; tr.tsu = 0;
-            if (tr.state == TENTATIVE && tr.hits >= tk.p.n_init) tr.state = CONFIRMED;
-        }
-        // Track.mark_missed, sort/track.py:147-153
-        for (int t : un_tracks) {
-            TrackRec& tr = tk.tracks[t];
-            if (tr.state == TENTATIVE) tr.state = DELETED;
-            else if (tr.tsu > tk.p.max_age) tr.state = DELETED;
-        }
-        // _initiate_track, sort/tracker.py:133-139
-        for (int d : un_dets) {
-            const int new_slot = slot_alloc(e);
-            VC_CHECK(new_slot >= 0, VC_ERR_CAPACITY, "track pool exhausted (max_tracks = %d)", e->cfg.max_tracks);
-            TrackRec tr{};
-            tr.id = tk.next_id++; tr.state = TENTATIVE; tr.hits = 1; tr.age = 1; tr.tsu = 0;
-            tr.slot = new_slot;
-            const int g = c.det_base[j] + d;
-            add_op(tr.slot, 2, &c.det_xyah[(size_t)g * 4], 0, c.featrow[g]);
-            tr.gal_head = 1 % tk.p.nn_budget; tr.gal_count = 1;
-            tr.last_conf = pr.conf[d];
-            tk.tracks.push_back(tr);
-        }
-        // drop deleted tracks, sort/tracker.py:80
-        std::vector<TrackRec> alive;
-        for (TrackRec& tr : tk.tracks) {
-            if (tr.state == DELETED) slot_free(e, tr.slot);
-            else alive.push_back(tr);
-        }
-        tk.tracks.swap(alive);
-    }
-    // deep_sort.py:46-58 output eligibility (confirmed, time_since_update <= 1): those tracks' posterior means go back
-    c.emit.clear();
-    c.mean_offsets.assign(njobs + 1, 0);
-    std::vector<int>& op_of_slot = e->slot_chain;    // scratch, -1 outside a call
-    const size_t n_real_ops = ops.size();
-    for (size_t i = 0; i < n_real_ops; ++i) op_of_slot[ops[i].slot] = (int)i;
-    int n_out = 0;
-    for (int j = 0; j < njobs; ++j) {
-        c.mean_offsets[j] = n_out;
-        for (const TrackRec& tr : e->trackers[c.ids[j]]->tracks) {
-            if (!c.all_means && (tr.state != CONFIRMED || tr.tsu > 1)) continue;
-            if (tr.state == CONFIRMED && tr.tsu <= 1) c.emit.push_back(StepCtx::Emit{n_out, tr.id, j < (int)c.labels.size() ? c.labels[j] : 0});
-            const int at = op_of_slot[tr.slot];
-            if (at < 0) { add_op(tr.slot, 0, nullptr, 0, -1); ops.back().out_row = n_out; }
-            else ops[at].out_row = n_out;
-            ++n_out;
-        }
-    }
-    for (size_t i = 0; i < n_real_ops; ++i) op_of_slot[ops[i].slot] = -1;
-    c.mean_offsets[njobs] = n_out;
-    return VC_OK;      // c.ops are pending: e->h_mean / c.emit are valid after the launch that carries them has completed
-}
-
-// Blocking form used by the per-frame entry points: cost jobs, host matching, then the operations in a second launch.
-int track_step_blocking(vc_engine* e, StepCtx& c, const float* d_feat) {
-    VC_TRY(track_prepare_a(e, c));
-    VC_TRY(track_launch(e, nullptr, nullptr, &c, d_feat));
-    VC_TRY(track_wait(e));
-    VC_TRY(track_host_b(e, c));
-    VC_TRY(track_launch(e, &c, d_feat, nullptr, nullptr));
-    VC_TRY(track_wait(e));
-    return VC_OK;
-}
-
-// deep_sort.py:46-58: confirmed tracks seen within one frame -> int rows [x1,y1,x2,y2,id,label] (box = Kalman posterior, Q7)
-void emit_rows(const StepCtx& c, const double* means, std::vector<int64_t>& rows6) {
-    for (const StepCtx::Emit& em : c.emit) {
-        const double* m = means + (size_t)em.row * 8;
-        const double w = m[2] * m[3], h = m[3];                         // sort/track.py:82-96 to_tlwh
-        const double x = m[0] - w / 2, y = m[1] - h / 2;
-        rows6.push_back(std::max((int64_t)x, (int64_t)0));              // deep_sort.py:97-108 int() + clamp
-        rows6.push_back(std::max((int64_t)y, (int64_t)0));
-        rows6.push_back(std::min((int64_t)(x + w), (int64_t)c.W - 1));
-        rows6.push_back(std::min((int64_t)(y + h), (int64_t)c.H - 1));
-        rows6.push_back(em.id);
-        rows6.push_back(em.label);
-    }
-}
-
 // DeepSort.update minus the embedding: confidence filter, tlwh, DeepSORT NMS -> detections in pick order
 void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k, const vc_tracker_params& p, Prepared& out) {
     std::vector<double> tl, cf;
@@ -507,6 +71,219 @@ void prepare_dets(const double* xyxy, const double* conf, const int* rows, int k
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pool
+static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+int tracker_init_pool(vc_engine* e) {
+    const size_t T = e->cfg.max_tracks, S = e->cfg.nn_budget_cap;
+    VC_CHECK(T >= 1 && S >= 1, VC_ERR_ARG, "max_tracks and nn_budget_cap must be positive");
+    e->max_trackers = e->cfg.max_trackers > 0 ? e->cfg.max_trackers : 256;
+    e->list_cap = e->cfg.tracks_per_tracker > 0 ? e->cfg.tracks_per_tracker : 512;
+    e->list_cap = (int)std::min<size_t>((size_t)e->list_cap, T);
+    e->pool.max_tracks = (int)T; e->pool.budget_cap = (int)S;
+    VC_TRY(dev_alloc(e, (void**)&e->pool.mean, T * 8 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->pool.cov, T * 64 * sizeof(double)));
+    VC_TRY(dev_alloc(e, (void**)&e->pool.gallery, T * S * VC_FEAT_DIM * sizeof(float)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_hdrs, (size_t)e->max_trackers * sizeof(TrackerHdr)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_lists, (size_t)e->max_trackers * e->list_cap * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_recs, T * sizeof(TrackRecD)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_free, 64));
+    VC_TRY(dev_alloc(e, (void**)&e->d_free_stack, T * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_freed, T * sizeof(int)));
+    VC_HIP(hipMemset(e->d_hdrs, 0, (size_t)e->max_trackers * sizeof(TrackerHdr)));
+    std::vector<int> st(T);
+    for (size_t i = 0; i < T; ++i) st[i] = (int)(T - 1 - i);
+    VC_HIP(hipMemcpy(e->d_free_stack, st.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    const int ctl[2] = {(int)T, 0};
+    VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(ctl), hipMemcpyHostToDevice));
+    e->det_cap = std::max(e->cfg.max_det * 2, 1024);
+    VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, (size_t)e->det_cap * VC_FEAT_DIM * sizeof(float)));
+    for (TrackStage& s : e->tstage) {
+        VC_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        VC_TRY(dev_alloc(e, (void**)&s.d_cursor, 64));
+    }
+    return VC_OK;
+}
+
+// (re)size a staging block; old blocks stay on the engine's free-at-destroy lists (sizes grow geometrically)
+static int stage_reserve(vc_engine* e, TrackStage& s, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > s.in_cap) {
+        const size_t cap = std::max(in_bytes * 3 / 2, (size_t)1 << 16);
+        VC_TRY(host_alloc(e, (void**)&s.h_in, cap));
+        VC_TRY(dev_alloc(e, (void**)&s.d_in, cap));
+        s.in_cap = cap;
+    }
+    if (out_bytes > s.out_cap) {
+        const size_t cap = std::max(out_bytes * 3 / 2, (size_t)1 << 16);
+        VC_TRY(host_alloc(e, (void**)&s.h_out, cap));
+        VC_HIP(hipHostGetDevicePointer((void**)&s.hd_out, s.h_out, 0));
+        s.out_cap = cap;
+    }
+    return VC_OK;
+}
+
+int track_idle(vc_engine* e) {
+    for (TrackStage& s : e->tstage)
+        if (s.busy) VC_HIP(hipEventSynchronize(s.done));
+    return VC_OK;
+}
+
+// output block layout (pinned, written by the kernel)
+struct OutLayout { size_t rows, row_off, row_n, ntracks, tT, status, total; };
+static OutLayout out_layout(int n_tasks, int rows_cap) {
+    OutLayout o;
+    size_t p = 0;
+    o.rows = p; p = align16(p + (size_t)rows_cap * 6 * sizeof(long long));
+    o.row_off = p; p = align16(p + (size_t)n_tasks * 4);
+    o.row_n = p; p = align16(p + (size_t)n_tasks * 4);
+    o.ntracks = p; p = align16(p + (size_t)n_tasks * 4);
+    o.tT = p; p = align16(p + (size_t)n_tasks * 4);
+    o.status = p; p = align16(p + 16);
+    o.total = p;
+    return o;
+}
+
+int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClassDets>>& frames, const float* d_feat, int W, int H,
+                  int rows_cap, hipEvent_t wait) {
+    TrackStage& s = e->tstage[st];
+    VC_CHECK(!s.busy, VC_ERR_STATE, "tracker staging slot %d is still in flight", st);
+    // tasks in (frame, class) order -- the order rows are handed back in -- and the detection arrays
+    s.tasks.clear(); s.tracker_dets.clear(); s.last_task_of.clear();
+    int n_dets = 0;
+    for (size_t f = 0; f < frames.size(); ++f)
+        for (const FrameClassDets& g : frames[f]) {
+            VC_CHECK(g.tracker >= 0 && g.tracker < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", g.tracker);
+            s.tasks.push_back(TrackTaskHost{g.tracker, g.label, (int)f, n_dets, (int)g.dets.conf.size()});
+            n_dets += (int)g.dets.conf.size();
+        }
+    const int n_tasks = (int)s.tasks.size();
+    s.n_tasks = n_tasks; s.n_dets = n_dets; s.rows_cap = rows_cap; s.b = (int)frames.size(); s.W = W; s.H = H; s.n_wg = 0;
+    if (n_tasks == 0) { s.busy = true; VC_HIP(hipEventRecord(s.done, e->stream)); return VC_OK; }
+    // device order: grouped by tracker, frames ascending inside a group (stable sort of the frame-major list)
+    std::vector<int> order(n_tasks);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s.tasks[a].tracker < s.tasks[b].tracker; });
+    s.dev_index.assign(n_tasks, 0);
+    for (int k = 0; k < n_tasks; ++k) s.dev_index[order[k]] = k;
+    std::vector<TrackWgPlan> plans;
+    int need = 8;
+    for (int k = 0; k < n_tasks;) {
+        const int tr = s.tasks[order[k]].tracker;
+        int k1 = k, dets = 0;
+        while (k1 < n_tasks && s.tasks[order[k1]].tracker == tr) { dets += s.tasks[order[k1]].det_n; ++k1; }
+        plans.push_back(TrackWgPlan{tr, k, k1, 0});
+        Tracker& tk = *e->trackers[tr];
+        need = std::max(need, tk.known_tracks + tk.pending_dets + dets);      // live tracks + detections can never exceed this in the batch
+        s.tracker_dets.emplace_back(tr, dets);
+        s.last_task_of.push_back(k1 - 1);
+        k = k1;
+    }
+    int cap = 32;
+    while (cap < need) cap *= 2;
+    VC_CHECK(cap <= 512, VC_ERR_CAPACITY, "a tracker may reach %d live tracks + detections in one step; the device tracker holds 512", need);
+    const int n_wg = (int)plans.size();
+    s.n_wg = n_wg;
+    s.step_cap = cap;
+    // input block
+    size_t p = 0;
+    const size_t o_tasks = p; p = align16(p + (size_t)n_tasks * sizeof(TrackTask));
+    const size_t o_plans = p; p = align16(p + (size_t)n_wg * sizeof(TrackWgPlan));
+    const size_t o_tlwh = p; p = align16(p + (size_t)n_dets * 32);
+    const size_t o_xyah = p; p = align16(p + (size_t)n_dets * 32);
+    const size_t o_frow = p; p = align16(p + (size_t)n_dets * 4);
+    const OutLayout ol = out_layout(n_tasks, rows_cap);
+    VC_TRY(stage_reserve(e, s, p, ol.total));
+    TrackTask* ht = (TrackTask*)(s.h_in + o_tasks);
+    for (int k = 0; k < n_tasks; ++k) {
+        const TrackTaskHost& t = s.tasks[order[k]];
+        ht[k] = TrackTask{t.tracker, t.det_off, t.det_n, t.frame, t.label, 0, 0, 0};
+    }
+    memcpy(s.h_in + o_plans, plans.data(), (size_t)n_wg * sizeof(TrackWgPlan));
+    {
+        double* tl = (double*)(s.h_in + o_tlwh);
+        double* xy = (double*)(s.h_in + o_xyah);
+        int* fr = (int*)(s.h_in + o_frow);
+        int g = 0;
+        for (const auto& fv : frames)
+            for (const FrameClassDets& c : fv)
+                for (size_t i = 0; i < c.dets.conf.size(); ++i, ++g) {
+                    const double* t = &c.dets.tlwh[i * 4];
+                    memcpy(tl + (size_t)g * 4, t, 32);
+                    double* o = xy + (size_t)g * 4;                           // sort/detection.py:42-50 to_xyah
+                    o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
+                    fr[g] = c.dets.feat_rows[i];
+                }
+    }
+    // scratch: 4 matrices of cap x cap doubles per workgroup
+    const size_t scratch = (size_t)n_wg * 4 * cap * cap * sizeof(double);
+    if (scratch > e->track_scratch_bytes) {
+        VC_TRY(track_idle(e));                                                // the old block may still be in use
+        const size_t bytes = scratch * 3 / 2;
+        VC_TRY(dev_alloc(e, (void**)&e->d_track_scratch, bytes));
+        e->track_scratch_bytes = bytes;
+    }
+    for (auto& td : s.tracker_dets) e->trackers[td.first]->pending_dets += td.second;
+    hipStream_t ts = e->stream;
+    if (wait) VC_HIP(hipStreamWaitEvent(ts, wait, 0));
+    VC_HIP(hipMemcpyAsync(s.d_in, s.h_in, p, hipMemcpyHostToDevice, ts));
+    VC_HIP(hipMemsetAsync(s.d_cursor, 0, 64, ts));           // [0] row cursor, [4..6] status
+    TrackBatchArgs a{};
+    a.pool = e->pool;
+    a.hdrs = e->d_hdrs; a.lists = e->d_lists; a.list_cap = e->list_cap; a.recs = e->d_recs;
+    a.free_top = e->d_free; a.freed_count = e->d_free + 1; a.free_stack = e->d_free_stack; a.freed = e->d_freed;
+    a.plans = (const TrackWgPlan*)(s.d_in + o_plans); a.tasks = (const TrackTask*)(s.d_in + o_tasks);
+    a.det_tlwh = (const double*)(s.d_in + o_tlwh); a.det_xyah = (const double*)(s.d_in + o_xyah); a.det_featrow = (const int*)(s.d_in + o_frow);
+    a.feat = d_feat;
+    a.rows = (long long*)(s.hd_out + ol.rows); a.rows_cap = rows_cap; a.row_cursor = s.d_cursor;
+    a.task_row_off = (int*)(s.hd_out + ol.row_off); a.task_row_n = (int*)(s.hd_out + ol.row_n);
+    a.task_ntracks = (int*)(s.hd_out + ol.ntracks); a.task_T = (int*)(s.hd_out + ol.tT);
+    a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
+    a.scratch = e->d_track_scratch; a.cap = cap; a.frame_w = W; a.frame_h = H;
+    {
+        ProfScope ps(e, VC_PROF_TRACK);
+        VC_TRY(launch_track_batch(a, n_wg, ts));
+    }
+    VC_HIP(hipMemcpyAsync(s.h_out + ol.status, s.d_cursor + 4, 16, hipMemcpyDeviceToHost, ts));
+    VC_HIP(hipEventRecord(s.done, ts));
+    s.busy = true;
+    return VC_OK;
+}
+
+int track_collect(vc_engine* e, int st, int64_t* out_rows6, int cap_rows_per_frame, int* out_m) {
+    TrackStage& s = e->tstage[st];
+    VC_CHECK(s.busy, VC_ERR_STATE, "no tracker batch in staging slot %d", st);
+    VC_HIP(hipEventSynchronize(s.done));
+    s.busy = false;
+    for (int f = 0; f < s.b; ++f) out_m[f] = 0;
+    if (s.n_tasks == 0) return VC_OK;
+    const OutLayout ol = out_layout(s.n_tasks, s.rows_cap);
+    const int* row_off = (const int*)(s.h_out + ol.row_off);
+    const int* row_n = (const int*)(s.h_out + ol.row_n);
+    const int* ntr = (const int*)(s.h_out + ol.ntracks);
+    const int* status = (const int*)(s.h_out + ol.status);
+    const long long* rows = (const long long*)(s.h_out + ol.rows);
+    for (size_t i = 0; i < s.tracker_dets.size(); ++i) {                        // size bounds for the next batches
+        Tracker& tk = *e->trackers[s.tracker_dets[i].first];
+        tk.pending_dets -= s.tracker_dets[i].second;
+        tk.known_tracks = ntr[s.last_task_of[i]];
+    }
+    if (status[0] != TERR_NONE) {
+        const char* what = status[0] == TERR_TRACK_CAP ? "live tracks + detections exceed the per-tracker capacity (vc_engine_config.tracks_per_tracker)"
+                         : status[0] == TERR_POOL     ? "track pool exhausted (vc_engine_config.max_tracks)"
+                         : status[0] == TERR_ROWS     ? "more output rows than the caller's buffers hold (cap_rows)"
+                                                      : "infeasible assignment problem";
+        set_error("tracker %d: %s; the tracker is stopped until vc_tracker_reset", status[1], what);
+        return VC_ERR_CAPACITY;
+    }
+    for (int i = 0; i < s.n_tasks; ++i) {                                       // (frame, class) order
+        const int k = s.dev_index[i], f = s.tasks[i].frame, m = row_n[k];
+        VC_CHECK(out_m[f] + m <= cap_rows_per_frame, VC_ERR_CAPACITY, "frame %d needs room for %d rows", f, out_m[f] + m);
+        memcpy(out_rows6 + ((size_t)f * cap_rows_per_frame + out_m[f]) * 6, rows + (size_t)row_off[k] * 6, (size_t)m * 6 * sizeof(int64_t));
+        out_m[f] += m;
+    }
+    return VC_OK;
+}
+
 static void xyxy_to_cxcywh(const double* b, double* o) {
     const double w = b[2] - b[0], h = b[3] - b[1];
     o[0] = b[0] + w / 2; o[1] = b[1] + h / 2; o[2] = w; o[3] = h;
@@ -515,25 +292,6 @@ static void xyxy_to_cxcywh(const double* b, double* o) {
 static void crop_corners_i(const double* b, int W, int H, int* c) {  // deep_sort.py:89-95
     c[0] = std::max((int)(b[0] - b[2] / 2), 0); c[2] = std::min((int)(b[0] + b[2] / 2), W - 1);
     c[1] = std::max((int)(b[1] - b[3] / 2), 0); c[3] = std::min((int)(b[1] + b[3] / 2), H - 1);
-}
-
-// Build the step context of one frame: per tracker the prepared (filtered, NMS'ed) detections.
-void build_ctx(vc_engine* e, StepCtx& c, int H, int W, const std::vector<int>& tracker_ids, const std::vector<int>& labels,
-               const std::vector<std::vector<int>>& groups, const double* xyxy, const double* conf, int feat_row0) {
-    const int nj = (int)tracker_ids.size();
-    c.ids = tracker_ids; c.labels = labels; c.H = H; c.W = W; c.all_means = false;
-    c.prep.assign(nj, Prepared{});
-    for (int j = 0; j < nj; ++j) {
-        const auto& g = groups[j];
-        std::vector<double> bx(g.size() * 4), cf(g.size());
-        std::vector<int> rows(g.size());
-        for (size_t i = 0; i < g.size(); ++i) {
-            memcpy(&bx[i * 4], xyxy + (size_t)g[i] * 4, 4 * sizeof(double));
-            cf[i] = conf[g[i]];
-            rows[i] = feat_row0 + g[i];
-        }
-        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, c.prep[j]);
-    }
 }
 
 // Shared by vc_deepsort_update / vc_videotracker_run: one frame already on the device, blocking.
@@ -552,11 +310,72 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
     }
     VC_HIP(hipMemcpyAsync(e->d_crops, e->h_crops, (size_t)n * 5 * sizeof(int), hipMemcpyHostToDevice, e->stream));
     VC_TRY(run_reid_dev(e, d_frame_base, H, W, n));
-    StepCtx c;
-    build_ctx(e, c, H, W, tracker_ids, labels, groups, xyxy, conf, 0);
-    VC_TRY(track_step_blocking(e, c, e->d_feat));
-    emit_rows(c, e->h_mean, rows6);
+    std::vector<std::vector<FrameClassDets>> frames(1);
+    int total_tracks = 0;
+    for (size_t j = 0; j < tracker_ids.size(); ++j) {
+        const auto& g = groups[j];
+        std::vector<double> bx(g.size() * 4), cf(g.size());
+        std::vector<int> rows(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            memcpy(&bx[i * 4], xyxy + (size_t)g[i] * 4, 4 * sizeof(double));
+            cf[i] = conf[g[i]];
+            rows[i] = g[i];
+        }
+        VC_CHECK(tracker_ids[j] >= 0 && tracker_ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
+        FrameClassDets fc{labels[j], tracker_ids[j], {}};
+        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, fc.dets);
+        total_tracks += e->trackers[tracker_ids[j]]->known_tracks + (int)fc.dets.conf.size();
+        frames[0].push_back(std::move(fc));
+    }
+    const int cap = std::max(total_tracks, 16);
+    VC_TRY(track_enqueue(e, 3, frames, e->d_feat, W, H, cap, nullptr));
+    std::vector<int64_t> buf((size_t)cap * 6);
+    int m = 0;
+    VC_TRY(track_collect(e, 3, buf.data(), cap, &m));
+    rows6.assign(buf.begin(), buf.begin() + (size_t)m * 6);
     return VC_OK;
+}
+
+// ---- tracker state on the host (blocking paths: the engine is idle) ---------------------------------------------------------------
+struct HostTrackerState { TrackerHdr hdr; std::vector<int> list; std::vector<TrackRecD> recs; };
+
+static int download_tracker(vc_engine* e, int id, HostTrackerState& st) {
+    VC_TRY(track_idle(e));
+    VC_HIP(hipStreamSynchronize(e->stream));
+    VC_HIP(hipMemcpy(&st.hdr, e->d_hdrs + id, sizeof(TrackerHdr), hipMemcpyDeviceToHost));
+    const int n = st.hdr.n_tracks;
+    st.list.resize(n); st.recs.resize(n);
+    if (n) VC_HIP(hipMemcpy(st.list.data(), e->d_lists + (size_t)id * e->list_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int t = 0; t < n; ++t) VC_HIP(hipMemcpy(&st.recs[t], e->d_recs + st.list[t], sizeof(TrackRecD), hipMemcpyDeviceToHost));
+    return VC_OK;
+}
+
+// free-slot stack, host side (engine idle): take n slots / give slots back
+static int host_take_slots(vc_engine* e, int n, std::vector<int>& out) {
+    int ctl[2];
+    VC_HIP(hipMemcpy(ctl, e->d_free, sizeof(ctl), hipMemcpyDeviceToHost));
+    VC_CHECK(ctl[0] >= n, VC_ERR_CAPACITY, "track pool too small for %d more tracks (max_tracks = %d)", n, e->cfg.max_tracks);
+    out.resize(n);
+    if (n) VC_HIP(hipMemcpy(out.data(), e->d_free_stack + (ctl[0] - n), (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    ctl[0] -= n;
+    VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(int), hipMemcpyHostToDevice));
+    return VC_OK;
+}
+static int host_give_slots(vc_engine* e, const std::vector<int>& slots) {
+    if (slots.empty()) return VC_OK;
+    int ctl[2];
+    VC_HIP(hipMemcpy(ctl, e->d_free, sizeof(ctl), hipMemcpyDeviceToHost));
+    VC_HIP(hipMemcpy(e->d_free_stack + ctl[0], slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctl[0] += (int)slots.size();
+    VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(int), hipMemcpyHostToDevice));
+    return VC_OK;
+}
+
+static TrackerHdr make_hdr(const vc_tracker_params& p) {
+    TrackerHdr h{};
+    h.max_dist = p.max_dist; h.max_iou_distance = p.max_iou_distance; h.next_id = 1;
+    h.max_age = p.max_age; h.n_init = p.n_init; h.nn_budget = p.nn_budget; h.n_tracks = 0; h.err = TERR_NONE;
+    return h;
 }
 
 }  // namespace vc
@@ -571,65 +390,105 @@ int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
     VC_CHECK(p->nn_budget >= 1 && p->nn_budget <= e->cfg.nn_budget_cap, VC_ERR_CAPACITY,
              "nn_budget %d outside [1, nn_budget_cap=%d] (an unbounded budget is not supported)", p->nn_budget, e->cfg.nn_budget_cap);
     VC_CHECK(p->max_age >= 1 && p->n_init >= 1, VC_ERR_ARG, "max_age and n_init must be >= 1");
+    VC_CHECK((int)e->trackers.size() < e->max_trackers, VC_ERR_CAPACITY, "more than max_trackers (%d) trackers", e->max_trackers);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));           // batches in flight index e->trackers
     std::unique_ptr<Tracker> t(new Tracker());
     t->p = *p;
+    const TrackerHdr h = make_hdr(*p);
+    VC_HIP(hipMemcpy(e->d_hdrs + e->trackers.size(), &h, sizeof(h), hipMemcpyHostToDevice));
     e->trackers.push_back(std::move(t));
     *id = (int)e->trackers.size() - 1;
     return VC_OK;
 }
 
 int vc_tracker_reset(vc_engine* e, int id) {
-    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
-    Tracker& tk = *e->trackers[id];
-    for (const TrackRec& t : tk.tracks) slot_free(e, t.slot);
-    tk.tracks.clear();
-    tk.next_id = 1;
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    HostTrackerState st;
+    VC_TRY(download_tracker(e, id, st));
+    VC_TRY(host_give_slots(e, st.list));
+    const TrackerHdr h = make_hdr(e->trackers[id]->p);
+    VC_HIP(hipMemcpy(e->d_hdrs + id, &h, sizeof(h), hipMemcpyHostToDevice));
+    e->trackers[id]->known_tracks = 0;
+    e->trackers[id]->pending_dets = 0;
     return VC_OK;
 }
 
 int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf, const float* feat, int k) {
-    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     VC_CHECK(k == 0 || (tlwh && conf && feat), VC_ERR_ARG, "null argument");
-    VC_CHECK(k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
+    VC_CHECK(k >= 0 && k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
     VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
     if (k > 0) VC_HIP(hipMemcpyAsync(e->d_feat_in, feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    StepCtx c;
-    c.ids = {id}; c.labels = {0}; c.all_means = false;
-    c.prep.assign(1, Prepared{});
-    c.prep[0].tlwh.assign(tlwh, tlwh + (size_t)k * 4);
-    c.prep[0].conf.assign(conf, conf + k);
-    c.prep[0].feat_rows.resize(k);
-    std::iota(c.prep[0].feat_rows.begin(), c.prep[0].feat_rows.end(), 0);
-    VC_TRY(track_step_blocking(e, c, e->d_feat_in));
-    return VC_OK;
+    std::vector<std::vector<FrameClassDets>> frames(1);
+    FrameClassDets fc{0, id, {}};
+    fc.dets.tlwh.assign(tlwh, tlwh + (size_t)k * 4);
+    fc.dets.conf.assign(conf, conf + k);
+    fc.dets.feat_rows.resize(k);
+    std::iota(fc.dets.feat_rows.begin(), fc.dets.feat_rows.end(), 0);
+    frames[0].push_back(std::move(fc));
+    const int cap = e->trackers[id]->known_tracks + k + 16;
+    VC_TRY(track_enqueue(e, 3, frames, e->d_feat_in, 1 << 30, 1 << 30, cap, nullptr));
+    std::vector<int64_t> buf((size_t)cap * 6);
+    int m = 0;
+    return track_collect(e, 3, buf.data(), cap, &m);
 }
 
 int vc_tracker_count(vc_engine* e, int id, int* n) {
-    if (e) async_wait_all(e);            // tracker state belongs to the worker thread while asynchronous batches run
     VC_CHECK(e && n && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
-    *n = (int)e->trackers[id]->tracks.size();
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    HostTrackerState st;
+    VC_TRY(download_tracker(e, id, st));
+    *n = st.hdr.n_tracks;
     return VC_OK;
 }
 
 int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
                      double* cov64, int* gallery_count) {
-    if (e) async_wait_all(e);
     VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
-    const Tracker& tk = *e->trackers[id];
-    VC_CHECK((int)tk.tracks.size() <= cap, VC_ERR_CAPACITY, "need room for %zu tracks", tk.tracks.size());
-    VC_HIP(hipStreamSynchronize(e->stream));
-    for (size_t t = 0; t < tk.tracks.size(); ++t) {
-        const TrackRec& tr = tk.tracks[t];
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    HostTrackerState st;
+    VC_TRY(download_tracker(e, id, st));
+    VC_CHECK(st.hdr.n_tracks <= cap, VC_ERR_CAPACITY, "need room for %d tracks", st.hdr.n_tracks);
+    for (int t = 0; t < st.hdr.n_tracks; ++t) {
+        const TrackRecD& tr = st.recs[t];
+        const int slot = st.list[t];
         if (ids) ids[t] = tr.id;
         if (state) state[t] = tr.state;
         if (hits) hits[t] = tr.hits;
         if (age) age[t] = tr.age;
         if (tsu) tsu[t] = tr.tsu;
         if (gallery_count) gallery_count[t] = tr.state == CONFIRMED ? tr.gal_count : 0;
-        if (mean8) VC_HIP(hipMemcpy(mean8 + t * 8, e->pool.mean + (size_t)tr.slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost));
-        if (cov64) VC_HIP(hipMemcpy(cov64 + t * 64, e->pool.cov + (size_t)tr.slot * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+        if (mean8) VC_HIP(hipMemcpy(mean8 + (size_t)t * 8, e->pool.mean + (size_t)slot * 8, 8 * sizeof(double), hipMemcpyDeviceToHost));
+        if (cov64) VC_HIP(hipMemcpy(cov64 + (size_t)t * 64, e->pool.cov + (size_t)slot * 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return VC_OK;
+}
+
+// The cost matrices of the LAST blocking step of this engine (vc_tracker_step / vc_deepsort_update on ONE tracker), as the batch
+// kernel left them in its scratch: app[t * D + d] = gated appearance cost of list position t (valid for tracks that were
+// confirmed when the step began), iou[t * D + d] = 1 - IoU (valid for the IoU candidates).  T = tracks before the step.
+int vc_tracker_debug_costs(vc_engine* e, int cap_entries, double* app, double* iou, int* T, int* D) {
+    VC_CHECK(e && app && iou && T && D, VC_ERR_ARG, "null argument");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    const TrackStage& s = e->tstage[3];
+    VC_CHECK(s.n_tasks == 1 && s.n_wg == 1 && !s.busy, VC_ERR_STATE, "the last blocking call did not step exactly one tracker");
+    const OutLayout ol = out_layout(1, s.rows_cap);
+    *T = ((const int*)(s.h_out + ol.tT))[0];
+    *D = s.tasks[0].det_n;
+    const size_t n = (size_t)*T * *D;
+    VC_CHECK(n <= (size_t)cap_entries, VC_ERR_CAPACITY, "need room for %zu entries", n);
+    VC_HIP(hipStreamSynchronize(e->stream));
+    const size_t mat = (size_t)s.step_cap * s.step_cap;              // scratch of workgroup 0: [appearance | IoU | ...], rows of D entries
+    if (n) {
+        VC_HIP(hipMemcpy(app, e->d_track_scratch, n * sizeof(double), hipMemcpyDeviceToHost));
+        VC_HIP(hipMemcpy(iou, e->d_track_scratch + mat, n * sizeof(double), hipMemcpyDeviceToHost));
     }
     return VC_OK;
 }
@@ -645,46 +504,52 @@ const char kSnapMagic[8] = {'V', 'C', 'T', 'R', 'K', '0', '1', 0};
 }  // namespace
 
 int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* size) {
-    if (e) async_wait_all(e);
     VC_CHECK(e && size && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
-    const Tracker& tk = *e->trackers[id];
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    HostTrackerState st;
+    VC_TRY(download_tracker(e, id, st));
+    const vc_tracker_params& tp = e->trackers[id]->p;
     size_t need = sizeof(SnapHeader);
-    for (const TrackRec& tr : tk.tracks) need += sizeof(SnapTrack) + (size_t)std::min(tr.gal_count, tk.p.nn_budget) * VC_FEAT_DIM * sizeof(float);
+    for (const TrackRecD& tr : st.recs) need += sizeof(SnapTrack) + (size_t)std::min(tr.gal_count, tp.nn_budget) * VC_FEAT_DIM * sizeof(float);
     *size = need;
     if (!buf) return VC_OK;                       // size query
     VC_CHECK(cap >= need, VC_ERR_CAPACITY, "snapshot needs %zu bytes", need);
-    VC_HIP(hipSetDevice(e->cfg.device));
-    VC_HIP(hipStreamSynchronize(e->stream));
     char* o = (char*)buf;
     SnapHeader h{};
     memcpy(h.magic, kSnapMagic, 8);
-    h.feat_dim = VC_FEAT_DIM; h.n_tracks = (int32_t)tk.tracks.size(); h.next_id = tk.next_id;
-    h.max_dist = tk.p.max_dist; h.min_confidence = tk.p.min_confidence; h.nms_max_overlap = tk.p.nms_max_overlap;
-    h.max_iou_distance = tk.p.max_iou_distance; h.max_age = tk.p.max_age; h.n_init = tk.p.n_init; h.nn_budget = tk.p.nn_budget;
+    h.feat_dim = VC_FEAT_DIM; h.n_tracks = st.hdr.n_tracks; h.next_id = st.hdr.next_id;
+    h.max_dist = tp.max_dist; h.min_confidence = tp.min_confidence; h.nms_max_overlap = tp.nms_max_overlap;
+    h.max_iou_distance = tp.max_iou_distance; h.max_age = tp.max_age; h.n_init = tp.n_init; h.nn_budget = tp.nn_budget;
     memcpy(o, &h, sizeof(h)); o += sizeof(h);
-    for (const TrackRec& tr : tk.tracks) {
+    for (int i = 0; i < st.hdr.n_tracks; ++i) {
+        const TrackRecD& tr = st.recs[i];
+        const int slot = st.list[i];
         SnapTrack t{};
         t.id = tr.id; t.state = tr.state; t.hits = tr.hits; t.age = tr.age; t.tsu = tr.tsu; t.gal_count = tr.gal_count; t.gal_head = tr.gal_head;
-        t.last_conf = tr.last_conf;
-        VC_HIP(hipMemcpy(t.mean, e->pool.mean + (size_t)tr.slot * 8, sizeof(t.mean), hipMemcpyDeviceToHost));
-        VC_HIP(hipMemcpy(t.cov, e->pool.cov + (size_t)tr.slot * 64, sizeof(t.cov), hipMemcpyDeviceToHost));
+        t.last_conf = 0.0;
+        VC_HIP(hipMemcpy(t.mean, e->pool.mean + (size_t)slot * 8, sizeof(t.mean), hipMemcpyDeviceToHost));
+        VC_HIP(hipMemcpy(t.cov, e->pool.cov + (size_t)slot * 64, sizeof(t.cov), hipMemcpyDeviceToHost));
         memcpy(o, &t, sizeof(t)); o += sizeof(t);
-        const size_t rows = (size_t)std::min(tr.gal_count, tk.p.nn_budget);
-        if (rows) VC_HIP(hipMemcpy(o, e->pool.gallery + (size_t)tr.slot * e->pool.budget_cap * VC_FEAT_DIM, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost));
+        const size_t rows = (size_t)std::min(tr.gal_count, tp.nn_budget);
+        if (rows) VC_HIP(hipMemcpy(o, e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost));
         o += rows * VC_FEAT_DIM * sizeof(float);
     }
     return VC_OK;
 }
 
 int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
-    if (e) async_wait_all(e);
     VC_CHECK(e && buf && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
     VC_CHECK(size >= sizeof(SnapHeader), VC_ERR_ARG, "snapshot truncated");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
     const char* in = (const char*)buf;
     SnapHeader h;
     memcpy(&h, in, sizeof(h)); in += sizeof(h);
     VC_CHECK(memcmp(h.magic, kSnapMagic, 8) == 0 && h.feat_dim == VC_FEAT_DIM && h.n_tracks >= 0, VC_ERR_ARG, "not a tracker snapshot");
     VC_CHECK(h.nn_budget >= 1 && h.nn_budget <= e->cfg.nn_budget_cap, VC_ERR_CAPACITY, "snapshot nn_budget %d exceeds nn_budget_cap %d", h.nn_budget, e->cfg.nn_budget_cap);
+    VC_CHECK(h.max_age >= 1 && h.n_init >= 1 && h.next_id >= 1, VC_ERR_ARG, "snapshot corrupt (parameters)");
+    VC_CHECK(h.n_tracks <= e->list_cap, VC_ERR_CAPACITY, "snapshot holds %d tracks, tracks_per_tracker is %d", h.n_tracks, e->list_cap);
     // validate the whole blob before touching the tracker
     {
         const char* q = in;
@@ -692,43 +557,49 @@ int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
             VC_CHECK((size_t)(q - (const char*)buf) + sizeof(SnapTrack) <= size, VC_ERR_ARG, "snapshot truncated");
             SnapTrack t;
             memcpy(&t, q, sizeof(t)); q += sizeof(t);
-            VC_CHECK(t.gal_count >= 0 && t.gal_head >= 0 && t.gal_head < h.nn_budget, VC_ERR_ARG, "snapshot corrupt (gallery ring)");
-            q += (size_t)std::min(t.gal_count, h.nn_budget) * VC_FEAT_DIM * sizeof(float);
+            VC_CHECK(t.gal_count >= 0 && t.gal_count <= h.nn_budget && t.gal_head >= 0 && t.gal_head < h.nn_budget, VC_ERR_ARG, "snapshot corrupt (gallery ring)");
+            VC_CHECK(t.state == TENTATIVE || t.state == CONFIRMED, VC_ERR_ARG, "snapshot corrupt (track state %d)", t.state);
+            VC_CHECK(t.hits >= 0 && t.age >= 0 && t.tsu >= 0 && t.id >= 1 && t.id < h.next_id, VC_ERR_ARG, "snapshot corrupt (track counters)");
+            q += (size_t)t.gal_count * VC_FEAT_DIM * sizeof(float);
         }
         VC_CHECK((size_t)(q - (const char*)buf) == size, VC_ERR_ARG, "snapshot size mismatch");
     }
+    HostTrackerState old;
+    VC_TRY(download_tracker(e, id, old));
+    VC_TRY(host_give_slots(e, old.list));
+    std::vector<int> slots;
+    VC_TRY(host_take_slots(e, h.n_tracks, slots));
     Tracker& tk = *e->trackers[id];
-    VC_CHECK((int)e->free_slots.size() + (int)tk.tracks.size() >= h.n_tracks, VC_ERR_CAPACITY, "track pool too small for %d tracks", h.n_tracks);
-    VC_HIP(hipSetDevice(e->cfg.device));
-    VC_HIP(hipStreamSynchronize(e->stream));
-    for (const TrackRec& t : tk.tracks) slot_free(e, t.slot);
-    tk.tracks.clear();
     tk.p.max_dist = h.max_dist; tk.p.min_confidence = h.min_confidence; tk.p.nms_max_overlap = h.nms_max_overlap;
     tk.p.max_iou_distance = h.max_iou_distance; tk.p.max_age = h.max_age; tk.p.n_init = h.n_init; tk.p.nn_budget = h.nn_budget;
-    tk.next_id = h.next_id;
+    TrackerHdr dh = make_hdr(tk.p);
+    dh.next_id = h.next_id; dh.n_tracks = h.n_tracks;
     for (int i = 0; i < h.n_tracks; ++i) {
         SnapTrack t;
         memcpy(&t, in, sizeof(t)); in += sizeof(t);
-        TrackRec tr{};
+        TrackRecD tr{};
         tr.id = t.id; tr.state = t.state; tr.hits = t.hits; tr.age = t.age; tr.tsu = t.tsu; tr.gal_count = t.gal_count; tr.gal_head = t.gal_head;
-        tr.last_conf = t.last_conf;
-        tr.slot = slot_alloc(e);
-        VC_HIP(hipMemcpy(e->pool.mean + (size_t)tr.slot * 8, t.mean, sizeof(t.mean), hipMemcpyHostToDevice));
-        VC_HIP(hipMemcpy(e->pool.cov + (size_t)tr.slot * 64, t.cov, sizeof(t.cov), hipMemcpyHostToDevice));
-        const size_t rows = (size_t)std::min(t.gal_count, h.nn_budget);
-        if (rows) VC_HIP(hipMemcpy(e->pool.gallery + (size_t)tr.slot * e->pool.budget_cap * VC_FEAT_DIM, in, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice));
+        const int slot = slots[i];
+        VC_HIP(hipMemcpy(e->d_recs + slot, &tr, sizeof(tr), hipMemcpyHostToDevice));
+        VC_HIP(hipMemcpy(e->pool.mean + (size_t)slot * 8, t.mean, sizeof(t.mean), hipMemcpyHostToDevice));
+        VC_HIP(hipMemcpy(e->pool.cov + (size_t)slot * 64, t.cov, sizeof(t.cov), hipMemcpyHostToDevice));
+        const size_t rows = (size_t)t.gal_count;
+        if (rows) VC_HIP(hipMemcpy(e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, in, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice));
         in += rows * VC_FEAT_DIM * sizeof(float);
-        tk.tracks.push_back(tr);
     }
+    if (h.n_tracks) VC_HIP(hipMemcpy(e->d_lists + (size_t)id * e->list_cap, slots.data(), (size_t)h.n_tracks * sizeof(int), hipMemcpyHostToDevice));
+    VC_HIP(hipMemcpy(e->d_hdrs + id, &dh, sizeof(dh), hipMemcpyHostToDevice));
+    tk.known_tracks = h.n_tracks;
+    tk.pending_dets = 0;
     return VC_OK;
 }
 
 int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy, const double* conf, int k,
                        int64_t* out_rows7, int cap_rows, int* out_m) {
-    if (e) async_wait_all(e);
     VC_CHECK(e && bgr && out_m && id >= 0 && id < (int)e->trackers.size(), VC_ERR_ARG, "bad argument");
     VC_CHECK(k >= 1 && bbox_xyxy && conf, VC_ERR_ARG, "DeepSort.update needs at least one box (the reference only calls it then)");
     VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
     const size_t bytes = (size_t)h * w * 3;
     VC_CHECK(bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frame exceeds the staging buffer");
     VC_HIP(hipMemcpyAsync(e->d_frames, bgr, bytes, hipMemcpyHostToDevice, e->stream));
@@ -749,10 +620,10 @@ int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, c
 
 int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, const uint8_t* bgr, int h, int w, const double* boxes_xywh,
                         const int64_t* labels, const double* scores, int n, int64_t* out_rows6, int cap_rows, int* out_m) {
-    if (e) async_wait_all(e);
     VC_CHECK(e && trackers && bgr && out_m, VC_ERR_ARG, "null argument");
     VC_CHECK(n >= 1 && boxes_xywh && labels && scores, VC_ERR_ARG, "VideoTracker.run needs at least one box (quirk Q1)");
     VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
     const size_t bytes = (size_t)h * w * 3;
     VC_CHECK(bytes <= e->d_frames_bytes, VC_ERR_CAPACITY, "frame exceeds the staging buffer");
     VC_HIP(hipMemcpyAsync(e->d_frames, bgr, bytes, hipMemcpyHostToDevice, e->stream));
@@ -789,16 +660,12 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
     return VC_OK;
 }
 
-// ---- single-function entry points (parity tests) --------------------------------------------------------------
-static int with_pool(int n, TrackPool& tp, std::vector<void*>& allocs, int** d_slots) {
+// ---- single-function entry points (parity tests): the batch kernel's device functions on caller-supplied state --------------------
+static int with_pool(int n, TrackPool& tp, std::vector<void*>& allocs) {
     tp.max_tracks = n; tp.budget_cap = 1;
     VC_HIP(hipMalloc((void**)&tp.mean, (size_t)n * 8 * sizeof(double))); allocs.push_back(tp.mean);
     VC_HIP(hipMalloc((void**)&tp.cov, (size_t)n * 64 * sizeof(double))); allocs.push_back(tp.cov);
     tp.gallery = nullptr;
-    std::vector<int> s(n);
-    std::iota(s.begin(), s.end(), 0);
-    VC_HIP(hipMalloc((void**)d_slots, (size_t)n * sizeof(int))); allocs.push_back(*d_slots);
-    VC_HIP(hipMemcpy(*d_slots, s.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     return VC_OK;
 }
 static void free_all(std::vector<void*>& a) { for (void* p : a) hipFree(p); a.clear(); }
@@ -806,47 +673,36 @@ static void free_all(std::vector<void*>& a) { for (void* p : a) hipFree(p); a.cl
 #define VC_HOST_FINISH(st)                                                                                              \
     if ((st) == VC_OK && hipDeviceSynchronize() != hipSuccess) { set_error("kernel failed: %s", hipGetErrorString(hipGetLastError())); (st) = VC_ERR_HIP; }
 
-int vc_kalman_initiate_host(const double* xyah, int n, double* mean8, double* cov64) {
-    VC_CHECK(xyah && mean8 && cov64 && n > 0, VC_ERR_ARG, "bad argument");
-    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double* dz = nullptr;
-    int st = with_pool(n, tp, al, &ds);
-    if (st == VC_OK && hipMalloc((void**)&dz, (size_t)n * 32) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; } else al.push_back(dz);
-    if (st == VC_OK && hipMemcpy(dz, xyah, (size_t)n * 32, hipMemcpyHostToDevice) != hipSuccess) { set_error("copy"); st = VC_ERR_HIP; }
-    if (st == VC_OK) st = launch_kalman_initiate(tp, ds, dz, n, nullptr);
-    VC_HOST_FINISH(st);
-    if (st == VC_OK) { hipMemcpy(mean8, tp.mean, (size_t)n * 64, hipMemcpyDeviceToHost); hipMemcpy(cov64, tp.cov, (size_t)n * 512, hipMemcpyDeviceToHost); }
-    free_all(al);
-    return st;
-}
-
-static int kalman_inout(double* mean8, double* cov64, const double* z4, int n, int which) {
+// which: 0 initiate (z -> mean, cov), 1 predict, 2 update (z)
+static int kalman_kat(double* mean8, double* cov64, const double* z4, int n, int which) {
     VC_CHECK(mean8 && cov64 && n > 0, VC_ERR_ARG, "bad argument");
-    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double* dz = nullptr;
-    int st = with_pool(n, tp, al, &ds);
-    if (st == VC_OK) { hipMemcpy(tp.mean, mean8, (size_t)n * 64, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov64, (size_t)n * 512, hipMemcpyHostToDevice); }
+    TrackPool tp{}; std::vector<void*> al; double* dz = nullptr;
+    int st = with_pool(n, tp, al);
+    if (st == VC_OK && which != 0) { hipMemcpy(tp.mean, mean8, (size_t)n * 64, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov64, (size_t)n * 512, hipMemcpyHostToDevice); }
     if (st == VC_OK && z4) {
         if (hipMalloc((void**)&dz, (size_t)n * 32) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; } else { al.push_back(dz); hipMemcpy(dz, z4, (size_t)n * 32, hipMemcpyHostToDevice); }
     }
-    if (st == VC_OK) st = which == 0 ? launch_kalman_predict(tp, ds, n, nullptr) : launch_kalman_update(tp, ds, dz, n, nullptr);
+    if (st == VC_OK) st = launch_kat_kalman(tp, which, dz, n, nullptr);
     VC_HOST_FINISH(st);
     if (st == VC_OK) { hipMemcpy(mean8, tp.mean, (size_t)n * 64, hipMemcpyDeviceToHost); hipMemcpy(cov64, tp.cov, (size_t)n * 512, hipMemcpyDeviceToHost); }
     free_all(al);
     return st;
 }
-int vc_kalman_predict_host(double* mean8, double* cov64, int n) { return kalman_inout(mean8, cov64, nullptr, n, 0); }
+int vc_kalman_initiate_host(const double* xyah, int n, double* mean8, double* cov64) {
+    VC_CHECK(xyah, VC_ERR_ARG, "null measurement");
+    return kalman_kat(mean8, cov64, xyah, n, 0);
+}
+int vc_kalman_predict_host(double* mean8, double* cov64, int n) { return kalman_kat(mean8, cov64, nullptr, n, 1); }
 int vc_kalman_update_host(double* mean8, double* cov64, const double* z4, int n) {
     VC_CHECK(z4, VC_ERR_ARG, "null measurement");
-    return kalman_inout(mean8, cov64, z4, n, 1);
+    return kalman_kat(mean8, cov64, z4, n, 2);
 }
 
-// gating distance of ONE track against n_meas measurements, through the appearance-cost kernel with an empty
-// gallery: returns the squared Mahalanobis distances reconstructed from the gate (exact values via a side channel)
+// squared Mahalanobis distances of ONE track against n_meas measurements (the gate's project4 / chol4 / maha4)
 int vc_kalman_gating_host(const double* mean8, const double* cov64, const double* z4, int n_meas, double* out) {
     VC_CHECK(mean8 && cov64 && z4 && out && n_meas > 0, VC_ERR_ARG, "bad argument");
-    // Reuse the device code path: a 1-track pool, gallery of one zero... the kernel only exposes the gated cost, so
-    // the distances themselves are produced by a dedicated tiny launch below.
-    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr; double *dz = nullptr, *dout = nullptr;
-    int st = with_pool(1, tp, al, &ds);
+    TrackPool tp{}; std::vector<void*> al; double *dz = nullptr, *dout = nullptr;
+    int st = with_pool(1, tp, al);
     if (st == VC_OK) { hipMemcpy(tp.mean, mean8, 64, hipMemcpyHostToDevice); hipMemcpy(tp.cov, cov64, 512, hipMemcpyHostToDevice); }
     if (st == VC_OK && (hipMalloc((void**)&dz, (size_t)n_meas * 32) != hipSuccess || hipMalloc((void**)&dout, (size_t)n_meas * 8) != hipSuccess)) { set_error("alloc"); st = VC_ERR_HIP; }
     if (dz) al.push_back(dz);
@@ -860,8 +716,6 @@ int vc_kalman_gating_host(const double* mean8, const double* cov64, const double
 
 int vc_iou_cost_host(const double* track_tlwh, int t, const double* det_tlwh, int d, double* out_iou) {
     VC_CHECK(track_tlwh && det_tlwh && out_iou && t > 0 && d > 0, VC_ERR_ARG, "bad argument");
-    // tracks are given as boxes: build means (cx, cy, a, h) whose to_tlwh() reproduces them is lossy, so the kernel is
-    // driven through its box-level twin
     double *da = nullptr, *db = nullptr, *dout = nullptr;
     std::vector<void*> al;
     int st = VC_OK;
@@ -880,8 +734,8 @@ int vc_iou_cost_host(const double* track_tlwh, int t, const double* det_tlwh, in
 
 int vc_cosine_cost_host(const float* gallery, const int* gal_count, int t, int s_cap, const float* feat, int d, double* out) {
     VC_CHECK(gallery && gal_count && feat && out && t > 0 && d > 0 && s_cap > 0, VC_ERR_ARG, "bad argument");
-    TrackPool tp{}; std::vector<void*> al; int* ds = nullptr;
-    int st = with_pool(t, tp, al, &ds);
+    TrackPool tp{}; std::vector<void*> al;
+    int st = with_pool(t, tp, al);
     tp.budget_cap = s_cap;
     float* dfeat = nullptr; double *dz = nullptr, *dout = nullptr; CostJob* dj = nullptr; int* drow = nullptr;
     if (st == VC_OK && (hipMalloc((void**)&tp.gallery, (size_t)t * s_cap * VC_FEAT_DIM * 4) != hipSuccess || hipMalloc((void**)&dfeat, (size_t)d * VC_FEAT_DIM * 4) != hipSuccess ||
@@ -930,13 +784,29 @@ int vc_dsort_nms_host(const double* tlwh, const double* scores, int n, double ma
     return VC_OK;
 }
 
+// scipy.optimize.linear_sum_assignment through the tracker kernel's own solver (track_core.h lap_solve, one wave on the device)
 int vc_lap_host(const double* cost, int nr, int nc, int* rows, int* cols, int* n_assigned) {
     VC_CHECK(cost && rows && cols && n_assigned && nr >= 0 && nc >= 0, VC_ERR_ARG, "bad argument");
-    std::vector<int> r, c;
-    VC_TRY(lap_solve(cost, nr, nc, r, c));
-    for (size_t i = 0; i < r.size(); ++i) { rows[i] = r[i]; cols[i] = c[i]; }
-    *n_assigned = (int)r.size();
-    return VC_OK;
+    *n_assigned = 0;
+    if (nr == 0 || nc == 0) return VC_OK;
+    VC_CHECK(nr <= 512 && nc <= 512, VC_ERR_CAPACITY, "lap: at most 512 rows / columns");
+    std::vector<void*> al;
+    double *dc = nullptr, *dt = nullptr; int *dr = nullptr, *dq = nullptr, *dn = nullptr;
+    const int k = std::min(nr, nc);
+    int st = VC_OK;
+    if (hipMalloc((void**)&dc, (size_t)nr * nc * 8) != hipSuccess || hipMalloc((void**)&dt, (size_t)nr * nc * 8) != hipSuccess ||
+        hipMalloc((void**)&dr, (size_t)k * 4) != hipSuccess || hipMalloc((void**)&dq, (size_t)k * 4) != hipSuccess || hipMalloc((void**)&dn, 4) != hipSuccess) { set_error("alloc"); st = VC_ERR_HIP; }
+    for (void* p : {(void*)dc, (void*)dt, (void*)dr, (void*)dq, (void*)dn}) if (p) al.push_back(p);
+    if (st == VC_OK) { hipMemcpy(dc, cost, (size_t)nr * nc * 8, hipMemcpyHostToDevice); st = launch_kat_lap(dc, nr, nc, dt, dr, dq, dn, nullptr); }
+    VC_HOST_FINISH(st);
+    if (st == VC_OK) {
+        int n = 0;
+        hipMemcpy(&n, dn, 4, hipMemcpyDeviceToHost);
+        if (n < 0) { set_error("lap: infeasible cost matrix"); st = VC_ERR_ARG; }
+        else { hipMemcpy(rows, dr, (size_t)n * 4, hipMemcpyDeviceToHost); hipMemcpy(cols, dq, (size_t)n * 4, hipMemcpyDeviceToHost); *n_assigned = n; }
+    }
+    free_all(al);
+    return st;
 }
 
 }  // extern "C"

@@ -156,6 +156,15 @@ class Engine:
                                          L.ptr(cov, C.c_double), L.ptr(gal, C.c_int)))
         return {"ids": ids, "state": st, "hits": hits, "age": age, "tsu": tsu, "mean": mean, "cov": cov, "gallery": gal}
 
+    def tracker_debug_costs(self, cap=1 << 18):
+        """(appearance [T, D], iou [T, D]) cost matrices of the last blocking single-tracker step, as the tracker kernel computed
+        them (rows are only meaningful for the tracks that took part: confirmed tracks / IoU candidates)."""
+        app, iou = np.zeros(cap), np.zeros(cap)
+        t, d = C.c_int(), C.c_int()
+        L.check(L.lib().vc_tracker_debug_costs(self._h, cap, L.ptr(app, C.c_double), L.ptr(iou, C.c_double), C.byref(t), C.byref(d)))
+        n = t.value * d.value
+        return app[:n].reshape(t.value, d.value).copy(), iou[:n].reshape(t.value, d.value).copy()
+
     def tracker_snapshot(self, tid) -> bytes:
         """Serialised tracker state (parameters, id counter, Kalman state, galleries) for stream migration."""
         n = C.c_size_t()
