@@ -116,10 +116,14 @@ struct TrackBatchArgs {
     int* task_ntracks;               // [n_tasks] live tracks after the step
     int* task_T;                     // [n_tasks] live tracks before the step (rows of the step's cost matrices)
     int* status;                     // [0] first error (tc::TERR_*), [1] tracker, [2] task
-    double* scratch;                 // per workgroup 4 x cap x cap doubles: appearance rows, IoU rows, gathered sub-matrix, transpose
-    int cap;                         // per-step capacity (tracks + detections), a multiple of 8
+    double* scratch;                 // per workgroup track_scratch_per_wg() bytes: appearance rows, IoU rows, gathered sub-matrix,
+    size_t scratch_per_wg;           // transpose (4 x 65536 doubles) + the work arrays of steps too large for the LDS
+    int cap;                         // tracks + detections per step whose work arrays live in LDS (a multiple of 8, <= 512)
     int frame_w, frame_h;
+    int dbg_costs;                   // 1: keep the cost rows in the global scratch (vc_tracker_debug_costs reads them back)
+    long long* dbg;                  // diagnostics (VC_TRACK_DBG): per task 8 timestamps (100 MHz): start, predict, cost rows, match, apply, finish
 };
+size_t track_scratch_per_wg();
 int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s);
 // test entry points: the batch kernel's own device functions on caller-supplied state
 int launch_kat_kalman(TrackPool& tp, int which /* 0 initiate, 1 predict, 2 update */, const double* z, int n, hipStream_t s);

@@ -336,6 +336,7 @@ int vc_nms_host(const float* boxes4, const float* conf, const int* cls, int n, f
     A((void**)&pb.cand_count, 4); A((void**)&pb.sort_box, mc * 16); A((void**)&pb.sort_conf, mc * 4); A((void**)&pb.sort_cls, mc * 4);
     A((void**)&pb.mask, mc * (mc / 64) * 8); A((void**)&pb.det, (size_t)max_det * 24); A((void**)&pb.det_count, 4); A((void**)&pb.overflow, 4);
     A((void**)&geom, 20);
+    if (st == VC_OK && hipMemset(pb.overflow, 0, 4) != hipSuccess) { set_error("memset failed"); st = VC_ERR_HIP; }
     if (st == VC_OK) {
         std::vector<int> idx(n);
         std::iota(idx.begin(), idx.end(), 0);

@@ -24,6 +24,9 @@ namespace tc {
 
 enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
 enum { TERR_NONE = 0, TERR_TRACK_CAP = 1, TERR_POOL = 2, TERR_ROWS = 3, TERR_LAP = 4 };
+// most live tracks + detections one tracker step can hold; a step's cost matrices are [T][D] with T + D <= TC_HARD_CAP, i.e. at
+// most TC_MAT = (TC_HARD_CAP / 2)^2 entries
+enum { TC_HARD_CAP = 512, TC_MAT = 256 * 256 };
 
 struct TrackRecD { long long id; int state, hits, age, tsu, gal_count, gal_head; };                       // per pool slot, 32 B
 struct TrackerHdr { double max_dist, max_iou_distance; long long next_id; int max_age, n_init, nn_budget, n_tracks, err, pad; };   // 48 B
@@ -165,6 +168,8 @@ struct StepWork {
     int *confirmed, *unconfirmed, *left, *rows, *un_rows, *un_cols, *un_tracks, *match_t, *match_d, *ri, *ci, *newslot;
     unsigned char *row_used, *col_used, *matched;
     LapWork lap;
+    double *small_c, *small_t;      // gathered sub-matrix / its transpose when it has at most small_n entries (LDS on the device:
+    int small_n;                    // the assignment's scans then never leave the CU); 0 = always use the caller's buffers
 };
 
 // bytes of one StepWork with capacity cap (all arrays 8-byte aligned: cap is a multiple of 8)
@@ -173,6 +178,7 @@ VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (5 + 12 + 4) +
 VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     char* p = (char*)base;
     w.cap = cap;
+    w.small_c = nullptr; w.small_t = nullptr; w.small_n = 0;
     auto D = [&](double*& q) { q = (double*)p; p += (size_t)cap * 8; };
     auto I = [&](int*& q) { q = (int*)p; p += (size_t)cap * 4; };
     auto B = [&](unsigned char*& q) { q = (unsigned char*)p; p += (size_t)cap; };
@@ -186,6 +192,22 @@ VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
 
 // scipy.optimize.linear_sum_assignment on c [nr][nc]: pairs (ri[k], ci[k]) sorted by row; returns their number (min(nr, nc)).
 VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc, double* tbuf, int& err) {
+    if (nr == 1 || nc == 1) {
+        // One row (or one column): the augmenting-path search reduces to its first scan -- the minimum entry, and among equal
+        // minima the smallest index (the scan walks the columns in descending order and keeps the LAST unassigned minimum; for one
+        // column SciPy solves the transpose).  Most cascade levels of a light scene hold a single track.
+        const int n = nr * nc;
+        Best b = {(double)INFINITY, 0, INT_MAX};
+        for (int e = L.lane; e < n; e += L.n) {
+            const Best x = {c[e], 0, e};
+            if (better(x, b)) b = x;
+        }
+        b = wave_best(L, b);
+        if (b.it == INT_MAX) { err = TERR_LAP; return 0; }
+        if (L.lane == 0) { w.ri[0] = nr == 1 ? 0 : b.it; w.ci[0] = nr == 1 ? b.it : 0; }
+        wave_sync();
+        return 1;
+    }
     if (nc < nr) {                                           // SciPy transposes so that rows <= columns
         for (int e = L.lane; e < nr * nc; e += L.n) {       // parallel
             const int i = e / nc, j = e - i * nc;
@@ -221,6 +243,7 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
         wave_sync();
         return;
     }
+    if (nr * nc <= w.small_n) { cbuf = w.small_c; tbuf = w.small_t; }
     for (int e = L.lane; e < nr * nc; e += L.n) {           // parallel gather + clamp
         const int i = e / nc, j = e - i * nc;
         const double v = cost[(size_t)rows[i] * ld + cols[j]];

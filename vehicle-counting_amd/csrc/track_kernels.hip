@@ -100,6 +100,7 @@ __device__ __forceinline__ void kalman_update_wave(double* m, double* P, const d
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define VC_SMALL_D 12       // detections per step up to which the appearance rows run one wave per track (appearance_row_wave)
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
@@ -107,6 +108,8 @@ struct TrackShared {
     int featrow[16];                 // feature rows / xyah of the 16 detections being scored
     double xyah[16][4];
     double kbuf[4][32];              // Kalman gain rows, one block per wave (kalman_update_wave)
+    double small_c[256], small_t[256];   // small assignment problems stay in LDS (StepWork::small_c / small_t)
+    double cost_small[2][512];           // the step's appearance / IoU rows when T x D <= 512 (else the workgroup's global scratch)
     int ctl[8];                      // P1 -> P2/P3 hand-over: n_match, n_un, n_new, newdets is w.left, error
 };
 
@@ -119,7 +122,7 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
                                                    const double* det_xyah, double* out, TrackShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
-    const int S = jb.gal_count, D = jb.det_n;
+    const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
     const double* m = tp.mean + (size_t)jb.slot * 8;
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
@@ -134,13 +137,14 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
         const float* fptr = feat + (size_t)sh.featrow[col] * VC_FEAT_DIM + kq * 4;
         float best = -INFINITY, ss = 0.f;
         for (int st = wave; st * 16 < S; st += 4) {
-            const float* gptr = gal + (size_t)min(st * 16 + col, S - 1) * VC_FEAT_DIM + kq * 4;
+            // gallery layout [k / 4][sample][4] (gallery_store_wave): 16 consecutive samples of one k-chunk are 256 contiguous bytes
+            const float* gptr = gal + ((size_t)kq * SC + min(st * 16 + col, S - 1)) * 4;
             // four independent accumulators (k mod 4 chunks): a 32-deep MFMA dependency chain instead of 128
             f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
             float s2 = 0.f;
 #pragma unroll 8
             for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
-                const float4 a = *(const float4*)(gptr + k0), b = *(const float4*)(fptr + k0);
+                const float4 a = *(const float4*)(gptr + (size_t)k0 * SC), b = *(const float4*)(fptr + k0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc2, 0, 0, 0);
@@ -172,16 +176,86 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
     }
 }
 
+// The same row for a SMALL number of detections, one wave per track: v_mfma_f32_4x4x1_16b_f32 = 16 independent 4x4 outer products
+// per instruction, block b = samples 4b .. 4b+3 (A operand: lane l feeds sample l), columns = 4 detections (B operand: lane l feeds
+// detection l % 4); measured layout (tools/ubench/mfma4x4_probe.hip): D[vgpr i] at lane l = A[lane 4*(l/4) + i] * B[lane l].
+// 64 samples x 4 detections per instruction with nothing wasted, where the 16x16x4 form above spends 16 columns on 2-3 detections
+// and needs all four waves for one track.  Accumulator c takes the elements k = c (mod 4) in increasing k, summed
+// (acc0 + acc1) + (acc2 + acc3), and |f|^2 is built from the same four partial sums as above: bit-identical to appearance_row_dev.
+__device__ __forceinline__ void appearance_row_wave(const TrackPool& tp, const CostJob& jb, const float* feat, const int* det_feat_row,
+                                                    const double* det_xyah, double* out, int lane) {
+    const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
+    const double* m = tp.mean + (size_t)jb.slot * 8;
+    const float* gal = tp.gallery + (size_t)jb.slot * SC * VC_FEAT_DIM;
+    double Lc[16];
+    {   // the gate's Cholesky factor depends on the track only (fp64, ~100 dependent operations): once, not per detection group
+        double Sg[16];
+        project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
+        chol4(Sg, Lc);
+    }
+    // eight detections per pass over the gallery: lane l feeds detection d0 + l % 4 (group A) and d0 + 4 + l % 4 (group B)
+    for (int d0 = 0; d0 < D; d0 += 8) {
+        const bool two = d0 + 4 < D;                               // wave-uniform
+        const int dA = jb.det_off + min(d0 + (lane & 3), D - 1), dB = jb.det_off + min(d0 + 4 + (lane & 3), D - 1);
+        const float* fa = feat + (size_t)det_feat_row[dA] * VC_FEAT_DIM;
+        const float* fb = feat + (size_t)det_feat_row[dB] * VC_FEAT_DIM;
+        float bestA = -INFINITY, bestB = -INFINITY, ssA = 0.f, ssB = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            // gallery layout [k / 4][sample][4]: the 64 lanes read 64 consecutive samples of one k-chunk = 1 KiB contiguous
+            const float* gp = gal + (size_t)min(s0 + lane, S - 1) * 4;
+            f32x4_t A0 = {0.f, 0.f, 0.f, 0.f}, A1 = A0, A2 = A0, A3 = A0, B0 = A0, B1 = A0, B2 = A0, B3 = A0;
+            float qa[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c0 = 0; c0 < VC_FEAT_DIM / 4; c0 += 4) {
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const float4 a = *(const float4*)(gp + (size_t)(c0 + kq) * SC * 4);
+                    const float4 b = *(const float4*)(fa + (c0 + kq) * 4);
+                    A0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, A0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, A1, 0, 0, 0);
+                    A2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, A2, 0, 0, 0);
+                    A3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, A3, 0, 0, 0);
+                    qa[kq] += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+                    if (two) {
+                        const float4 b2 = *(const float4*)(fb + (c0 + kq) * 4);
+                        B0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b2.x, B0, 0, 0, 0);
+                        B1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b2.y, B1, 0, 0, 0);
+                        B2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b2.z, B2, 0, 0, 0);
+                        B3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b2.w, B3, 0, 0, 0);
+                        qb[kq] += b2.x * b2.x + b2.y * b2.y + b2.z * b2.z + b2.w * b2.w;
+                    }
+                }
+            }
+            const f32x4_t accA = (A0 + A1) + (A2 + A3), accB = (B0 + B1) + (B2 + B3);
+            ssA = (qa[0] + qa[1]) + (qa[2] + qa[3]);
+            ssB = (qb[0] + qb[1]) + (qb[2] + qb[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                           // acc[i] = <g_{s0 + 4*(lane/4) + i}, f_{d + lane%4}>
+                if (s0 + (lane & ~3) + i < S) { bestA = fmaxf(bestA, accA[i]); bestB = fmaxf(bestB, accB[i]); }
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { bestA = fmaxf(bestA, __shfl_xor(bestA, o)); bestB = fmaxf(bestB, __shfl_xor(bestB, o)); }
+        // lanes 0-3 finish group A, lanes 4-7 group B (lane & 3 = detection within the group, same value in every block)
+        const int d = d0 + lane;                                   // lanes 0..7 -> detections d0 .. d0 + 7
+        if (lane < 8 && d < D) {
+            const float best = lane < 4 ? bestA : bestB, ss = lane < 4 ? ssA : ssB;
+            const float cosv = best * (1.0f / sqrtf(ss));
+            const double g2 = maha4(m, Lc, det_xyah + (size_t)(jb.det_off + d) * 4);
+            out[jb.out_off + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+        }
+    }
+}
+
 // gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector).
-// One wave: lane l holds elements [4l, 4l+4) and [256 + 4l, 256 + 4l + 4).
-__device__ __forceinline__ void gallery_store_wave(float* dst, const float* src, int lane) {
+// Layout of a slot's gallery: [k / 4][sample position][4 floats] -- a k-chunk of all samples is contiguous, which is how both
+// appearance kernels read it (their lanes are samples).  One wave: lane l holds chunks l and 64 + l of the feature.
+__device__ __forceinline__ void gallery_store_wave(float* slot_gallery, int pos, int SC, const float* src, int lane) {
     const float4 a = ((const float4*)src)[lane], b = ((const float4*)src)[64 + lane];
     float ss = (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float nrm = sqrtf(ss);
-    ((float4*)dst)[lane] = make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm);
-    ((float4*)dst)[64 + lane] = make_float4(b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm);
+    *(float4*)(slot_gallery + ((size_t)lane * SC + pos) * 4) = make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm);
+    *(float4*)(slot_gallery + ((size_t)(64 + lane) * SC + pos) * 4) = make_float4(b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm);
 }
 
 // ---- slot pool: during a kernel slots are only TAKEN from the free stack (filled before the launch) and freed slots are only
@@ -210,26 +284,36 @@ extern __shared__ __attribute__((aligned(16))) char track_dyn_lds[];
 
 __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a) {
     __shared__ TrackShared sh;
-    StepWork w;
-    step_work_carve(w, track_dyn_lds, a.cap);
+    // Work arrays: in LDS for steps with up to a.cap tracks + detections (what the host expects from the trackers' recent sizes),
+    // in the workgroup's global scratch for the rare larger step (same code, L2 latency instead of LDS latency) up to TC_HARD_CAP.
+    StepWork w_lds, w_glb;
+    step_work_carve(w_lds, track_dyn_lds, a.cap);
     const TrackWgPlan plan = a.plans[blockIdx.x];
     TrackerHdr* hdr = a.hdrs + plan.tracker;
     int* list = a.lists + (size_t)plan.tracker * a.list_cap;
-    const size_t mat = (size_t)a.cap * a.cap;
-    double* cost_app = a.scratch + (size_t)blockIdx.x * 4 * mat;
-    double* cost_iou = cost_app + mat;
-    double* cbuf = cost_iou + mat;
-    double* tbuf = cbuf + mat;
+    char* wg_scratch = (char*)a.scratch + (size_t)blockIdx.x * a.scratch_per_wg;
+    double* const cost_app_g = (double*)wg_scratch;         // 4 matrices of TC_MAT doubles: T x D <= TC_MAT whenever T + D <= TC_HARD_CAP
+    double* const cost_iou_g = cost_app_g + TC_MAT;
+    double* cbuf = cost_iou_g + TC_MAT;
+    double* tbuf = cbuf + TC_MAT;
+    step_work_carve(w_glb, wg_scratch + 4 * TC_MAT * sizeof(double), TC_HARD_CAP);
+    w_lds.small_c = w_glb.small_c = sh.small_c; w_lds.small_t = w_glb.small_t = sh.small_t; w_lds.small_n = w_glb.small_n = 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Lanes L{lane, 64};
     const TrackPool& tp = a.pool;
 
+#define VC_TTS(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)task * 8 + (i)] = wall_clock64(); } while (0)
     for (int task = plan.task_begin; task < plan.task_end; ++task) {
+        VC_TTS(0);
         const TrackTask tk = a.tasks[task];
         const int T = hdr->n_tracks, D = tk.det_n;
         const int prior = hdr->err;
+        const StepWork& w = T + D <= a.cap ? w_lds : w_glb;
+        const bool small_cost = T * D <= 512 && !a.dbg_costs;            // block-uniform
+        double* cost_app = small_cost ? sh.cost_small[0] : cost_app_g;
+        double* cost_iou = small_cost ? sh.cost_small[1] : cost_iou_g;
         // every capacity check comes before anything is mutated: a refused step leaves the tracker exactly as it was
-        if (prior != TERR_NONE || T + D > a.cap || T + D > a.list_cap) {
+        if (prior != TERR_NONE || T + D > TC_HARD_CAP || T + D > a.list_cap) {
             __syncthreads();
             if (threadIdx.x == 0) {
                 if (prior == TERR_NONE) report_error(a, hdr, TERR_TRACK_CAP, plan.tracker, task);
@@ -250,7 +334,22 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane);
         }
         __syncthreads();
-        if (D > 0) {
+        VC_TTS(1);
+        if (D > 0 && D <= VC_SMALL_D) {
+            // few detections (the usual frame): one wave per track, no workgroup barriers
+            for (int t = wave; t < T; t += 4) {
+                const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
+                if (st == CONFIRMED) {
+                    const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
+                    appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
+                }
+                if (!(st == CONFIRMED && tsu != 1) && lane < D) {
+                    double b[4];
+                    mean_to_tlwh(tp.mean + (size_t)slot * 8, b);
+                    cost_iou[(size_t)t * D + lane] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + lane) * 4);
+                }
+            }
+        } else if (D > 0) {
             for (int t = 0; t < T; ++t) {                               // block-uniform
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
@@ -266,6 +365,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             }
         }
         __syncthreads();
+        VC_TTS(2);
         // ---- P1: matching (wave 0) --------------------------------------------------------------------------------------------
         if (wave == 0) {
             int n_match = 0, n_un = 0, n_new = 0, err = TERR_NONE;
@@ -275,6 +375,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             if (lane == 0) { sh.ctl[0] = n_match; sh.ctl[1] = n_un; sh.ctl[2] = n_new; sh.ctl[3] = newdets == w.left ? 1 : 0; sh.ctl[4] = err; }
         }
         __syncthreads();
+        VC_TTS(3);
         const int n_match = sh.ctl[0], n_un = sh.ctl[1], n_new = sh.ctl[2], err = sh.ctl[4];
         const int* newdets = sh.ctl[3] ? w.left : w.un_cols;
         if (err != TERR_NONE) {                                          // pool exhausted / infeasible assignment: the tracker stops here
@@ -290,14 +391,15 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             if (k < n_match) {                                           // Track.update (track.py:126-145)
                 const int t = w.match_t[k], g = tk.det_off + w.match_d[k], slot = w.slot[t];
                 kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave]);
-                gallery_store_wave(tp.gallery + ((size_t)slot * tp.budget_cap + w.galh[t]) * VC_FEAT_DIM, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, w.galh[t], tp.budget_cap, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
             } else {                                                     // _initiate_track (tracker.py:133-139)
                 const int i = k - n_match, g = tk.det_off + newdets[i], slot = w.newslot[i];
                 kalman_initiate_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane);
-                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, 0, tp.budget_cap, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
             }
         }
         __syncthreads();
+        VC_TTS(4);
         // ---- P3: FSM, list maintenance, rows (wave 0) -----------------------------------------------------------------------------
         if (wave == 0) {
             const int n = finish_step(L, w, hdr, list, a.recs, T, n_match, n_un, n_new, [&](const int* slots, int nd) {
@@ -323,7 +425,10 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             if (lane == 0) { a.task_ntracks[task] = n; a.task_T[task] = T; }
         }
         __syncthreads();
+        VC_TTS(5);
+        if (a.dbg && threadIdx.x == 0) { a.dbg[(size_t)task * 8 + 6] = T; a.dbg[(size_t)task * 8 + 7] = D; }
     }
+#undef VC_TTS
 }
 
 // freed slots of the last batch -> free stack (between batches, one workgroup)
@@ -334,10 +439,13 @@ __global__ __launch_bounds__(256) void merge_free_kernel(int* free_top, int* fre
     if (threadIdx.x == 0) { *free_top = top + n; *freed_count = 0; }
 }
 
+size_t track_scratch_per_wg() { return ((size_t)4 * TC_MAT * sizeof(double) + step_work_bytes(TC_HARD_CAP) + 255) & ~(size_t)255; }
+
 int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
     if (n_wg <= 0) return VC_OK;
     const size_t lds = step_work_bytes(a.cap);
-    VC_CHECK(a.cap % 8 == 0 && lds <= 64 * 1024 - 4096, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
+    VC_CHECK(a.cap % 8 == 0 && a.cap <= TC_HARD_CAP && lds <= 64 * 1024 - 4096, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
+    VC_CHECK(a.scratch_per_wg >= track_scratch_per_wg(), VC_ERR_ARG, "tracker scratch too small");
     hipLaunchKernelGGL(track_batch_kernel, dim3(n_wg), dim3(256), lds, s, a);
     VC_HIP(hipGetLastError());
     hipLaunchKernelGGL(merge_free_kernel, dim3(1), dim3(256), 0, s, a.free_top, a.free_stack, a.freed_count, a.freed);
@@ -382,7 +490,7 @@ int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, 
 
 __global__ __launch_bounds__(64) void kat_gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
     const int* e = sps + (size_t)blockIdx.x * 3;
-    gallery_store_wave(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x);
+    gallery_store_wave(tp.gallery + (size_t)e[0] * tp.budget_cap * VC_FEAT_DIM, e[1], tp.budget_cap, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x);
 }
 
 int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {

@@ -14,6 +14,9 @@
 #include <cstring>
 #include <cmath>
 #include <numeric>
+#include <climits>
+#include <cstdint>
+#include <cstdlib>
 
 #include "engine.h"
 #include "track_core.h"
@@ -169,18 +172,17 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     int need = 8;
     for (int k = 0; k < n_tasks;) {
         const int tr = s.tasks[order[k]].tracker;
-        int k1 = k, dets = 0;
-        while (k1 < n_tasks && s.tasks[order[k1]].tracker == tr) { dets += s.tasks[order[k1]].det_n; ++k1; }
+        int k1 = k, dets = 0, dmax = 0;
+        while (k1 < n_tasks && s.tasks[order[k1]].tracker == tr) { dets += s.tasks[order[k1]].det_n; dmax = std::max(dmax, s.tasks[order[k1]].det_n); ++k1; }
         plans.push_back(TrackWgPlan{tr, k, k1, 0});
-        Tracker& tk = *e->trackers[tr];
-        need = std::max(need, tk.known_tracks + tk.pending_dets + dets);      // live tracks + detections can never exceed this in the batch
+        // LDS capacity from the tracker's recent size (the kernel falls back to global-memory work arrays for a larger step)
+        need = std::max(need, 2 * e->trackers[tr]->known_tracks + 2 * dmax + 16);
         s.tracker_dets.emplace_back(tr, dets);
         s.last_task_of.push_back(k1 - 1);
         k = k1;
     }
     int cap = 32;
-    while (cap < need) cap *= 2;
-    VC_CHECK(cap <= 512, VC_ERR_CAPACITY, "a tracker may reach %d live tracks + detections in one step; the device tracker holds 512", need);
+    while (cap < need && cap < TC_HARD_CAP) cap *= 2;
     const int n_wg = (int)plans.size();
     s.n_wg = n_wg;
     s.step_cap = cap;
@@ -214,8 +216,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
                     fr[g] = c.dets.feat_rows[i];
                 }
     }
-    // scratch: 4 matrices of cap x cap doubles per workgroup
-    const size_t scratch = (size_t)n_wg * 4 * cap * cap * sizeof(double);
+    const size_t scratch = (size_t)n_wg * track_scratch_per_wg();
     if (scratch > e->track_scratch_bytes) {
         VC_TRY(track_idle(e));                                                // the old block may still be in use
         const size_t bytes = scratch * 3 / 2;
@@ -238,10 +239,47 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.task_row_off = (int*)(s.hd_out + ol.row_off); a.task_row_n = (int*)(s.hd_out + ol.row_n);
     a.task_ntracks = (int*)(s.hd_out + ol.ntracks); a.task_T = (int*)(s.hd_out + ol.tT);
     a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
-    a.scratch = e->d_track_scratch; a.cap = cap; a.frame_w = W; a.frame_h = H;
+    a.scratch = e->d_track_scratch; a.scratch_per_wg = track_scratch_per_wg(); a.cap = cap; a.frame_w = W; a.frame_h = H;
+    a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back
+    static const bool dbg_on = getenv("VC_TRACK_DBG") != nullptr;        // diagnostics: phase times of every task, printed per batch
+    long long* dbg = nullptr;
+    if (dbg_on && hipMalloc((void**)&dbg, (size_t)n_tasks * 64) == hipSuccess) { hipMemsetAsync(dbg, 0, (size_t)n_tasks * 64, ts); a.dbg = dbg; }
     {
         ProfScope ps(e, VC_PROF_TRACK);
         VC_TRY(launch_track_batch(a, n_wg, ts));
+    }
+    if (dbg) {
+        std::vector<long long> h((size_t)n_tasks * 8);
+        hipStreamSynchronize(ts);
+        hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        hipFree(dbg);
+        double acc[5] = {0, 0, 0, 0, 0}, sumT = 0, sumD = 0;
+        int maxwg = 0;
+        for (const TrackWgPlan& pl : plans) maxwg = std::max(maxwg, pl.task_end - pl.task_begin);
+        for (int k = 0; k < n_tasks; ++k) {
+            for (int i = 0; i < 5; ++i) acc[i] += (double)(h[(size_t)k * 8 + i + 1] - h[(size_t)k * 8 + i]) / 100.0;
+            sumT += (double)h[(size_t)k * 8 + 6]; sumD += (double)h[(size_t)k * 8 + 7];
+        }
+        fprintf(stderr, "[vc track dbg] %d tasks in %d workgroups (longest %d tasks), LDS cap %d; us per task: predict %.1f cost %.1f match %.1f apply %.1f finish %.1f; mean T %.1f D %.1f\n",
+                n_tasks, n_wg, maxwg, cap, acc[0] / n_tasks, acc[1] / n_tasks, acc[2] / n_tasks, acc[3] / n_tasks, acc[4] / n_tasks, sumT / n_tasks, sumD / n_tasks);
+        long long t_lo = INT64_MAX, t_hi = 0;
+        double worst = 0; const TrackWgPlan* wp = nullptr;
+        for (const TrackWgPlan& pl : plans) {
+            const long long b0 = h[(size_t)pl.task_begin * 8], b1 = h[(size_t)(pl.task_end - 1) * 8 + 5];
+            t_lo = std::min(t_lo, b0); t_hi = std::max(t_hi, b1);
+            if ((double)(b1 - b0) > worst) { worst = (double)(b1 - b0); wp = &pl; }
+        }
+        if (wp) {
+            double a2[5] = {0, 0, 0, 0, 0}, sT = 0, sD = 0, gaps = 0;
+            const int nt = wp->task_end - wp->task_begin;
+            for (int k = wp->task_begin; k < wp->task_end; ++k) {
+                for (int i = 0; i < 5; ++i) a2[i] += (double)(h[(size_t)k * 8 + i + 1] - h[(size_t)k * 8 + i]) / 100.0;
+                sT += (double)h[(size_t)k * 8 + 6]; sD += (double)h[(size_t)k * 8 + 7];
+                if (k > wp->task_begin) gaps += (double)(h[(size_t)k * 8] - h[(size_t)(k - 1) * 8 + 5]) / 100.0;
+            }
+            fprintf(stderr, "[vc track dbg]   kernel span %.0f us; slowest workgroup (tracker %d): %d tasks, %.0f us, per task predict %.1f cost %.1f match %.1f apply %.1f finish %.1f gap %.1f; mean T %.1f D %.1f\n",
+                    (double)(t_hi - t_lo) / 100.0, wp->tracker, nt, worst / 100.0, a2[0] / nt, a2[1] / nt, a2[2] / nt, a2[3] / nt, a2[4] / nt, gaps / nt, sT / nt, sD / nt);
+        }
     }
     VC_HIP(hipMemcpyAsync(s.h_out + ol.status, s.d_cursor + 4, 16, hipMemcpyDeviceToHost, ts));
     VC_HIP(hipEventRecord(s.done, ts));
@@ -485,7 +523,7 @@ int vc_tracker_debug_costs(vc_engine* e, int cap_entries, double* app, double* i
     const size_t n = (size_t)*T * *D;
     VC_CHECK(n <= (size_t)cap_entries, VC_ERR_CAPACITY, "need room for %zu entries", n);
     VC_HIP(hipStreamSynchronize(e->stream));
-    const size_t mat = (size_t)s.step_cap * s.step_cap;              // scratch of workgroup 0: [appearance | IoU | ...], rows of D entries
+    const size_t mat = TC_MAT;                                       // scratch of workgroup 0: [appearance | IoU | ...], rows of D entries
     if (n) {
         VC_HIP(hipMemcpy(app, e->d_track_scratch, n * sizeof(double), hipMemcpyDeviceToHost));
         VC_HIP(hipMemcpy(iou, e->d_track_scratch + mat, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -532,7 +570,14 @@ int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* siz
         VC_HIP(hipMemcpy(t.cov, e->pool.cov + (size_t)slot * 64, sizeof(t.cov), hipMemcpyDeviceToHost));
         memcpy(o, &t, sizeof(t)); o += sizeof(t);
         const size_t rows = (size_t)std::min(tr.gal_count, tp.nn_budget);
-        if (rows) VC_HIP(hipMemcpy(o, e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost));
+        if (rows) {                                              // device layout [k / 4][sample][4] -> rows of 512 floats
+            const size_t SC = e->pool.budget_cap;
+            std::vector<float> blk(SC * VC_FEAT_DIM);
+            VC_HIP(hipMemcpy(blk.data(), e->pool.gallery + (size_t)slot * SC * VC_FEAT_DIM, blk.size() * sizeof(float), hipMemcpyDeviceToHost));
+            float* dst = (float*)o;
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t c = 0; c < VC_FEAT_DIM / 4; ++c) memcpy(dst + r * VC_FEAT_DIM + c * 4, &blk[(c * SC + r) * 4], 16);
+        }
         o += rows * VC_FEAT_DIM * sizeof(float);
     }
     return VC_OK;
@@ -584,7 +629,14 @@ int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
         VC_HIP(hipMemcpy(e->pool.mean + (size_t)slot * 8, t.mean, sizeof(t.mean), hipMemcpyHostToDevice));
         VC_HIP(hipMemcpy(e->pool.cov + (size_t)slot * 64, t.cov, sizeof(t.cov), hipMemcpyHostToDevice));
         const size_t rows = (size_t)t.gal_count;
-        if (rows) VC_HIP(hipMemcpy(e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, in, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice));
+        if (rows) {                                              // rows of 512 floats -> device layout [k / 4][sample][4]
+            const size_t SC = e->pool.budget_cap;
+            std::vector<float> blk(SC * VC_FEAT_DIM, 0.f);
+            const float* src = (const float*)in;
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t c = 0; c < VC_FEAT_DIM / 4; ++c) memcpy(&blk[(c * SC + r) * 4], src + r * VC_FEAT_DIM + c * 4, 16);
+            VC_HIP(hipMemcpy(e->pool.gallery + (size_t)slot * SC * VC_FEAT_DIM, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         in += rows * VC_FEAT_DIM * sizeof(float);
     }
     if (h.n_tracks) VC_HIP(hipMemcpy(e->d_lists + (size_t)id * e->list_cap, slots.data(), (size_t)h.n_tracks * sizeof(int), hipMemcpyHostToDevice));
