@@ -158,6 +158,12 @@ struct vc_engine {
     vc::TrackStage tstage[4];                    // 0..2: batches of the stream path in flight, 3: the blocking entry points
     unsigned tstage_seq = 0;
     double* d_track_scratch = nullptr; size_t track_scratch_bytes = 0;
+    // appearance dots hoisted out of the sequential loop (TrackDotPlan, kernels.h)
+    vc::TrackDotPlan* d_dot_plans = nullptr; size_t dot_plans_cap = 0;
+    float* d_dot_arena = nullptr; size_t dot_arena_floats = 0;
+    int* d_row_src = nullptr; int row_src_cap = 0;
+    int* d_gal_row = nullptr; int* d_dot_ctl = nullptr;
+    float* d_nfeat = nullptr; float* d_det_ss = nullptr; size_t nfeat_cap = 0;
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
     int det_cap = 0;
 

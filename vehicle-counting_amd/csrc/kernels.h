@@ -90,8 +90,14 @@ struct CostJob {
 // One tracker step = (tracker, frame): Tracker.predict() + Tracker.update(detections) on the prepared (confidence-filtered,
 // DeepSORT-NMS'ed, deep_sort.py:31-41) detections [det_off, det_off + det_n) of the batch's detection arrays.
 struct TrackTask { int tracker, det_off, det_n, frame, label, pad0, pad1, pad2; };
-// workgroup b of the batch kernel owns one tracker and runs its tasks [task_begin, task_end) in order
-struct TrackWgPlan { int tracker, task_begin, task_end, pad; };
+// workgroup b of the batch kernel owns one tracker and runs its tasks [task_begin, task_end) in order; the tracker's detections of
+// the batch are the contiguous range [det_begin, det_begin + det_n) of the detection arrays (frames ascending)
+struct TrackWgPlan { int tracker, task_begin, task_end, det_begin, det_n, pad0, pad1, pad2; };
+// Appearance dot products hoisted out of the sequential tracker loop (track_kernels.hip, "dots"): every gallery sample a tracker
+// can hold during the batch is either a sample it held when the batch began or the normalised feature of one of the batch's own
+// detections, so <sample, detection feature> for ALL pairs is state-independent and is computed up front by a grid-wide kernel.
+// table[row * n_dets + d]: rows [0, n_old_rows) = the old samples (track order, ring position), rows n_old_rows + e = detection e.
+struct TrackDotPlan { long long table_off; int n_old_rows, n_dets, row_src_off, tile_begin, tiles, det_tiles, use_table, pad; };
 struct TrackBatchArgs {
     TrackPool pool;
     tc::TrackerHdr* hdrs;            // [max_trackers]
@@ -108,6 +114,14 @@ struct TrackBatchArgs {
     const double* det_xyah;          // [n_det][4]
     const int* det_featrow;          // [n_det] row of `feat`
     const float* feat;               // [rows][512] embeddings of the batch
+    TrackDotPlan* dot_plans;         // [n_wg], written by track_plan_kernel
+    float* dot_arena; long long dot_arena_floats;
+    int* row_src; int row_src_cap;   // per old table row: slot * budget_cap + ring position
+    int* gal_row;                    // [max_tracks][budget_cap]: table row of every gallery ring entry (valid during a batch)
+    float* nfeat;                    // [n_det][512] normalised detection features (what a gallery write stores)
+    float* det_ss;                   // [n_det] |feature|^2
+    int* dot_ctl;                    // [0..1] arena cursor (long long), [2] row_src cursor, [3] tile total, [4] tile cursor
+    int n_det_total;
     long long* rows;                 // [rows_cap][6] output arena: x1,y1,x2,y2,id,label
     int rows_cap;
     int* row_cursor;

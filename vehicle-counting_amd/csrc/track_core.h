@@ -45,6 +45,14 @@ VC_HD void wave_sync() {
 VC_HD int imin(int a, int b) { return a < b ? a : b; }
 VC_HD int imax(int a, int b) { return a > b ? a : b; }
 
+VC_HD unsigned long long wave_or(Lanes L, unsigned long long x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 1; o < 64; o <<= 1) x |= __shfl_xor(x, o);
+#endif
+    (void)L;
+    return x;
+}
+
 VC_HD int wave_max(Lanes L, int x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     for (int o = 1; o < 64; o <<= 1) x = imax(x, __shfl_xor(x, o));
@@ -281,12 +289,43 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
     int* other = w.un_cols;
     int n_left = D;
     n_match = 0;
-    // matching_cascade: level = time_since_update - 1, most recently seen tracks first (levels above the oldest track are empty)
-    for (int level = 0; level < h.max_age && level < max_tsu; ++level) {
+    // matching_cascade: level = time_since_update - 1, most recently seen tracks first.  Only the levels that hold a track are
+    // visited (a 64-bit presence mask for the first 64 levels, a plain scan above).
+    unsigned long long lm = 0;
+    for (int q = L.lane; q < n_conf; q += L.n) { const int lv = w.tsu[w.confirmed[q]] - 1; if (lv >= 0 && lv < 64) lm |= 1ull << lv; }
+    const unsigned long long level_mask = wave_or(L, lm);
+    const int n_levels = imin(h.max_age, max_tsu);
+    for (int level = 0; level < n_levels; ++level) {
         if (n_left == 0) break;
+        if (level < 64 && !((level_mask >> level) & 1ull)) continue;
         const int nl = compact(L, n_conf, [&](int q) { return w.tsu[w.confirmed[q]] == 1 + level; }, [&](int pos, int q) { w.rows[pos] = w.confirmed[q]; });
         if (nl == 0) continue;
         wave_sync();
+        if (nl == 1 || n_left == 1) {
+            // One track in the level, or one detection left: the assignment is the minimum of a vector (smallest index among equal
+            // minima, lap_solve), and min_cost_matching's list handling reduces to removing the column when the pair is accepted
+            // or moving it to the END of the list when it is rejected (linear_assignment.py:69-76 appends rejected pairs last).
+            const int n = nl == 1 ? n_left : nl;
+            Best b = {(double)INFINITY, 0, INT_MAX};
+            for (int e = L.lane; e < n; e += L.n) {
+                const int t = nl == 1 ? w.rows[0] : w.rows[e], d = nl == 1 ? left[e] : left[0];
+                const double v = cost_app[(size_t)t * D + d];
+                const Best x = {v > h.max_dist ? h.max_dist + 1e-5 : v, 0, e};
+                if (better(x, b)) b = x;
+            }
+            b = wave_best(L, b);
+            const bool accepted = !(b.v > h.max_dist);
+            const int t = nl == 1 ? w.rows[0] : w.rows[b.it];
+            const int ci = nl == 1 ? b.it : 0, col = left[ci];
+            for (int e = L.lane; e < n_left; e += L.n)
+                if (e != ci) other[e < ci ? e : e - 1] = left[e];
+            if (!accepted && L.lane == 0) other[n_left - 1] = col;
+            if (accepted && L.lane == 0) { w.match_t[n_match] = t; w.match_d[n_match] = col; w.matched[t] = 1; }
+            if (accepted) { ++n_match; --n_left; }
+            int* sw = left; left = other; other = sw;
+            wave_sync();
+            continue;
+        }
         const int m0 = n_match;
         int n_ur = 0, n_uc = 0;
         min_cost_matching(L, w, w.rows, nl, left, n_left, cost_app, D, h.max_dist, cbuf, tbuf, n_match, w.un_rows, n_ur, other, n_uc, err);

@@ -122,7 +122,7 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
                                                    const double* det_xyah, double* out, TrackShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
-    const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
+    const int S = jb.gal_count, D = jb.det_n;
     const double* m = tp.mean + (size_t)jb.slot * 8;
     const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     for (int d0 = 0; d0 < D; d0 += 16) {
@@ -137,14 +137,13 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
         const float* fptr = feat + (size_t)sh.featrow[col] * VC_FEAT_DIM + kq * 4;
         float best = -INFINITY, ss = 0.f;
         for (int st = wave; st * 16 < S; st += 4) {
-            // gallery layout [k / 4][sample][4] (gallery_store_wave): 16 consecutive samples of one k-chunk are 256 contiguous bytes
-            const float* gptr = gal + ((size_t)kq * SC + min(st * 16 + col, S - 1)) * 4;
+            const float* gptr = gal + (size_t)min(st * 16 + col, S - 1) * VC_FEAT_DIM + kq * 4;
             // four independent accumulators (k mod 4 chunks): a 32-deep MFMA dependency chain instead of 128
             f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
             float s2 = 0.f;
 #pragma unroll 8
             for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
-                const float4 a = *(const float4*)(gptr + (size_t)k0 * SC), b = *(const float4*)(fptr + k0);
+                const float4 a = *(const float4*)(gptr + k0), b = *(const float4*)(fptr + k0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc2, 0, 0, 0);
@@ -184,9 +183,9 @@ __device__ __forceinline__ void appearance_row_dev(const TrackPool& tp, const Co
 // (acc0 + acc1) + (acc2 + acc3), and |f|^2 is built from the same four partial sums as above: bit-identical to appearance_row_dev.
 __device__ __forceinline__ void appearance_row_wave(const TrackPool& tp, const CostJob& jb, const float* feat, const int* det_feat_row,
                                                     const double* det_xyah, double* out, int lane) {
-    const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
+    const int S = jb.gal_count, D = jb.det_n;
     const double* m = tp.mean + (size_t)jb.slot * 8;
-    const float* gal = tp.gallery + (size_t)jb.slot * SC * VC_FEAT_DIM;
+    const float* gal = tp.gallery + (size_t)jb.slot * tp.budget_cap * VC_FEAT_DIM;
     double Lc[16];
     {   // the gate's Cholesky factor depends on the track only (fp64, ~100 dependent operations): once, not per detection group
         double Sg[16];
@@ -201,14 +200,13 @@ __device__ __forceinline__ void appearance_row_wave(const TrackPool& tp, const C
         const float* fb = feat + (size_t)det_feat_row[dB] * VC_FEAT_DIM;
         float bestA = -INFINITY, bestB = -INFINITY, ssA = 0.f, ssB = 0.f;
         for (int s0 = 0; s0 < S; s0 += 64) {
-            // gallery layout [k / 4][sample][4]: the 64 lanes read 64 consecutive samples of one k-chunk = 1 KiB contiguous
-            const float* gp = gal + (size_t)min(s0 + lane, S - 1) * 4;
+            const float* gp = gal + (size_t)min(s0 + lane, S - 1) * VC_FEAT_DIM;
             f32x4_t A0 = {0.f, 0.f, 0.f, 0.f}, A1 = A0, A2 = A0, A3 = A0, B0 = A0, B1 = A0, B2 = A0, B3 = A0;
             float qa[4] = {0.f, 0.f, 0.f, 0.f}, qb[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c0 = 0; c0 < VC_FEAT_DIM / 4; c0 += 4) {
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) {
-                    const float4 a = *(const float4*)(gp + (size_t)(c0 + kq) * SC * 4);
+                    const float4 a = *(const float4*)(gp + (c0 + kq) * 4);
                     const float4 b = *(const float4*)(fa + (c0 + kq) * 4);
                     A0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, A0, 0, 0, 0);
                     A1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, A1, 0, 0, 0);
@@ -246,16 +244,148 @@ __device__ __forceinline__ void appearance_row_wave(const TrackPool& tp, const C
 }
 
 // gallery row = feature / |feature|_2 (nn_matching.py:45-47 normalises at distance time; the result is the same vector).
-// Layout of a slot's gallery: [k / 4][sample position][4 floats] -- a k-chunk of all samples is contiguous, which is how both
-// appearance kernels read it (their lanes are samples).  One wave: lane l holds chunks l and 64 + l of the feature.
-__device__ __forceinline__ void gallery_store_wave(float* slot_gallery, int pos, int SC, const float* src, int lane) {
+// One wave: lane l holds elements [4l, 4l+4) and [256 + 4l, 256 + 4l + 4).  Returns |feature|^2.
+__device__ __forceinline__ float gallery_store_wave(float* dst, const float* src, int lane) {
     const float4 a = ((const float4*)src)[lane], b = ((const float4*)src)[64 + lane];
     float ss = (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float nrm = sqrtf(ss);
-    *(float4*)(slot_gallery + ((size_t)lane * SC + pos) * 4) = make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm);
-    *(float4*)(slot_gallery + ((size_t)(64 + lane) * SC + pos) * 4) = make_float4(b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm);
+    ((float4*)dst)[lane] = make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm);
+    ((float4*)dst)[64 + lane] = make_float4(b.x / nrm, b.y / nrm, b.z / nrm, b.w / nrm);
+    return ss;
+}
+
+// ---- appearance dots, hoisted out of the sequential loop (TrackDotPlan in kernels.h) ----------------------------------------------
+// plan: one workgroup per tracker of the batch.  Numbers the samples the tracker holds now (track order, ring position) as table
+// rows, records the row of every ring entry (gal_row) and the entry of every row (row_src), reserves the table in the arena.
+__global__ __launch_bounds__(256) void track_plan_kernel(const TrackBatchArgs a) {
+    __shared__ int s_cnt[TC_HARD_CAP];
+    __shared__ int s_base[TC_HARD_CAP + 1];
+    __shared__ TrackDotPlan s_dp;
+    const TrackWgPlan plan = a.plans[blockIdx.x];
+    const TrackerHdr* hdr = a.hdrs + plan.tracker;
+    const int* list = a.lists + (size_t)plan.tracker * a.list_cap;
+    const int T = min(hdr->n_tracks, (int)TC_HARD_CAP), SC = a.pool.budget_cap;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) s_cnt[t] = min(a.recs[list[t]].gal_count, SC);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                  // T <= 512 and a batch has one plan pass: a serial prefix sum is fine
+        int acc = 0;
+        for (int t = 0; t < T; ++t) { s_base[t] = acc; acc += s_cnt[t]; }
+        s_base[T] = acc;
+        TrackDotPlan dp{};
+        dp.n_old_rows = acc; dp.n_dets = plan.det_n;
+        const long long rows = (long long)acc + plan.det_n, need = rows * plan.det_n;
+        dp.det_tiles = (plan.det_n + 15) / 16;
+        dp.tiles = (int)((rows + 15) / 16) * dp.det_tiles;
+        dp.use_table = 0;
+        if (plan.det_n > 0 && need < (1ll << 31)) {
+            const unsigned long long off = __hip_atomic_fetch_add((unsigned long long*)a.dot_ctl, (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int roff = __hip_atomic_fetch_add(a.dot_ctl + 2, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((long long)off + need <= a.dot_arena_floats && roff + acc <= a.row_src_cap) {
+                dp.use_table = 1; dp.table_off = (long long)off; dp.row_src_off = roff;
+                dp.tile_begin = __hip_atomic_fetch_add(a.dot_ctl + 3, dp.tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        s_dp = dp;
+        a.dot_plans[blockIdx.x] = dp;
+    }
+    __syncthreads();
+    if (!s_dp.use_table) return;                             // no room (or nothing to score): the batch kernel computes the rows itself
+    for (int t = 0; t < T; ++t) {
+        const int slot = list[t], n = s_cnt[t], base = s_base[t];
+        for (int pos = threadIdx.x; pos < n; pos += blockDim.x) {
+            a.gal_row[(size_t)slot * SC + pos] = base + pos;
+            a.row_src[s_dp.row_src_off + base + pos] = slot * SC + pos;
+        }
+    }
+}
+
+// norm: one wave per detection of the batch: the normalised feature a gallery write would store, and |feature|^2
+__global__ __launch_bounds__(256) void track_norm_kernel(const TrackBatchArgs a) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= a.n_det_total) return;
+    const float ss = gallery_store_wave(a.nfeat + (size_t)g * VC_FEAT_DIM, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+    if (lane == 0) a.det_ss[g] = ss;
+}
+
+// dots: persistent waves pull 16 x 16 tiles (rows x detections) of all trackers' tables; one v_mfma_f32_16x16x4_f32 chain per
+// tile exactly as in appearance_row_dev (four accumulators by k mod 4), so a table entry equals what that function computes.
+__global__ __launch_bounds__(256) void track_dots_kernel(const TrackBatchArgs a, int n_wg) {
+    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+    const int total = a.dot_ctl[3];
+    for (;;) {
+        int x = 0;
+        if (lane == 0) x = __hip_atomic_fetch_add(a.dot_ctl + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = __shfl(x, 0);
+        if (x >= total) return;
+        int p = 0;
+        for (; p < n_wg; ++p) {                                           // wave-uniform search (n_wg <= a few hundred, L2-resident)
+            const TrackDotPlan& q = a.dot_plans[p];
+            if (q.use_table && x >= q.tile_begin && x < q.tile_begin + q.tiles) break;
+        }
+        if (p == n_wg) continue;
+        const TrackDotPlan dp = a.dot_plans[p];
+        const TrackWgPlan plan = a.plans[p];
+        const int local = x - dp.tile_begin, rt = local / dp.det_tiles, dt = local - rt * dp.det_tiles;
+        const int rows = dp.n_old_rows + dp.n_dets, row0 = rt * 16, d0 = dt * 16;
+        const int r = min(row0 + col, rows - 1), d = min(d0 + col, dp.n_dets - 1);
+        const float* aptr = (r < dp.n_old_rows ? a.pool.gallery + (size_t)a.row_src[dp.row_src_off + r] * VC_FEAT_DIM
+                                                : a.nfeat + (size_t)(plan.det_begin + r - dp.n_old_rows) * VC_FEAT_DIM) + kq * 4;
+        const float* bptr = a.feat + (size_t)a.det_featrow[plan.det_begin + d] * VC_FEAT_DIM + kq * 4;
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll 8
+        for (int k0 = 0; k0 < VC_FEAT_DIM; k0 += 16) {
+            const float4 av = *(const float4*)(aptr + k0), bv = *(const float4*)(bptr + k0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc3, 0, 0, 0);
+        }
+        const f32x4_t acc = (acc0 + acc1) + (acc2 + acc3);                // acc[i] = <row row0 + kq*4 + i, detection d0 + col>
+        float* tab = a.dot_arena + dp.table_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = row0 + kq * 4 + i;
+            if (rr < rows && d0 + col < dp.n_dets) tab[(size_t)rr * dp.n_dets + d0 + col] = acc[i];
+        }
+    }
+}
+
+// One wave per track: the gated appearance row from the precomputed table.  Lane = detection (coalesced reads of a table row),
+// loop over the track's ring entries; cost = 1 - max_s <g_s, f_d> / |f_d|.
+__device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, const TrackDotPlan& dp, const CostJob& jb, int det_local0,
+                                                     double* out, int lane) {
+    const TrackPool& tp = a.pool;
+    const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
+    const double* m = tp.mean + (size_t)jb.slot * 8;
+    const float* tab = a.dot_arena + dp.table_off;
+    double Lc[16];
+    {
+        double Sg[16];
+        project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
+        chol4(Sg, Lc);
+    }
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        const bool ok = d < D;
+        float best = -INFINITY;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int my = s0 + lane < S ? a.gal_row[(size_t)jb.slot * SC + s0 + lane] : 0;
+            const int ns = min(64, S - s0);
+#pragma unroll 4
+            for (int s = 0; s < ns; ++s) {
+                const int rid = __shfl(my, s);
+                if (ok) best = fmaxf(best, tab[(size_t)rid * dp.n_dets + det_local0 + d]);
+            }
+        }
+        if (ok) {
+            const int g = jb.det_off + d;
+            const float cosv = best * (1.0f / sqrtf(a.det_ss[g]));
+            const double g2 = maha4(m, Lc, a.det_xyah + (size_t)g * 4);
+            out[jb.out_off + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+        }
+    }
 }
 
 // ---- slot pool: during a kernel slots are only TAKEN from the free stack (filled before the launch) and freed slots are only
@@ -289,6 +419,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
     StepWork w_lds, w_glb;
     step_work_carve(w_lds, track_dyn_lds, a.cap);
     const TrackWgPlan plan = a.plans[blockIdx.x];
+    const TrackDotPlan dp = a.dot_plans[blockIdx.x];
     TrackerHdr* hdr = a.hdrs + plan.tracker;
     int* list = a.lists + (size_t)plan.tracker * a.list_cap;
     char* wg_scratch = (char*)a.scratch + (size_t)blockIdx.x * a.scratch_per_wg;
@@ -335,18 +466,21 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
         }
         __syncthreads();
         VC_TTS(1);
-        if (D > 0 && D <= VC_SMALL_D) {
-            // few detections (the usual frame): one wave per track, no workgroup barriers
+        if (D > 0 && (dp.use_table || D <= VC_SMALL_D)) {
+            // one wave per track, no workgroup barriers: rows from the precomputed dot table (the normal case), or computed here
+            // for a few detections when the table did not fit the arena
             for (int t = wave; t < T; t += 4) {
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
+                    if (dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane);
+                    else appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
                 }
-                if (!(st == CONFIRMED && tsu != 1) && lane < D) {
+                if (!(st == CONFIRMED && tsu != 1)) {
                     double b[4];
                     mean_to_tlwh(tp.mean + (size_t)slot * 8, b);
-                    cost_iou[(size_t)t * D + lane] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + lane) * 4);
+                    for (int d = lane; d < D; d += 64)
+                        cost_iou[(size_t)t * D + d] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + d) * 4);
                 }
             }
         } else if (D > 0) {
@@ -391,11 +525,17 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             if (k < n_match) {                                           // Track.update (track.py:126-145)
                 const int t = w.match_t[k], g = tk.det_off + w.match_d[k], slot = w.slot[t];
                 kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave]);
-                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, w.galh[t], tp.budget_cap, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+                float* dst = tp.gallery + ((size_t)slot * tp.budget_cap + w.galh[t]) * VC_FEAT_DIM;
+                ((float4*)dst)[lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[lane];              // the normalised feature (track_norm_kernel)
+                ((float4*)dst)[64 + lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[64 + lane];
+                if (lane == 0) a.gal_row[(size_t)slot * tp.budget_cap + w.galh[t]] = dp.n_old_rows + g - plan.det_begin;
             } else {                                                     // _initiate_track (tracker.py:133-139)
                 const int i = k - n_match, g = tk.det_off + newdets[i], slot = w.newslot[i];
                 kalman_initiate_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane);
-                gallery_store_wave(tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM, 0, tp.budget_cap, a.feat + (size_t)a.det_featrow[g] * VC_FEAT_DIM, lane);
+                float* dst = tp.gallery + (size_t)slot * tp.budget_cap * VC_FEAT_DIM;
+                ((float4*)dst)[lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[lane];
+                ((float4*)dst)[64 + lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[64 + lane];
+                if (lane == 0) a.gal_row[(size_t)slot * tp.budget_cap] = dp.n_old_rows + g - plan.det_begin;
             }
         }
         __syncthreads();
@@ -446,6 +586,12 @@ int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
     const size_t lds = step_work_bytes(a.cap);
     VC_CHECK(a.cap % 8 == 0 && a.cap <= TC_HARD_CAP && lds <= 64 * 1024 - 4096, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
     VC_CHECK(a.scratch_per_wg >= track_scratch_per_wg(), VC_ERR_ARG, "tracker scratch too small");
+    if (a.n_det_total > 0) {
+        hipLaunchKernelGGL(track_plan_kernel, dim3(n_wg), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(track_norm_kernel, dim3((a.n_det_total + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(track_dots_kernel, dim3(std::min(2048, std::max(64, a.n_det_total))), dim3(256), 0, s, a, n_wg);
+        VC_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(track_batch_kernel, dim3(n_wg), dim3(256), lds, s, a);
     VC_HIP(hipGetLastError());
     hipLaunchKernelGGL(merge_free_kernel, dim3(1), dim3(256), 0, s, a.free_top, a.free_stack, a.freed_count, a.freed);
@@ -490,7 +636,7 @@ int launch_appearance_cost(const TrackPool& tp, const CostJob* jobs, int njobs, 
 
 __global__ __launch_bounds__(64) void kat_gallery_write_kernel(TrackPool tp, const int* __restrict__ sps, const float* __restrict__ feat) {
     const int* e = sps + (size_t)blockIdx.x * 3;
-    gallery_store_wave(tp.gallery + (size_t)e[0] * tp.budget_cap * VC_FEAT_DIM, e[1], tp.budget_cap, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x);
+    gallery_store_wave(tp.gallery + ((size_t)e[0] * tp.budget_cap + e[1]) * VC_FEAT_DIM, feat + (size_t)e[2] * VC_FEAT_DIM, threadIdx.x);
 }
 
 int launch_gallery_write(TrackPool& tp, const int* slot_pos_src, int n, const float* feat, hipStream_t s) {

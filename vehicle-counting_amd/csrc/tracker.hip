@@ -99,6 +99,13 @@ int tracker_init_pool(vc_engine* e) {
     VC_HIP(hipMemcpy(e->d_free_stack, st.data(), T * sizeof(int), hipMemcpyHostToDevice));
     const int ctl[2] = {(int)T, 0};
     VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(ctl), hipMemcpyHostToDevice));
+    // hoisted appearance dots (track_kernels.hip): table arena, row bookkeeping
+    e->dot_arena_floats = getenv("VC_DOT_ARENA_MB") ? (size_t)atol(getenv("VC_DOT_ARENA_MB")) * 262144 : (size_t)64 << 20;   // 256 MB by default
+    VC_TRY(dev_alloc(e, (void**)&e->d_dot_arena, e->dot_arena_floats * sizeof(float)));
+    e->row_src_cap = (int)std::min<size_t>(T * S, (size_t)1 << 24);
+    VC_TRY(dev_alloc(e, (void**)&e->d_row_src, (size_t)e->row_src_cap * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_gal_row, T * S * sizeof(int)));
+    VC_TRY(dev_alloc(e, (void**)&e->d_dot_ctl, 64));
     e->det_cap = std::max(e->cfg.max_det * 2, 1024);
     VC_TRY(dev_alloc(e, (void**)&e->d_feat_in, (size_t)e->det_cap * VC_FEAT_DIM * sizeof(float)));
     for (TrackStage& s : e->tstage) {
@@ -150,37 +157,45 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
                   int rows_cap, hipEvent_t wait) {
     TrackStage& s = e->tstage[st];
     VC_CHECK(!s.busy, VC_ERR_STATE, "tracker staging slot %d is still in flight", st);
-    // tasks in (frame, class) order -- the order rows are handed back in -- and the detection arrays
+    // tasks in (frame, class) order -- the order rows are handed back in
     s.tasks.clear(); s.tracker_dets.clear(); s.last_task_of.clear();
-    int n_dets = 0;
+    std::vector<const FrameClassDets*> src;
     for (size_t f = 0; f < frames.size(); ++f)
         for (const FrameClassDets& g : frames[f]) {
             VC_CHECK(g.tracker >= 0 && g.tracker < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", g.tracker);
-            s.tasks.push_back(TrackTaskHost{g.tracker, g.label, (int)f, n_dets, (int)g.dets.conf.size()});
-            n_dets += (int)g.dets.conf.size();
+            s.tasks.push_back(TrackTaskHost{g.tracker, g.label, (int)f, 0, (int)g.dets.conf.size()});
+            src.push_back(&g);
         }
     const int n_tasks = (int)s.tasks.size();
-    s.n_tasks = n_tasks; s.n_dets = n_dets; s.rows_cap = rows_cap; s.b = (int)frames.size(); s.W = W; s.H = H; s.n_wg = 0;
+    s.n_tasks = n_tasks; s.rows_cap = rows_cap; s.b = (int)frames.size(); s.W = W; s.H = H; s.n_wg = 0; s.n_dets = 0;
     if (n_tasks == 0) { s.busy = true; VC_HIP(hipEventRecord(s.done, e->stream)); return VC_OK; }
-    // device order: grouped by tracker, frames ascending inside a group (stable sort of the frame-major list)
+    // device order: grouped by tracker, frames ascending inside a group (stable sort of the frame-major list); the detection arrays
+    // follow the same order, so every tracker's detections of the batch are one contiguous range
     std::vector<int> order(n_tasks);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s.tasks[a].tracker < s.tasks[b].tracker; });
     s.dev_index.assign(n_tasks, 0);
     for (int k = 0; k < n_tasks; ++k) s.dev_index[order[k]] = k;
     std::vector<TrackWgPlan> plans;
-    int need = 8;
+    int need = 8, n_dets = 0;
     for (int k = 0; k < n_tasks;) {
         const int tr = s.tasks[order[k]].tracker;
         int k1 = k, dets = 0, dmax = 0;
-        while (k1 < n_tasks && s.tasks[order[k1]].tracker == tr) { dets += s.tasks[order[k1]].det_n; dmax = std::max(dmax, s.tasks[order[k1]].det_n); ++k1; }
-        plans.push_back(TrackWgPlan{tr, k, k1, 0});
+        const int det_begin = n_dets;
+        while (k1 < n_tasks && s.tasks[order[k1]].tracker == tr) {
+            TrackTaskHost& t = s.tasks[order[k1]];
+            t.det_off = n_dets; n_dets += t.det_n;
+            dets += t.det_n; dmax = std::max(dmax, t.det_n);
+            ++k1;
+        }
+        plans.push_back(TrackWgPlan{tr, k, k1, det_begin, dets, 0, 0, 0});
         // LDS capacity from the tracker's recent size (the kernel falls back to global-memory work arrays for a larger step)
         need = std::max(need, 2 * e->trackers[tr]->known_tracks + 2 * dmax + 16);
         s.tracker_dets.emplace_back(tr, dets);
         s.last_task_of.push_back(k1 - 1);
         k = k1;
     }
+    s.n_dets = n_dets;
     int cap = 32;
     while (cap < need && cap < TC_HARD_CAP) cap *= 2;
     const int n_wg = (int)plans.size();
@@ -205,16 +220,28 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         double* tl = (double*)(s.h_in + o_tlwh);
         double* xy = (double*)(s.h_in + o_xyah);
         int* fr = (int*)(s.h_in + o_frow);
-        int g = 0;
-        for (const auto& fv : frames)
-            for (const FrameClassDets& c : fv)
-                for (size_t i = 0; i < c.dets.conf.size(); ++i, ++g) {
-                    const double* t = &c.dets.tlwh[i * 4];
-                    memcpy(tl + (size_t)g * 4, t, 32);
-                    double* o = xy + (size_t)g * 4;                           // sort/detection.py:42-50 to_xyah
-                    o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
-                    fr[g] = c.dets.feat_rows[i];
-                }
+        for (int k = 0; k < n_tasks; ++k) {
+            const FrameClassDets& c = *src[order[k]];
+            int g = s.tasks[order[k]].det_off;
+            for (size_t i = 0; i < c.dets.conf.size(); ++i, ++g) {
+                const double* t = &c.dets.tlwh[i * 4];
+                memcpy(tl + (size_t)g * 4, t, 32);
+                double* o = xy + (size_t)g * 4;                           // sort/detection.py:42-50 to_xyah
+                o[0] = t[0] + t[2] / 2; o[1] = t[1] + t[3] / 2; o[2] = t[2] / t[3]; o[3] = t[3];
+                fr[g] = c.dets.feat_rows[i];
+            }
+        }
+    }
+    // buffers of the hoisted appearance dots (engine-wide: the tracker stream runs one batch at a time)
+    if ((size_t)n_wg > e->dot_plans_cap || (size_t)n_dets > e->nfeat_cap) {
+        VC_TRY(track_idle(e));
+        VC_HIP(hipStreamSynchronize(e->stream));
+        if ((size_t)n_wg > e->dot_plans_cap) { e->dot_plans_cap = (size_t)n_wg * 2; VC_TRY(dev_alloc(e, (void**)&e->d_dot_plans, e->dot_plans_cap * sizeof(TrackDotPlan))); }
+        if ((size_t)n_dets > e->nfeat_cap) {
+            e->nfeat_cap = (size_t)n_dets * 3 / 2 + 64;
+            VC_TRY(dev_alloc(e, (void**)&e->d_nfeat, e->nfeat_cap * VC_FEAT_DIM * sizeof(float)));
+            VC_TRY(dev_alloc(e, (void**)&e->d_det_ss, e->nfeat_cap * sizeof(float)));
+        }
     }
     const size_t scratch = (size_t)n_wg * track_scratch_per_wg();
     if (scratch > e->track_scratch_bytes) {
@@ -228,6 +255,8 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     if (wait) VC_HIP(hipStreamWaitEvent(ts, wait, 0));
     VC_HIP(hipMemcpyAsync(s.d_in, s.h_in, p, hipMemcpyHostToDevice, ts));
     VC_HIP(hipMemsetAsync(s.d_cursor, 0, 64, ts));           // [0] row cursor, [4..6] status
+    VC_HIP(hipMemsetAsync(e->d_dot_ctl, 0, 64, ts));
+    VC_HIP(hipMemsetAsync(e->d_dot_plans, 0, (size_t)n_wg * sizeof(TrackDotPlan), ts));
     TrackBatchArgs a{};
     a.pool = e->pool;
     a.hdrs = e->d_hdrs; a.lists = e->d_lists; a.list_cap = e->list_cap; a.recs = e->d_recs;
@@ -235,6 +264,9 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.plans = (const TrackWgPlan*)(s.d_in + o_plans); a.tasks = (const TrackTask*)(s.d_in + o_tasks);
     a.det_tlwh = (const double*)(s.d_in + o_tlwh); a.det_xyah = (const double*)(s.d_in + o_xyah); a.det_featrow = (const int*)(s.d_in + o_frow);
     a.feat = d_feat;
+    a.dot_plans = e->d_dot_plans; a.dot_arena = e->d_dot_arena; a.dot_arena_floats = (long long)e->dot_arena_floats;
+    a.row_src = e->d_row_src; a.row_src_cap = e->row_src_cap; a.gal_row = e->d_gal_row; a.nfeat = e->d_nfeat; a.det_ss = e->d_det_ss;
+    a.dot_ctl = e->d_dot_ctl; a.n_det_total = n_dets;
     a.rows = (long long*)(s.hd_out + ol.rows); a.rows_cap = rows_cap; a.row_cursor = s.d_cursor;
     a.task_row_off = (int*)(s.hd_out + ol.row_off); a.task_row_n = (int*)(s.hd_out + ol.row_n);
     a.task_ntracks = (int*)(s.hd_out + ol.ntracks); a.task_T = (int*)(s.hd_out + ol.tT);
@@ -570,14 +602,7 @@ int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* siz
         VC_HIP(hipMemcpy(t.cov, e->pool.cov + (size_t)slot * 64, sizeof(t.cov), hipMemcpyDeviceToHost));
         memcpy(o, &t, sizeof(t)); o += sizeof(t);
         const size_t rows = (size_t)std::min(tr.gal_count, tp.nn_budget);
-        if (rows) {                                              // device layout [k / 4][sample][4] -> rows of 512 floats
-            const size_t SC = e->pool.budget_cap;
-            std::vector<float> blk(SC * VC_FEAT_DIM);
-            VC_HIP(hipMemcpy(blk.data(), e->pool.gallery + (size_t)slot * SC * VC_FEAT_DIM, blk.size() * sizeof(float), hipMemcpyDeviceToHost));
-            float* dst = (float*)o;
-            for (size_t r = 0; r < rows; ++r)
-                for (size_t c = 0; c < VC_FEAT_DIM / 4; ++c) memcpy(dst + r * VC_FEAT_DIM + c * 4, &blk[(c * SC + r) * 4], 16);
-        }
+        if (rows) VC_HIP(hipMemcpy(o, e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost));
         o += rows * VC_FEAT_DIM * sizeof(float);
     }
     return VC_OK;
@@ -629,14 +654,7 @@ int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
         VC_HIP(hipMemcpy(e->pool.mean + (size_t)slot * 8, t.mean, sizeof(t.mean), hipMemcpyHostToDevice));
         VC_HIP(hipMemcpy(e->pool.cov + (size_t)slot * 64, t.cov, sizeof(t.cov), hipMemcpyHostToDevice));
         const size_t rows = (size_t)t.gal_count;
-        if (rows) {                                              // rows of 512 floats -> device layout [k / 4][sample][4]
-            const size_t SC = e->pool.budget_cap;
-            std::vector<float> blk(SC * VC_FEAT_DIM, 0.f);
-            const float* src = (const float*)in;
-            for (size_t r = 0; r < rows; ++r)
-                for (size_t c = 0; c < VC_FEAT_DIM / 4; ++c) memcpy(&blk[(c * SC + r) * 4], src + r * VC_FEAT_DIM + c * 4, 16);
-            VC_HIP(hipMemcpy(e->pool.gallery + (size_t)slot * SC * VC_FEAT_DIM, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
-        }
+        if (rows) VC_HIP(hipMemcpy(e->pool.gallery + (size_t)slot * e->pool.budget_cap * VC_FEAT_DIM, in, rows * VC_FEAT_DIM * sizeof(float), hipMemcpyHostToDevice));
         in += rows * VC_FEAT_DIM * sizeof(float);
     }
     if (h.n_tracks) VC_HIP(hipMemcpy(e->d_lists + (size_t)id * e->list_cap, slots.data(), (size_t)h.n_tracks * sizeof(int), hipMemcpyHostToDevice));
