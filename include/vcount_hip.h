@@ -40,6 +40,8 @@ extern "C" {
 
 #define VC_PREC_BF16 0     /* bf16 activations/weights, fp32 accumulate (throughput mode) */
 #define VC_PREC_F32 1      /* fp32 everywhere (tight-parity mode) */
+#define VC_PREC_FP8 2      /* detector convs on the MX-scaled fp8 MFMA (OCP e4m3fn activations, per-channel-scaled e4m3fn weights,
+                              fp32 accumulate); the 3-channel stem, the Detect logits and the ReID net stay bf16 */
 
 #define VC_FEAT_DIM 512    /* networks/deepsort/deep/model.py: embedding width */
 #define VC_REID_SIZE 50    /* feature_extractor.py:18 */

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(_HERE, "libvcount_hip.so")   # override: A/B runs of two builds on one box
 
 VC_OK = 0
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_FP8 = 0, 1, 2
+PREC_ID = {"bf16": 0, "f32": 1, "fp8": 2}
 NET_YOLO, NET_REID = 0, 1
 FEAT_DIM = 512
 PROF_CONV, PROF_DETECT_AUX, PROF_REID_AUX, PROF_TRACK = 0, 1, 2, 3

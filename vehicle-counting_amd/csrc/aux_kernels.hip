@@ -321,7 +321,61 @@ __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
     }
 }
 
+// fp8 (e4m3fn) planes: max-pooling only selects, so it runs on an order-preserving integer key of the byte (sign-magnitude ->
+// biased unsigned) and stores the winner's byte; 4 channels per thread.
+__device__ __forceinline__ unsigned int fp8_key4(unsigned int v) {           // per byte: b ^ (b & 0x80 ? 0xff : 0x80)
+    const unsigned int neg = (v >> 7) & 0x01010101u;
+    return v ^ (0x80808080u | (neg * 0x7fu));
+}
+__device__ __forceinline__ unsigned int fp8_unkey4(unsigned int k) {        // inverse: key >= 0x80 was a positive byte (k ^ 0x80), else negative (k ^ 0xff)
+    const unsigned int pos = (k >> 7) & 0x01010101u;
+    return k ^ (0xffffffffu ^ (pos * 0x7fu));
+}
+__device__ __forceinline__ unsigned int umax4(unsigned int a, unsigned int b) {
+    unsigned int r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const unsigned int x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff; r |= (x > y ? x : y) << (8 * i); }
+    return r;
+}
+__global__ __launch_bounds__(256) void sppf_pool_fp8_kernel(View cat, int C) {
+    const int cv = C / 4;
+    const long total = (long)cat.B * cat.H * cat.W * cv;
+    char* base = (char*)cat.ptr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 4;
+        long pix = i / cv;
+        const int x = (int)(pix % cat.W);
+        const int y = (int)((pix / cat.W) % cat.H);
+        const int b = (int)(pix / ((long)cat.W * cat.H));
+        unsigned int m1 = 0, m2 = 0, m3 = 0;                              // key 0 is below every finite value's key
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= cat.H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= cat.W) continue;
+                const unsigned int k = fp8_key4(*(const unsigned int*)(base + (((size_t)b * cat.H + yy) * cat.W + xx) * cat.cs + cat.co + c));
+                const int r = max(abs(dx), abs(dy));
+                m3 = umax4(m3, k);
+                if (r <= 4) m2 = umax4(m2, k);
+                if (r <= 2) m1 = umax4(m1, k);
+            }
+        }
+        char* o = base + (((size_t)b * cat.H + y) * cat.W + x) * cat.cs + cat.co + c;
+        *(unsigned int*)(o + (size_t)C) = fp8_unkey4(m1);
+        *(unsigned int*)(o + (size_t)2 * C) = fp8_unkey4(m2);
+        *(unsigned int*)(o + (size_t)3 * C) = fp8_unkey4(m3);
+    }
+}
+
 int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
+    if (prec == PREC_FP8) {
+        VC_CHECK(C % 4 == 0 && cat.cs % 4 == 0 && cat.co % 4 == 0, VC_ERR_ARG, "sppf fp8: channel alignment");
+        const long total = (long)cat.B * cat.H * cat.W * (C / 4);
+        hipLaunchKernelGGL(sppf_pool_fp8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, cat, C);
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     const int n = prec == PREC_F32 ? 4 : 8;
     VC_CHECK(C % n == 0 && cat.cs % n == 0 && cat.co % n == 0, VC_ERR_ARG, "sppf: channel alignment");
     const int cw = prec == PREC_F32 ? 32 : 64;
@@ -370,7 +424,45 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(View src, View dst) {
     }
 }
 
+// bf16 -> fp8 (e4m3fn): 8 channels per thread
+__global__ __launch_bounds__(256) void bf16_to_fp8_kernel(View src, View dst, float inv_scale) {
+    const int cv = src.C / 8;
+    const long total = (long)src.B * src.H * src.W * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        const long pix = i / cv;
+        const uint4 t = *(const uint4*)((const char*)src.ptr + ((size_t)pix * src.cs + src.co + c) * 2);
+        const unsigned int w[4] = {t.x, t.y, t.z, t.w};
+        unsigned int o[2] = {0u, 0u};
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[2 * j] = __builtin_amdgcn_fmed3f(__uint_as_float(w[j] << 16) * inv_scale, -448.0f, 448.0f);
+            f[2 * j + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(w[j] & 0xffff0000u) * inv_scale, -448.0f, 448.0f);
+        }
+        o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0u, false); o[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], o[0], true);
+        o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0u, false); o[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], o[1], true);
+        *(uint2*)((char*)dst.ptr + (size_t)pix * dst.cs + dst.co + c) = make_uint2(o[0], o[1]);
+    }
+}
+
+int launch_bf16_to_fp8(const View& src, const View& dst, float inv_scale, hipStream_t s) {
+    VC_CHECK(src.C % 8 == 0 && src.cs % 8 == 0 && src.co % 8 == 0 && dst.cs % 8 == 0 && dst.co % 8 == 0, VC_ERR_ARG, "bf16 -> fp8: alignment");
+    const long total = (long)src.B * src.H * src.W * (src.C / 8);
+    hipLaunchKernelGGL(bf16_to_fp8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst, inv_scale);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s) {
+    if (prec == PREC_FP8) {
+        VC_CHECK(src.C % 16 == 0 && src.cs % 16 == 0 && src.co % 16 == 0 && dst.cs % 16 == 0 && dst.co % 16 == 0, VC_ERR_ARG, "upsample fp8: alignment");
+        VC_CHECK(dst.H == 2 * src.H && dst.W == 2 * src.W && dst.B == src.B, VC_ERR_ARG, "upsample: shape");
+        const long total = (long)dst.B * dst.H * dst.W * (src.C / 16);
+        hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, dst);
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     const int n = prec == PREC_F32 ? 4 : 8;
     VC_CHECK(src.C % n == 0 && src.cs % n == 0 && src.co % n == 0 && dst.cs % n == 0 && dst.co % n == 0, VC_ERR_ARG, "upsample: alignment");
     VC_CHECK(dst.H == 2 * src.H && dst.W == 2 * src.W && dst.B == src.B, VC_ERR_ARG, "upsample: shape");

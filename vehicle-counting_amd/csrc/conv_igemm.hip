@@ -160,6 +160,89 @@ __device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[
     }
 }
 
+// fp8 (OCP e4m3fn) epilogue of the MX-scaled path: value = acc * scale[channel] + bias[channel] with scale = weight scale x activation
+// scale (the block scales of the MFMA itself are 1), activation, residual (stored fp8, times the activation scale), then either
+// fp8 again (divide by the activation scale, clamp to +-448: the conversion does not saturate by itself, v_cvt_pk_fp8_f32) or,
+// for the Detect heads, the dequantised value as bf16.  Lane pairs (lane, lane ^ 16) exchange halves exactly as in
+// conv_epilogue_bf16, so fp8 stores are 8 bytes (8 channels of one pixel).  Preconditions: Cout, strides, offsets multiples of 8.
+template <int PT, int CT>
+__device__ __forceinline__ void conv_epilogue_fp8(const ConvP& p, f32x4 (&acc)[CT][PT], int mbase, int nbase, int frow) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res_mode != RES_NONE ? p.res : (const void*)p.bias), 0, 0x7ffffff0, 0x00020000);
+    float4 bias[CT], scl[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) {
+        const bool in = nbase + a * 16 < p.Cout;
+        bias[a] = in ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        scl[a] = in ? *(const float4*)(p.scale + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+    const float inv_s = p.inv_act_scale, rs = p.act_scale;
+#pragma unroll
+    for (int b = 0; b < PT; b += 2) {
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int n = nbase + a * 16;
+            const bool grp_ok = n < p.Cout;
+            unsigned int P[2];
+            u32x2 Q[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = mbase + (b + t) * 16 + frow;
+                float v[4] = {acc[a][b + t][0] * scl[a].x + bias[a].x, acc[a][b + t][1] * scl[a].y + bias[a].y,
+                              acc[a][b + t][2] * scl[a].z + bias[a].z, acc[a][b + t][3] * scl[a].w + bias[a].w};
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.res_mode != RES_NONE) {
+                    const unsigned int r = __builtin_amdgcn_raw_buffer_load_b32(rsrd, (grp_ok && m < p.M) ? m * p.res_cs + p.res_co + n : 0, 0, 0);
+                    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(r, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(r, true);
+                    rv[0] = lo[0] * rs; rv[1] = lo[1] * rs; rv[2] = hi[0] * rs; rv[3] = hi[1] * rs;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = v[j];
+                    if (p.res_mode == RES_BEFORE_ACT) x += rv[j];
+                    if (p.act == ACT_SILU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                    else if (p.act == ACT_RELU) x = x > 0.f ? x : 0.f;
+                    if (p.res_mode == RES_AFTER_ACT) x += rv[j];
+                    v[j] = x;
+                }
+                if (p.out_bf16) {
+                    Q[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * inv_s, -448.0f, 448.0f);
+                    unsigned int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0u, false);
+                    P[t] = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                }
+            }
+            if (p.out_bf16) {                                     // dequantised bf16 output (Detect logits): 8-byte stores per tile
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int m = mbase + (b + t) * 16 + frow;
+                    const bool ok = grp_ok && m < p.M;
+                    __builtin_amdgcn_raw_buffer_store_b64(Q[t], osrd, ok ? (m * p.out_cs + p.out_co + n) * 2 : (int)0x80000000u, 0, 0);
+                }
+                continue;
+            }
+            const u32x2 sx = __builtin_amdgcn_permlane16_swap(P[0], P[1], false, false);
+            const int m = mbase + (b + (odd ? 1 : 0)) * 16 + frow;
+            const int nn = odd ? n - 4 : n;
+            const bool ok = grp_ok && m < p.M;
+            const int off1 = m * p.out_cs + p.out_co + nn;
+            if (p.split == 0) {
+                __builtin_amdgcn_raw_buffer_store_b64(sx, osrd, ok ? off1 : (int)0x80000000u, 0, 0);
+            } else {
+                const bool second = nn >= p.split;
+                __builtin_amdgcn_raw_buffer_store_b64(sx, osrd, (ok && !second) ? off1 : (int)0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(sx, osrd2, (ok && second) ? m * p.out2_cs + p.out2_co + nn - p.split : (int)0x80000000u, 0, 0);
+            }
+        }
+    }
+}
+
 // Epilogue shared by the conv kernels: D[channel = (lane>>4)*4 + reg][pixel = lane&15] -> bias, activation, residual, bf16
 // pack, concat-slice / split-destination store.  mbase = first pixel of the wave's tile, nbase = this lane's first channel.
 template <int PT, int CT, bool F32>
@@ -254,9 +337,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
 // hardware answers with zeros (verified by the padded test cases); the per-row validity of all kh*kw taps is one 64-bit
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
-template <int BP, int BC, int WP, int WC, int KC, int NS, bool F32>
+template <int BP, int BC, int WP, int WC, int KC, int NS, int PR>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
 __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p) {
-    constexpr int ES = F32 ? 4 : 2;           // element size
+    constexpr bool F32 = PR == PREC_F32, FP8 = PR == PREC_FP8;
+    constexpr int ES = F32 ? 4 : FP8 ? 1 : 2; // element size
+    static_assert(!FP8 || KC == 8, "fp8: one 128-byte LDS row = one K = 128 MX-scaled MFMA step");
     constexpr int CH = 16 / ES;               // elements per 16-byte chunk
     constexpr int BK = KC * CH;               // K elements per tile
     constexpr int RPI = 64 / KC;              // tile rows covered by one wave-instruction
@@ -457,6 +542,37 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
         for (int kt = 0; kt < nk; ++kt) {
             VC_STAGE_NEXT(sbuf);                        // into the slot consumed last iteration (all waves passed its barrier)
             sbuf = sbuf + 1 == NS ? 0 : sbuf + 1;
+            if constexpr (FP8) {
+                // MX-scaled fp8 MFMA, K = 128 per instruction (twice the bf16 rate): a lane's 32 K-bytes are the chunks fch and 4 + fch of
+                // its LDS row -- the same two ds_read_b128 the bf16 halves issue; any K assignment works as long as both operands use
+                // the same one.  Block scales are 1 (E8M0 0x7f): per-channel weight scales are applied in the epilogue.
+                u32x4v xr[2][PT], wr[2][CT];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[h][i]) : "v"(boff + xfrag[h][i]) : "memory");
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wr[h][i]) : "v"(boff + wfrag[h][i]) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                typedef int i32x8 __attribute__((ext_vector_type(8)));
+                i32x8 xa[PT], wa[CT];
+#pragma unroll
+                for (int i = 0; i < PT; ++i) {
+                    asm volatile("" : "+v"(xr[0][i])); asm volatile("" : "+v"(xr[1][i]));
+                    xa[i] = (i32x8){(int)xr[0][i].x, (int)xr[0][i].y, (int)xr[0][i].z, (int)xr[0][i].w, (int)xr[1][i].x, (int)xr[1][i].y, (int)xr[1][i].z, (int)xr[1][i].w};
+                }
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    asm volatile("" : "+v"(wr[0][i])); asm volatile("" : "+v"(wr[1][i]));
+                    wa[i] = (i32x8){(int)wr[0][i].x, (int)wr[0][i].y, (int)wr[0][i].z, (int)wr[0][i].w, (int)wr[1][i].x, (int)wr[1][i].y, (int)wr[1][i].z, (int)wr[1][i].w};
+                }
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int b = 0; b < PT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa[a], xa[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            } else
 #pragma unroll
             for (int h = 0; h < KC / 4; ++h) {
                 u32x4v xr[PT], wr[CT];
@@ -488,7 +604,8 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             __builtin_amdgcn_s_barrier();
         }
         // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]; the next tile's first K tiles are already in flight
-        conv_epilogue<PT, CT, F32>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
+        if constexpr (FP8) conv_epilogue_fp8<PT, CT>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
+        else conv_epilogue<PT, CT, F32>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the K tiles issued past the last tile before the LDS is released
     VC_TS(3);
@@ -753,7 +870,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_direct_kernel(const ConvP p)
     }
 }
 
-int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : 64; }    // weights are padded to the widest K tile (KC = 8)
+int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : prec == PREC_FP8 ? 128 : 64; }    // weights are padded to the widest K tile (KC = 8)
 
 double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * (double)p.K; }
 
@@ -800,7 +917,7 @@ static int resident_workgroups(K kernel, int threads = 256) {
 template <int BP, int BC, int WP, int WC, int KC, int NS>
 static int launch_one(ConvP p, hipStream_t s) {
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
-    const int bk = KC * (p.prec == PREC_F32 ? 4 : 8);
+    const int bk = KC * (p.prec == PREC_F32 ? 4 : p.prec == PREC_FP8 ? 16 : 8);
     p.Kw = p.Kp;                              // weight row stride as packed
     p.Kp = (p.K + bk - 1) / bk * bk;          // K-loop extent: only the tiles that hold real taps
     p.ntiles = tiles;
@@ -812,21 +929,35 @@ static int launch_one(ConvP p, hipStream_t s) {
     // unchanged; 256 free slots cost 9 % of conv time).
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
     if (p.prec == PREC_F32) {
-        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, WP * WC * 64);
+        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, true>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+    } else if (p.prec == PREC_FP8) {
+        if constexpr (KC == 8 && (BP / WP / 16) % 2 == 0) {        // the fp8 epilogue pairs pixel tiles (PT even)
+            static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_FP8>, WP * WC * 64);
+            const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
+            const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+            launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_FP8>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+        } else {
+            return VC_ERR_ARG;                                       // quietly: the autotuner skips it (fp8 runs on the 128-byte-row tiles only)
+        }
     } else {
-        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, WP * WC * 64);
+        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, false>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     }
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
 
 static int conv_heuristic(const ConvP& p) {
+    if (p.prec == PREC_FP8) {                  // 128-byte-row tiles only (KC = 8, even pixel tiles per wave)
+        if (p.Cout <= 64) return 4;
+        const long t = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+        return t >= 512 ? 5 : 6;
+    }
     // narrow layers get tall pixel tiles; late (small-M) layers get small tiles so the grid still covers 256 CUs
     if (p.Cout <= 32) return 0;
     if (p.Cout <= 64) return 1;
@@ -914,7 +1045,10 @@ int launch_conv(const ConvP& p, hipStream_t s) {
 }
 
 int conv_check(const ConvP& p) {
-    const int ch = p.prec == PREC_F32 ? 4 : 8;
+    const int ch = p.prec == PREC_F32 ? 4 : p.prec == PREC_FP8 ? 16 : 8;
+    if (p.prec == PREC_FP8)
+        VC_CHECK(p.scale && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_co % 8 == 0 && (p.split == 0 || (p.split % 8 == 0 && p.out2_cs % 8 == 0 && p.out2_co % 8 == 0)) &&
+                 (p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_co % 4 == 0)), VC_ERR_ARG, "conv fp8: channel scales / 8-channel alignment of the outputs");
     VC_CHECK(p.Cin % ch == 0 && p.in_cs % ch == 0 && p.in_co % ch == 0, VC_ERR_ARG,
              "conv: input channels/stride/offset (%d,%d,%d) must be multiples of %d", p.Cin, p.in_cs, p.in_co, ch);
     VC_CHECK(p.out_cs % 4 == 0 && p.out_co % 4 == 0, VC_ERR_ARG, "conv: output stride/offset must be multiples of 4");
@@ -927,7 +1061,7 @@ int conv_check(const ConvP& p) {
     VC_CHECK((size_t)((p.Cout + 127) / 128 * 128) * p.Kp * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: weights exceed 2 GiB");
     VC_CHECK(p.kh * p.kw <= 40, VC_ERR_ARG, "conv: at most 40 taps (validity mask is 64 bits incl. K padding)");
     VC_CHECK(p.M < (1 << 24), VC_ERR_CAPACITY, "conv: more than 2^24 output pixels in one launch");
-    VC_CHECK((size_t)p.M * std::max(p.out_cs, std::max(p.res_cs, p.out2_cs)) * ((p.prec == PREC_F32 || p.out_f32) ? 4 : 2) < (1ull << 31),
+    VC_CHECK((size_t)p.M * std::max(p.out_cs, std::max(p.res_cs, p.out2_cs)) * ((p.prec == PREC_F32 || p.out_f32) ? 4 : (p.prec == PREC_FP8 && !p.out_bf16) ? 1 : 2) < (1ull << 31),
              VC_ERR_CAPACITY, "conv: output tensor exceeds 2 GiB (32-bit buffer offsets)");
     return VC_OK;
 }

@@ -22,12 +22,14 @@ struct ConvParam {
     bool hidden = false;             // internal (fused) parameters are not enumerated to the caller
     std::vector<float> w, b;         // host copies (OIHW, BN folded) until finalize()
     void* d_w = nullptr;             // packed [Cout_pad][Kp]
+    float* d_scale = nullptr;        // fp8: [Cout_pad] weight scale x activation scale
+    int prec = 0;                    // precision the parameter was packed in (the detector's fp8 mode keeps its stem in bf16)
     float* d_b = nullptr;            // [Cout_pad]
     int cin_eff = 0, K = 0, Kp = 0, cout_pad = 0;
 };
 
 struct Op {
-    enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL } kind;
+    enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL, TO_FP8 } kind;
     ConvP conv{};
     View a{}, b{};
     int C = 0;
@@ -82,7 +84,9 @@ struct TrackStage {
 
 struct vc_engine {
     vc_engine_config cfg{};
-    int prec = 0;
+    int prec = 0;                    // precision of the detector's convolutions (VC_PREC_*)
+    int aux_prec = 0;                // precision of everything else (= prec, or bf16 when prec is fp8)
+    float act_scale = 1.0f;          // fp8: real value = stored value x act_scale, one scale for all activations (e4m3 is a floating format)
     hipStream_t stream = nullptr;    // ReID + tracker
     hipStream_t dstream = nullptr;   // detector (runs ahead of the tracker on the next batch)
     hipStream_t rstream = nullptr;   // ReID of the next batch (stream path), concurrent with detector and tracker

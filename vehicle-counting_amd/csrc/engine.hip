@@ -55,9 +55,10 @@ ProfScope::~ProfScope() {
 // ------------------------------------------------------------------------------------------------ weights
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-static int pack_and_upload(vc_engine* e, ConvParam& p, int prec) {
+static int pack_and_upload(vc_engine* e, ConvParam& p, int prec, float act_scale = 1.0f) {
     VC_CHECK(p.set, VC_ERR_STATE, "parameter '%s' was never set", p.name.c_str());
-    const int ch = prec == PREC_F32 ? 4 : 8;
+    p.prec = prec;
+    const int ch = prec == PREC_F32 ? 4 : prec == PREC_FP8 ? 16 : 8;
     const int kt = conv_k_tile(prec);
     int kw_eff = p.kw;
     if (p.pair_stem) {                       // two 4-channel pixels per chunk: kernel becomes kh x kw/2 over 8 channels
@@ -87,6 +88,22 @@ static int pack_and_upload(vc_engine* e, ConvParam& p, int prec) {
     VC_TRY(dev_alloc(e, (void**)&p.d_b, bias.size() * sizeof(float)));
     if (prec == PREC_F32) {
         VC_HIP(hipMemcpy(p.d_w, packed.data(), nel * 4, hipMemcpyHostToDevice));
+    } else if (prec == PREC_FP8) {
+        // OCP e4m3fn weights with one scale per output channel (|w|max -> 448); the kernel multiplies the accumulator by
+        // weight scale x activation scale in its epilogue (the MFMA's own block scales stay 1)
+        std::vector<uint8_t> h(nel);
+        std::vector<float> sc(p.cout_pad, 0.f);
+        for (int n = 0; n < p.O; ++n) {
+            float amax = 0.f;
+            for (int k = 0; k < p.Kp; ++k) amax = std::max(amax, std::fabs(packed[(size_t)n * p.Kp + k]));
+            const float sw = amax > 0.f ? amax / 448.0f : 1.0f;
+            for (int k = 0; k < p.Kp; ++k) h[(size_t)n * p.Kp + k] = f32_to_e4m3(packed[(size_t)n * p.Kp + k] / sw);
+            sc[n] = sw * act_scale;
+        }
+        for (size_t i = (size_t)p.O * p.Kp; i < nel; ++i) h[i] = 0;
+        VC_HIP(hipMemcpy(p.d_w, h.data(), nel, hipMemcpyHostToDevice));
+        VC_TRY(dev_alloc(e, (void**)&p.d_scale, sc.size() * sizeof(float)));
+        VC_HIP(hipMemcpy(p.d_scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
     } else {
         std::vector<uint16_t> h(nel);
         for (size_t i = 0; i < nel; ++i) h[i] = f32_to_bf16(packed[i]);
@@ -105,7 +122,7 @@ static View mkview(const View& buf, int B, int H, int W, int C, int co) {
 
 static int alloc_buf(vc_engine* e, std::map<std::string, View>& m, const std::string& name, size_t pixels, int C, int es) {
     View v{};
-    v.cs = C; v.co = 0; v.C = C;
+    v.cs = C; v.co = 0; v.C = C; v.es = es;
     VC_TRY(dev_alloc(e, &v.ptr, pixels * C * es));
     m[name] = v;
     return VC_OK;
@@ -141,7 +158,8 @@ struct PlanBuilder {
         }
         c.Cout = cp.O; c.out_cs = out.cs; c.out_co = out.co;
         c.K = cp.K; c.Kp = cp.Kp;
-        c.act = act; c.res_mode = res_mode; c.out_f32 = out_f32 ? 1 : 0; c.prec = prec;
+        c.act = act; c.res_mode = res_mode; c.out_f32 = out_f32 ? 1 : 0; c.prec = cp.prec;
+        c.scale = cp.d_scale; c.act_scale = e->act_scale; c.inv_act_scale = 1.0f / e->act_scale; c.out_bf16 = 0;
         if (res) { c.res = res->ptr; c.res_cs = res->cs; c.res_co = res->co; }
         c.M = c.B * c.Ho * c.Wo;
         c.cfg = -1;
@@ -179,7 +197,7 @@ static void yolo_define(vc_engine* e) {
     Net& n = e->yolo;
     const int* c = e->ch;
     n.add("model.0.conv", c[0], 3, 6, 6);
-    n.params.back().pair_stem = (e->prec == PREC_BF16);
+    n.params.back().pair_stem = (e->aux_prec == PREC_BF16);       // the stem stays bf16 in the fp8 mode
     n.add("model.1.conv", c[1], c[0], 3, 3); yolo_c3_params(n, 2, c[1], c[1], e->rep[0]);
     n.add("model.3.conv", c[2], c[1], 3, 3); yolo_c3_params(n, 4, c[2], c[2], e->rep[1]);
     n.add("model.5.conv", c[3], c[2], 3, 3); yolo_c3_params(n, 6, c[3], c[3], e->rep[2]);
@@ -197,7 +215,7 @@ static void yolo_define(vc_engine* e) {
 }
 
 static int yolo_alloc(vc_engine* e) {
-    const int es = elem_size(e->prec);
+    const int es = elem_size(e->prec), aes = elem_size(e->aux_prec);
     const int S = round_up(e->cfg.img_size, 32);
     const size_t B = e->cfg.max_batch;
     auto px = [&](int stride) { return B * (size_t)(S / stride) * (S / stride); };
@@ -212,8 +230,9 @@ static int yolo_alloc(vc_engine* e) {
         VC_TRY(alloc_buf(e, m, p + ".cat", px(stride), 2 * h, es));
         return VC_OK;
     };
-    VC_TRY(alloc_buf(e, m, "in", px(1), 4, es));
-    VC_TRY(alloc_buf(e, m, "l0", px(2), c[0], es));
+    VC_TRY(alloc_buf(e, m, "in", px(1), 4, aes));
+    VC_TRY(alloc_buf(e, m, "l0", px(2), c[0], aes));
+    if (e->prec == PREC_FP8) VC_TRY(alloc_buf(e, m, "l0q", px(2), c[0], es));       // the bf16 stem output converted to fp8
     VC_TRY(alloc_buf(e, m, "l1", px(4), c[1], es)); VC_TRY(c3(2, 4, c[1])); VC_TRY(alloc_buf(e, m, "l2", px(4), c[1], es));
     VC_TRY(alloc_buf(e, m, "l3", px(8), c[2], es)); VC_TRY(c3(4, 8, c[2])); VC_TRY(alloc_buf(e, m, "cat16", px(8), 2 * c[2], es));
     VC_TRY(alloc_buf(e, m, "l5", px(16), c[3], es)); VC_TRY(c3(6, 16, c[3])); VC_TRY(alloc_buf(e, m, "cat12", px(16), 2 * c[3], es));
@@ -286,6 +305,10 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     View* lv = e->layer_view;
     View x = full("in", 1, 4);
     lv[0] = x = pb.conv("model.0.conv", x, full("l0", 2, c[0]), 6, 2, 2, ACT_SILU);
+    if (e->prec == PREC_FP8) {             // 3-channel stem in bf16 (K = 108), its output quantised once for the fp8 layers
+        Op op{}; op.kind = Op::TO_FP8; op.a = x; op.b = full("l0q", 2, c[0]); op.b.B = x.B; op.b.H = x.H; op.b.W = x.W; ops.push_back(op);
+        x = op.b;
+    }
     lv[1] = x = pb.conv("model.1.conv", x, full("l1", 4, c[1]), 3, 2, 1, ACT_SILU);
     lv[2] = x = yolo_c3(pb, e, 2, x, full("l2", 4, c[1]), c[1], e->rep[0], true);
     lv[3] = x = pb.conv("model.3.conv", x, full("l3", 8, c[2]), 3, 2, 1, ACT_SILU);
@@ -328,6 +351,7 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
         const bool wide = e->prec == PREC_F32;
         pb.conv("model.24.m." + std::to_string(i), heads[i], o, 1, 1, 0, ACT_NONE, nullptr, RES_NONE, wide);
         if (!wide && pb.status == VC_OK) { Op& op = ops.back(); op.cout_logical = op.conv.Cout; op.conv.Cout = lcs; }
+        if (e->prec == PREC_FP8 && pb.status == VC_OK) ops.back().conv.out_bf16 = 1;        // logits leave the fp8 domain as bf16
     }
     return pb.status;
 }
@@ -442,7 +466,8 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
             }
             case Op::SPPF: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, s)); break; }
             case Op::UPSAMPLE: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, s)); break; }
-            case Op::MAXPOOL: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_maxpool3s2(op.a, op.b, e->prec, s)); break; }
+            case Op::MAXPOOL: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_maxpool3s2(op.a, op.b, e->aux_prec, s)); break; }   // ReID only
+            case Op::TO_FP8: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_bf16_to_fp8(op.a, op.b, 1.0f / e->act_scale, s)); break; }
         }
     }
     return VC_OK;
@@ -516,12 +541,12 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     // bf16, frame already at network scale: the stem reads the u8 frames itself (same arithmetic per pixel, bit-identical stem
     // output) and the 8-byte-per-pixel letterboxed tensor is neither written nor read back
     static const bool fuse_on = !(getenv("VC_STEM_U8") && atoi(getenv("VC_STEM_U8")) == 0) && !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
-    const bool fuse = fuse_on && e->prec == PREC_BF16 && g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0 &&
+    const bool fuse = fuse_on && e->aux_prec == PREC_BF16 && g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0 &&
                       e->ch[0] % 16 == 0 && e->ch[0] <= 64;
     e->stem_src = fuse ? d_frames : nullptr;
     e->stem_geom = g;
     e->in_stale = fuse;
-    if (!fuse) { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->prec, e->dstream)); }
+    if (!fuse) { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->aux_prec, e->dstream)); }
     const int st = yolo_forward(e, B, nh, nw);
     if (fuse) e->stem_src = d_frames;             // kept for vc_detect_debug_layer(-1)
     return st;
@@ -545,10 +570,10 @@ static void reid_define(vc_engine* e) {
 static int reid_cpad(int prec) { return prec == PREC_F32 ? 4 : 8; }
 
 static int reid_alloc(vc_engine* e) {
-    const int es = elem_size(e->prec);
+    const int es = elem_size(e->aux_prec);
     const size_t K = e->cfg.max_crops;
     auto& m = e->rbuf;
-    VC_TRY(alloc_buf(e, m, "in", K * 50 * 50, reid_cpad(e->prec), es));
+    VC_TRY(alloc_buf(e, m, "in", K * 50 * 50, reid_cpad(e->aux_prec), es));
     VC_TRY(alloc_buf(e, m, "r0", K * 50 * 50, 64, es));
     VC_TRY(alloc_buf(e, m, "x0", K * 25 * 25, 64, es));
     int hw = 25;
@@ -576,9 +601,9 @@ static int reid_alloc(vc_engine* e) {
 // forward from the pre-filled "in" buffer (k x 50 x 50 x cpad) to e->d_feat
 static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     std::vector<Op> ops;
-    PlanBuilder pb{e, &e->reid, &ops, e->prec};
+    PlanBuilder pb{e, &e->reid, &ops, e->aux_prec};
     auto& m = e->rbuf;
-    View x = mkview(m["in"], k, 50, 50, reid_cpad(e->prec), 0);
+    View x = mkview(m["in"], k, 50, 50, reid_cpad(e->aux_prec), 0);
     x = pb.conv("conv", x, mkview(m["r0"], k, 50, 50, 64, 0), 3, 1, 1, ACT_RELU);             // model.py:51-55
     { Op op{}; op.kind = Op::MAXPOOL; op.a = x; op.b = mkview(m["x0"], k, 25, 25, 64, 0); ops.push_back(op); x = op.b; }   // :58
     for (const auto& b : kReidBlocks) {                                                        // BasicBlock.forward, model.py:30-38
@@ -591,7 +616,7 @@ static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     }
     VC_TRY(pb.status);
     VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, rs));
-    { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs); VC_TRY(launch_avgpool_l2norm(x, feat_out, e->prec, rs)); }               // model.py:70,93
+    { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs); VC_TRY(launch_avgpool_l2norm(x, feat_out, e->aux_prec, rs)); }               // model.py:70,93
     return VC_OK;
 }
 
@@ -600,7 +625,7 @@ int run_reid_on(vc_engine* e, const uint8_t* d_frames, int H, int W, int k, cons
     VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
     if (k <= 0) return VC_OK;
     { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs);
-      VC_TRY(launch_crop_resize(d_frames, H, W, d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, rs)); }
+      VC_TRY(launch_crop_resize(d_frames, H, W, d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->aux_prec), e->aux_prec, rs)); }
     return reid_forward(e, k, rs, feat_out);
 }
 
@@ -640,7 +665,7 @@ int vc_engine_config_default(vc_engine_config* c) {
 int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     VC_CHECK(cfg && out, VC_ERR_ARG, "null argument");
     VC_CHECK(cfg->yolo_variant >= 0 && cfg->yolo_variant <= 2, VC_ERR_ARG, "yolo_variant must be 0..2");
-    VC_CHECK(cfg->precision == VC_PREC_BF16 || cfg->precision == VC_PREC_F32, VC_ERR_ARG, "bad precision");
+    VC_CHECK(cfg->precision == VC_PREC_BF16 || cfg->precision == VC_PREC_F32 || cfg->precision == VC_PREC_FP8, VC_ERR_ARG, "bad precision");
     VC_CHECK(cfg->max_candidates % 64 == 0 && cfg->max_candidates >= 64 && cfg->max_candidates <= 8192, VC_ERR_ARG,
              "max_candidates must be a multiple of 64 in [64, 8192]");
     VC_CHECK(cfg->max_batch >= 1 && cfg->num_classes >= 1 && cfg->max_det >= 1, VC_ERR_ARG, "bad sizes");
@@ -651,6 +676,8 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     vc_engine* e = new vc_engine();
     e->cfg = *cfg;
     e->prec = cfg->precision;
+    e->aux_prec = cfg->precision == VC_PREC_FP8 ? (int)PREC_BF16 : cfg->precision;      // stem, logits, pools of the ReID net, ReID convs
+    e->act_scale = getenv("VC_FP8_ACT_SCALE") ? (float)atof(getenv("VC_FP8_ACT_SCALE")) : 1.0f;
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
     do {
@@ -784,10 +811,13 @@ int vc_engine_finalize(vc_engine* e) {
         for (auto& p : e->yolo.params) if (p.fuse_a >= 0) { part[p.fuse_a] = 1; part[p.fuse_b] = 1; }
         for (size_t i = 0; i < e->yolo.params.size(); ++i) {
             if (part[i]) { VC_CHECK(e->yolo.params[i].set, VC_ERR_STATE, "parameter '%s' was never set", e->yolo.params[i].name.c_str()); continue; }
-            VC_TRY(pack_and_upload(e, e->yolo.params[i], e->prec));
+            ConvParam& cp = e->yolo.params[i];
+            // fp8 mode: every detector conv but the 3-channel stem (Cin must be a multiple of 16 for 16-byte K chunks)
+            const bool fp8 = e->prec == PREC_FP8 && cp.I % 16 == 0;
+            VC_TRY(pack_and_upload(e, cp, fp8 ? (int)PREC_FP8 : e->aux_prec, e->act_scale));
         }
     }
-    for (auto& p : e->reid.params) VC_TRY(pack_and_upload(e, p, e->prec));
+    for (auto& p : e->reid.params) VC_TRY(pack_and_upload(e, p, e->aux_prec));
     e->d_frames_bytes = (size_t)e->cfg.max_batch * e->cfg.max_frame_h * e->cfg.max_frame_w * 3;     // staging for host frames
     VC_TRY(dev_alloc(e, (void**)&e->d_frames, e->d_frames_bytes));
     if (e->cfg.with_detector) VC_TRY(yolo_alloc(e));
@@ -827,11 +857,11 @@ int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* 
     }
     VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->dstream));
     VC_HIP(hipStreamSynchronize(e->dstream));        // hg / rgb[] are caller or stack memory
-    const size_t px = (size_t)nh * nw * 4 * elem_size(e->prec);
+    const size_t px = (size_t)nh * nw * 4 * elem_size(e->aux_prec);
     for (int i = 0; i < n; ++i) {
         const LetterboxGeom g = letterbox_geom(h[i], w[i], nh, nw, false);
         ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream);
-        VC_TRY(launch_letterbox(e->d_frames + offs[i], (char*)e->ybuf["in"].ptr + (size_t)i * px, 1, g, e->prec, e->dstream));
+        VC_TRY(launch_letterbox(e->d_frames + offs[i], (char*)e->ybuf["in"].ptr + (size_t)i * px, 1, g, e->aux_prec, e->dstream));
     }
     VC_TRY(yolo_forward(e, n, nh, nw));
     const int md = e->cfg.max_det;
@@ -857,7 +887,7 @@ int vc_detect_debug_shape(const vc_engine* e, int* net_h, int* net_w, int* n_can
 static int read_view_f32(vc_engine* e, const View& v, float* out, size_t cap, int dims[4]) {
     const size_t n = (size_t)v.B * v.H * v.W * v.C;
     VC_CHECK(n <= cap, VC_ERR_CAPACITY, "debug buffer too small: need %zu floats", n);
-    const int es = elem_size(e->prec);
+    const int es = v.es ? v.es : elem_size(e->prec);
     const size_t rows = (size_t)v.B * v.H * v.W;
     std::vector<uint8_t> raw(rows * v.cs * es);
     VC_HIP(hipStreamSynchronize(e->stream));
@@ -866,7 +896,7 @@ static int read_view_f32(vc_engine* e, const View& v, float* out, size_t cap, in
     for (size_t r = 0; r < rows; ++r)
         for (int c = 0; c < v.C; ++c) {
             const size_t o = r * v.cs + v.co + c;
-            out[r * v.C + c] = es == 4 ? ((const float*)raw.data())[o] : bf16_to_f32(((const uint16_t*)raw.data())[o]);
+            out[r * v.C + c] = es == 4 ? ((const float*)raw.data())[o] : es == 2 ? bf16_to_f32(((const uint16_t*)raw.data())[o]) : e4m3_to_f32(raw[o]) * e->act_scale;
         }
     dims[0] = v.B; dims[1] = v.H; dims[2] = v.W; dims[3] = v.C;
     return VC_OK;
@@ -878,7 +908,7 @@ int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int d
     VC_CHECK(layer >= -1 && layer < 24, VC_ERR_ARG, "layer must be -1..23");
     if (layer == -1) {
         if (e->in_stale && e->stem_src) {         // the last pass folded the letterbox into the stem: produce the tensor now (the frames must still be there)
-            VC_TRY(launch_letterbox(e->stem_src, e->ybuf["in"].ptr, e->last_B, e->stem_geom, e->prec, e->dstream));
+            VC_TRY(launch_letterbox(e->stem_src, e->ybuf["in"].ptr, e->last_B, e->stem_geom, e->aux_prec, e->dstream));
             VC_HIP(hipStreamSynchronize(e->dstream));
             e->in_stale = false;
         }
@@ -939,7 +969,7 @@ int vc_embed_tensor(vc_engine* e, const float* x, int k, float* out_feat) {
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_HIP(hipMemcpyAsync(e->d_reid_in_nchw, x, (size_t)k * 3 * 2500 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     VC_HIP(hipStreamSynchronize(e->rstream));
-    VC_TRY(launch_nchw_to_nhwc_pad(e->d_reid_in_nchw, k, 3, 50, 50, e->rbuf["in"].ptr, reid_cpad(e->prec), e->prec, e->stream));
+    VC_TRY(launch_nchw_to_nhwc_pad(e->d_reid_in_nchw, k, 3, 50, 50, e->rbuf["in"].ptr, reid_cpad(e->aux_prec), e->aux_prec, e->stream));
     VC_TRY(reid_forward(e, k, e->stream, e->d_feat));
     VC_HIP(hipMemcpyAsync(e->h_feat, e->d_feat, (size_t)k * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     VC_HIP(hipStreamSynchronize(e->stream));
@@ -1015,7 +1045,7 @@ int vc_profile_conv_busy(vc_engine* e, double* union_ms, double* span_ms) {
 // ---- single-function entry points --------------------------------------------------------------------------
 int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res, float* y) {
     VC_CHECK(d && x && w && bias && y, VC_ERR_ARG, "null argument");
-    const int prec = d->precision, es = elem_size(prec), ch = prec == PREC_F32 ? 4 : 8;
+    const int prec = d->precision, es = elem_size(prec), ch = prec == PREC_F32 ? 4 : prec == PREC_FP8 ? 16 : 8;
     vc_engine tmp;                           // only used as an allocation list
     ConvParam p;
     p.name = "host"; p.O = d->cout; p.I = d->cin; p.kh = d->kh; p.kw = d->kw; p.set = true;
@@ -1025,14 +1055,15 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
     const int cin_eff = p.cin_eff;
     const int Ho = (d->h + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
     const size_t npix_in = (size_t)d->b * d->h * d->w, npix_out = (size_t)d->b * Ho * Wo;
-    const int cout_s = round_up(d->cout, 4);
+    const int cout_s = round_up(d->cout, prec == PREC_FP8 ? 8 : 4);
     void *dx = nullptr, *dy = nullptr, *dr = nullptr;
     auto upload = [&](const float* src, size_t npix, int C, int Cs, void** dst) -> int {
         std::vector<uint8_t> buf(npix * Cs * es, 0);
         for (size_t i = 0; i < npix; ++i)
             for (int c = 0; c < C; ++c) {
                 if (es == 4) ((float*)buf.data())[i * Cs + c] = src[i * C + c];
-                else ((uint16_t*)buf.data())[i * Cs + c] = f32_to_bf16(src[i * C + c]);
+                else if (es == 2) ((uint16_t*)buf.data())[i * Cs + c] = f32_to_bf16(src[i * C + c]);
+                else buf[i * Cs + c] = f32_to_e4m3(src[i * C + c]);                 // activation scale 1
             }
         VC_TRY(dev_alloc(&tmp, dst, buf.size()));
         VC_HIP(hipMemcpy(*dst, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -1048,6 +1079,8 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         c.Ho = Ho; c.Wo = Wo; c.Cout = d->cout; c.out_cs = cout_s; c.out_co = 0; c.res_cs = cout_s; c.res_co = 0;
         c.kh = d->kh; c.kw = d->kw; c.sh = c.sw = d->stride; c.ph = c.pw = d->pad;
         c.K = p.K; c.Kp = p.Kp; c.act = d->act; c.res_mode = res ? d->res_mode : RES_NONE; c.out_f32 = 0; c.prec = prec;
+        c.scale = p.d_scale; c.act_scale = 1.0f; c.inv_act_scale = 1.0f; c.out_bf16 = 0;
+        if (prec == PREC_FP8) c.Cout = round_up(d->cout, 8);      // the fp8 epilogue stores 8 channels at a time (weight / bias / scale rows are zero-padded)
         c.M = d->b * Ho * Wo;
         c.cfg = getenv("VC_CONV_CFG") ? atoi(getenv("VC_CONV_CFG")) : -1;
         c.ablate = getenv("VC_CONV_ABLATE") ? atoi(getenv("VC_CONV_ABLATE")) : 0;
@@ -1081,7 +1114,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         if (hipMemcpy(buf.data(), dy, buf.size(), hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy back failed"); st = VC_ERR_HIP; }
         for (size_t i = 0; i < npix_out && st == VC_OK; ++i)
             for (int c = 0; c < d->cout; ++c)
-                y[i * d->cout + c] = es == 4 ? ((const float*)buf.data())[i * cout_s + c] : bf16_to_f32(((const uint16_t*)buf.data())[i * cout_s + c]);
+                y[i * d->cout + c] = es == 4 ? ((const float*)buf.data())[i * cout_s + c] : es == 2 ? bf16_to_f32(((const uint16_t*)buf.data())[i * cout_s + c]) : e4m3_to_f32(buf[i * cout_s + c]);
     }
     for (void* q : tmp.allocs) hipFree(q);
     tmp.allocs.clear();

@@ -10,6 +10,7 @@ struct View {
     void* ptr;
     int B, H, W, C;
     int cs, co;
+    int es;               // element size in bytes (0: the engine's default), set where the buffer is allocated
 };
 
 // ---- detect side -----------------------------------------------------------------------------------
@@ -25,6 +26,8 @@ int launch_letterbox(const uint8_t* src, void* dst, int B, const LetterboxGeom& 
 // SPPF: x = view slice [0,C); writes maxpool5, maxpool5∘2, maxpool5∘3 into slices [C,2C), [2C,3C), [3C,4C) of the same buffer.
 int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s);
 int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s);
+// bf16 NHWC -> OCP e4m3fn, value x inv_scale, clamped to +-448 (the stem's output entering the fp8 layers)
+int launch_bf16_to_fp8(const View& src, const View& dst, float inv_scale, hipStream_t s);
 
 // Detect decode + candidate filter.  logits: B x ny x nx x lc_stride (channel a*(5+nc)+o), f32 in the fp32 parity mode, bf16 in
 // the bf16 mode (like every other activation there).

@@ -103,7 +103,7 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
     pd.fd.assign(b, FrameDets{});
     pd.row0.assign(b, 0);
     for (int f = 0; f < b; ++f) {
-        VC_CHECK(h_cnt[f] >= 0, VC_ERR_CAPACITY, "frame %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates", f,
+        VC_CHECK(h_cnt[f] >= 0 || e->inject_b > 0, VC_ERR_CAPACITY, "frame %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates", f,
                  e->cfg.max_candidates);
         if (e->inject_b > 0) {
             const int fi = f % e->inject_b;

@@ -39,8 +39,36 @@ const char* last_error();
     } while (0)
 
 // ---- element types --------------------------------------------------------------------------
-enum Prec : int { PREC_BF16 = 0, PREC_F32 = 1 };
-static inline int elem_size(int prec) { return prec == PREC_BF16 ? 2 : 4; }
+enum Prec : int { PREC_BF16 = 0, PREC_F32 = 1, PREC_FP8 = 2 };   // PREC_FP8: OCP e4m3fn activations + weights on the MX-scaled K = 128 MFMA
+static inline int elem_size(int prec) { return prec == PREC_BF16 ? 2 : prec == PREC_FP8 ? 1 : 4; }
+
+// round-to-nearest-even f32 -> OCP e4m3fn (1-4-3, bias 7, max 448, no infinities), saturating; host-side weight packing and tests
+static inline uint8_t f32_to_e4m3(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    float a = f < 0 ? -f : f;
+    if (!(a == a)) return (uint8_t)(sign | 0x7f);
+    if (a >= 448.0f) return (uint8_t)(sign | 0x7e);               // saturate to +-448
+    if (a < 0.0009765625f) return sign;                            // below half of the smallest subnormal (2^-10)
+    int e;
+    const float m = frexpf(a, &e);                                 // a = m * 2^e, m in [0.5, 1)
+    int exp = e - 1;                                               // a = (2m) * 2^exp, 2m in [1, 2)
+    if (exp < -6) {                                                // subnormal: value = k * 2^-9, k = 0..7
+        const float k = nearbyintf(a * 512.0f);
+        return (uint8_t)(sign | (k >= 8.0f ? 0x08 : (uint8_t)k));
+    }
+    float frac = nearbyintf((2.0f * m - 1.0f) * 8.0f);             // 3 mantissa bits, RNE (default rounding mode)
+    if (frac >= 8.0f) { frac = 0.0f; ++exp; }
+    if (exp > 8 || (exp == 8 && frac > 6.0f)) return (uint8_t)(sign | 0x7e);
+    return (uint8_t)(sign | ((exp + 7) << 3) | (int)frac);
+}
+static inline float e4m3_to_f32(uint8_t b) {
+    const int e = (b >> 3) & 15, m = b & 7;
+    float v = e == 0 ? (float)m * 0.001953125f : ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    if (e == 15 && m == 7) v = NAN;
+    return (b & 0x80) ? -v : v;
+}
 
 // round-to-nearest-even f32 -> bf16 (matches torch .bfloat16() and v_cvt_pk_bf16_f32)
 __host__ __device__ static inline uint16_t f32_to_bf16(float f) {
@@ -92,6 +120,11 @@ struct ConvP {
     int K, Kp;           // kh*kw*Cin and the padded row length of the packed weights (multiple of conv_k_tile)
     int Kw;              // set by launch_conv: weight row stride (= caller's Kp); Kp then becomes the K-loop extent
     int act, res_mode, out_f32, prec;
+    // fp8 path (PREC_FP8): per-output-channel scale [Cout_pad] = weight scale x activation scale, applied to the accumulator; activation
+    // scale of the fp8 tensors (real = stored x act_scale); out_bf16 = store the dequantised result as bf16 (Detect heads)
+    const float* scale;
+    float act_scale, inv_act_scale;
+    int out_bf16;
     int M;               // B*Ho*Wo
     int cfg;             // tile configuration index (conv_igemm.hip kCfg), -1 = heuristic
     hipEvent_t ev_start, ev_stop;   // optional (in-flight profiling): receive the kernel's own start / stop timestamps (hipExtLaunchKernel)

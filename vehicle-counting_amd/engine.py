@@ -21,7 +21,7 @@ class Engine:
         cfg = L.EngineConfig()
         L.check(lib.vc_engine_config_default(C.byref(cfg)))
         cfg.device = device
-        cfg.precision = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
+        cfg.precision = L.PREC_ID[precision]
         cfg.yolo_variant = YOLO_VARIANT_ID[model_name]
         cfg.num_classes, cfg.img_size, cfg.max_batch = num_classes, img_size, max_batch
         cfg.max_frame_h, cfg.max_frame_w = max_frame_hw
@@ -286,7 +286,7 @@ def conv2d(x_nhwc, w_oihw, bias, *, stride=1, pad=0, act=0, res=None, res_mode=0
     B, H, W, Ci = x.shape
     Co, _, kh, kw = w.shape
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-    d = L.ConvDesc(B, H, W, Ci, Co, kh, kw, stride, pad, act, res_mode, L.PREC_BF16 if precision == "bf16" else L.PREC_F32)
+    d = L.ConvDesc(B, H, W, Ci, Co, kh, kw, stride, pad, act, res_mode, L.PREC_ID[precision])
     y = np.zeros((B, Ho, Wo, Co), np.float32)
     r = L.f32(res) if res is not None else None
     L.check(L.lib().vc_conv2d_host(C.byref(d), L.ptr(x, C.c_float), L.ptr(w, C.c_float), L.ptr(b, C.c_float),
