@@ -1,18 +1,23 @@
 """bench.py -- end-to-end frames/s of the detect + NMS + ReID + track hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload s640-bf16|l1280-fp8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of B = 64 synthetic 640x640 frames of ONE camera stream per GPU
-(BASELINE.json configs[1]: YOLOv5s 640x640, bf16 convs): letterbox -> YOLOv5s conv stack -> decode -> NMS -> crops ->
-ReID CNN -> per-class DeepSORT step, frames already resident in HBM.  Each rank owns its own camera stream (weak
-scaling); the only collective is the all-gather of the per-camera count tensors at the end.
-Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one batch of B synthetic frames of ONE camera stream per GPU: letterbox -> YOLOv5
+conv stack -> decode -> NMS -> crops -> ReID CNN -> per-class DeepSORT (device-resident, one kernel per batch), frames already
+resident in HBM.  Each rank owns its own camera stream (weak scaling); the only collective is the all-gather of
+the per-camera count tensors at the end.  Rank 0 prints ONE JSON line.
+
+Workloads (config.workload names the one measured):
+  s640-bf16   BASELINE.json configs[1] -- the headline: YOLOv5s, 640x640 frames, bf16 convs, B = 128, 512-frame clip, 12 objects
+  l1280-fp8   BASELINE.json configs[4] -- YOLOv5l, 1280x1280 frames, fp8 (MX-scaled MFMA) detector convs, B = 16, ground-truth
+              rectangles injected after the conv stack has run (the seeded random head of the deep variant saturates)
+With the default workload on one GPU the line also carries `extra_points`: the same pipeline at K = 32 and K = 256 detections per
+frame (detection injection) and `value_host_frames`, the PCIe-inclusive rate with the frames in pinned host memory.
 """
 import argparse
 import gc
 import json
-import math
 import os
 import sys
 import time
@@ -27,20 +32,25 @@ import vehicle_counting_amd.engine as E  # noqa: E402
 from vehicle_counting_amd import _lib as L  # noqa: E402
 from vehicle_counting_amd import parallel  # noqa: E402
 from vehicle_counting_amd.counting import count_directions, csv_records  # noqa: E402
-from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames, synth_tracks  # noqa: E402
 from vehicle_counting_amd.track import VideoCounting  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
 
-B = int(os.environ.get("VC_BENCH_B", 128))  # frames per step (one batch of the camera stream; 64 -> 128 -> 256: 11.0 -> 11.6 -> 11.8 k frames/s)
-H = W = 640
 NC = 80
-N_OBJ = 12
-CLIP = int(os.environ.get("VC_BENCH_CLIP", 512))   # distinct synthetic frames per stream (F = 512), cycled
-ASYNC = os.environ.get("VC_BENCH_ASYNC", "1") != "0"     # tracker loop on the engine's worker thread (vc_stream_run_async)
 TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PEAK_HBM_GBS = 8000.0          # HBM3E (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md; fp8 = MX-scaled K = 128 form)
+PEAK_HBM_GBS = 8000.0                              # HBM3E (MI355X_MICROARCH.md)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
+
+WORKLOADS = {
+    "s640-bf16": dict(model="yolov5s", size=640, precision="bf16", B=int(os.environ.get("VC_BENCH_B", 128)),
+                      clip=int(os.environ.get("VC_BENCH_CLIP", 512)), n_obj=12, inject=0, obj_shift=1.0,
+                      desc="YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])"),
+    "l1280-fp8": dict(model="yolov5l", size=1280, precision="fp8", B=int(os.environ.get("VC_BENCH_B", 16)), clip=64, n_obj=16, inject=16,
+                      obj_shift=-8.0,      # the random head of the deep variant would pass most of its 100 800 candidates per frame
+                      desc="YOLOv5l 1280x1280 single camera stream per GPU, fp8 MX-MFMA detector convs (BASELINE.json configs[4]), "
+                           "16 ground-truth rectangles per frame injected after the conv stack"),
+}
 
 
 def cpu_baseline(ysd, rsd, frames, n_frames):
@@ -51,7 +61,6 @@ def cpu_baseline(ysd, rsd, frames, n_frames):
     t0 = time.perf_counter()
     _, _, nd = op.run_video(frames[:n_frames], ysd, rsd, cfg, ZONE, nc=NC)
     dt = time.perf_counter() - t0
-    gc.enable()
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"first {n_frames} frames of the rank-0 stream through oracle/pipeline.py (torch-CPU fp32 YOLOv5s + ReID, "
                       f"NumPy/SciPy DeepSORT), {int(np.mean(nd))} det/frame, {dt:.1f} s"}
@@ -76,12 +85,146 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def injected_detections(n_frames, size, n_obj, seed):
+    """Ground-truth rectangles of the synthetic stream as detector output rows [x1, y1, x2, y2, conf, cls] (SURVEY.md 8d injection)."""
+    tr = synth_tracks(n_frames, size, size, n_obj=n_obj, seed=seed, bounce=True)
+    det = np.zeros((n_frames, n_obj, 6), np.float32)
+    for f, (xywh, labels, scores) in enumerate(tr):
+        det[f, :, 0:2] = xywh[:, 0:2]
+        det[f, :, 2:4] = xywh[:, 0:2] + xywh[:, 2:4]
+        det[f, :, 4] = scores
+        det[f, :, 5] = labels
+    return det, np.full(n_frames, n_obj, np.int32)
+
+
+class Stream:
+    """One camera stream on one engine: the three overlapped stages of the fused path."""
+
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None):
+        self.wl, self.dev = wl, dev
+        self.B = B or wl["B"]
+        self.H = self.W = wl["size"]
+        n_obj = n_obj or wl["n_obj"]
+        inject = wl["inject"] if inject is None else inject
+        clip = clip or wl["clip"]
+        clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
+        self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=4.0, obj_shift=wl["obj_shift"])
+        self.rsd = synth_reid(1702)
+        per_frame = max(64, 2 * max(inject, n_obj))
+        self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
+                            img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=self.B * per_frame,
+                            max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096)
+        k = 32
+        sizes = []
+        while k <= self.B * per_frame:
+            sizes.append(k); k *= 2
+        self.eng.pretune(tuple(sizes))                               # conv autotune for every ReID size bucket
+        self.trackers = [self.eng.tracker_create(**TRACK) for _ in range(NC)]
+        self.frames = synth_frames(clip, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True)      # one camera stream per rank
+        self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region
+        self.clip = clip
+        self.inject = injected_detections(clip, self.H, inject, 1702 + rank) if inject else None
+        self.counter = VideoCounting([str(c) for c in range(NC)], ZONE)
+        self.ndet = [0, 0]
+        self.nrows = 0
+        self.host = None
+        self._dev_ptr = {}
+
+    def use_host_frames(self):
+        """Frames in pinned host memory: every batch crosses PCIe inside the timed region (vc_stream_submit_host)."""
+        self.host = torch.from_numpy(self.frames).pin_memory()
+
+    def batch_ptr(self, i):
+        f0 = (i * self.B) % self.clip
+        return self.d_frames[f0:f0 + self.B].data_ptr()
+
+    def submit(self, i):
+        if self.inject is not None:                                  # batch i gets the rectangles of its own frames (captured at submit time)
+            f0 = (i * self.B) % self.clip
+            self.eng.stream_inject(self.inject[0][f0:f0 + self.B], self.inject[1][f0:f0 + self.B])
+        if self.host is not None:
+            f0 = (i * self.B) % self.clip
+            self._dev_ptr[i] = self.eng.stream_submit_host(self.host[f0:f0 + self.B].data_ptr(), self.B, self.H, self.W)
+        else:
+            self.eng.stream_submit(self.batch_ptr(i), self.B, self.H, self.W)
+
+    def run_async(self, i):
+        ptr = self._dev_ptr.pop(i) if self.host is not None else self.batch_ptr(i)
+        self.eng.stream_run_async(self.trackers, ptr, self.B, self.H, self.W)
+
+    def collect(self, i, record):
+        rows, fidx, nd = self.eng.stream_collect()
+        if record:
+            self.ndet[0] += int(nd.sum()); self.ndet[1] += self.B
+            self.nrows += len(rows)
+            # VideoCounting's zone filter + per-track lists for one batch, on the host while the GPU works on the next batches
+            self.counter.run((i * self.B + 1 + fidx).tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]),
+                             finalize=False)
+
+    def run_steps(self, first, n, record):
+        """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker kernel of batch i
+        (tracker stream); rows come back one batch late.  Everything is collected before the function returns, so the timed
+        region contains the whole work of its n steps."""
+        if n <= 0:
+            return
+        self.submit(first)
+        for i in range(first, first + n):
+            if i + 1 < first + n:
+                self.submit(i + 1)
+            self.run_async(i)
+            if i > first:
+                self.collect(i - 1, record)
+        self.collect(first + n - 1, record)
+
+    def sync(self, world):
+        self.eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    def timed(self, first, steps, world):
+        """(seconds, post-pass ms, gathered counts) for `steps` steps starting at batch `first`, counting post-pass included."""
+        self.sync(world)
+        gc.collect(); gc.disable()                 # a generation-2 collection over the per-track box lists costs 40 ms when it lands in the serial tail
+        t0 = time.perf_counter()
+        self.run_steps(first, steps, True)
+        t_post = time.perf_counter()
+        td = self.counter.run([], [], [], np.zeros((0, 4), np.int64))      # every batch was appended as it was collected: directions only
+        rows = csv_records(td)
+        dirs = list(self.counter.directions.keys())
+        local_counts = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)[None]
+        all_counts = parallel.allgather_counts(local_counts, device=self.dev if world > 1 else None)
+        self.sync(world)
+        dt = time.perf_counter() - t0
+        gc.enable()
+        return dt, (time.perf_counter() - t_post) * 1e3, all_counts
+
+
+def quick_point(wl, rank, local, dev, world, **kw):
+    """Throughput of one extra operating point: a short run of the same pipeline with other stream parameters."""
+    steps, warm = kw.pop("steps", 8), kw.pop("warmup", 2)
+    host = kw.pop("host", False)
+    st = Stream(wl, rank, local, dev, **kw)
+    if host:
+        st.use_host_frames()
+    st.run_steps(0, warm, False)
+    dt, _, _ = st.timed(warm, steps, world)
+    out = {"value": steps * st.B / dt, "unit": "frames/s", "frames_per_step": st.B, "steps": steps,
+           "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "tracked_rows": st.nrows}
+    st.eng.close()
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s640-bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the K = 32 / 256 and host-frames operating points")
     ap.add_argument("--cpu-frames", type=int, default=12)
     args = ap.parse_args()
 
@@ -95,97 +238,15 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local} of {world}, but only {ndev} device(s) are visible (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    wl = WORKLOADS[args.workload]
+    peak_tflops = PEAK_TFLOPS[wl["precision"]]
 
-    ysd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=1.0)
-    rsd = synth_reid(1702)
-    eng = E.Engine(ysd, rsd, device=local, precision="bf16", model_name="yolov5s", num_classes=NC, max_batch=B,
-                   max_frame_hw=(H, W), max_crops=B * 64, max_tracks=8192, nn_budget_cap=60)
-    eng.pretune((32, 64, 128, 256, 512, 1024, 2048, 4096))                      # conv autotune for every ReID size bucket
-    trackers = [eng.tracker_create(**TRACK) for _ in range(NC)]
-    frames = synth_frames(CLIP, H, W, n_obj=N_OBJ, seed=1702 + rank, bounce=True)          # one camera stream per rank
-    d_frames = torch.from_numpy(frames).to(dev)                                 # resident in HBM before the timed region
-    LOOP = math.lcm(CLIP, B)                  # the cycled clip laid out so that every batch is one contiguous run of frames
-    if LOOP > CLIP:
-        d_frames = d_frames.repeat(LOOP // CLIP, 1, 1, 1)
-    ndet_total = [0, 0]
-
-    def batch_ptr(i):
-        f0 = (i * B) % LOOP
-        return d_frames[f0:f0 + B].data_ptr()
-
-    def step(i, record, prefetch=True):
-        if prefetch:
-            eng.stream_submit(batch_ptr(i + 1), B, H, W)      # detector of the NEXT batch runs on its own stream while this one is tracked
-        rows, fidx, nd = eng.stream_run_packed(trackers, batch_ptr(i), B, H, W)
-        if record:
-            ndet_total[0] += int(nd.sum()); ndet_total[1] += B
-            count_rows(i * B + 1, rows, fidx)
-
-    counter = VideoCounting([str(c) for c in range(NC)], ZONE)
-    nrows_total = [0]
-
-    def count_rows(f0, rows, fidx):
-        """VideoCounting's zone filter + per-track lists for one batch, on the host while the GPU works on the next batches."""
-        nrows_total[0] += len(rows)
-        counter.run((f0 + fidx).tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]), finalize=False)
-
-    step_marks = []
-
-    def collect(i, record):
-        rows, fidx, nd = eng.stream_collect()
-        if record:
-            step_marks.append(time.perf_counter())
-            ndet_total[0] += int(nd.sum()); ndet_total[1] += B
-            count_rows(i * B + 1, rows, fidx)
-
-    def run_steps(first, n, record):
-        """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker loop of batch
-        i-1 (the engine's worker thread + tracker stream); rows come back one batch late.  Everything is collected before
-        the function returns, so the timed region contains the whole work of its n steps."""
-        if n <= 0:
-            return
-        if ASYNC:
-            for i in range(first, first + n):
-                eng.stream_submit(batch_ptr(i + 1), B, H, W)
-                eng.stream_run_async(trackers, batch_ptr(i), B, H, W)
-                if i > first:
-                    collect(i - 1, record)
-            collect(first + n - 1, record)
-        else:
-            for i in range(first, first + n):
-                step(i, record)
-
-    def sync_all():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-
-    eng.stream_submit(batch_ptr(0), B, H, W)
-    run_steps(0, args.warmup, False)
-    sync_all()
+    st = Stream(wl, rank, local, dev)
+    eng, B = st.eng, st.B
+    st.run_steps(0, args.warmup, False)
+    st.sync(world)
     eng.profile_reset(); eng.profile(2)            # in-flight event pairs around every conv launch of the timed steps (no host waits)
-    gc.collect(); gc.disable()                     # a generation-2 collection over the per-track box lists costs 40 ms when it lands in the serial tail
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps, True)
-    # end of run: per-camera counts (VideoCounting) merged with the one collective of the design
-    t_post = time.perf_counter()
-    tt = [time.perf_counter()]
-    tt.append(time.perf_counter())
-    td = counter.run([], [], [], np.zeros((0, 4), np.int64))      # every batch was appended as it was collected: directions only
-    tt.append(time.perf_counter())
-    rows = csv_records(td)
-    tt.append(time.perf_counter())
-    dirs = list(counter.directions.keys())
-    local_counts = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)[None]
-    all_counts = parallel.allgather_counts(local_counts, device=dev if world > 1 else None)
-    tt.append(time.perf_counter())
-    sync_all()
-    dt = time.perf_counter() - t0
-    post_ms = (time.perf_counter() - t_post) * 1e3
-    tt.append(time.perf_counter())
-    if os.environ.get('VC_BENCH_DBG') and len(step_marks) > 1: print('ms between collects: ' + ' '.join('%.1f' % ((b - a) * 1e3) for a, b in zip([t0] + step_marks[:-1], step_marks)), file=sys.stderr)
-    if os.environ.get('VC_BENCH_DBG'): print('post-pass ms: setup %.1f run %.1f csv %.1f count+gather %.1f final sync %.1f' % tuple((b - a) * 1e3 for a, b in zip(tt[:-1], tt[1:])), file=sys.stderr)
+    dt, post_ms, all_counts = st.timed(args.warmup, args.steps, world)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -197,10 +258,10 @@ def main():
     conv_timed = eng.profile_read(L.PROF_CONV)
     conv_union_ms, conv_span_ms = eng.profile_conv_busy()
     eng.profile(0)
-    step(args.warmup + args.steps, False, prefetch=False)       # drain the submission left in flight
     eng.profile(True); eng.profile_reset()
+    first = args.warmup + args.steps
     for i in range(2):
-        step(args.warmup + args.steps + 1 + i, False, prefetch=False)
+        st.run_steps(first + i, 1, False)
     eng.sync()
     conv = eng.profile_read(L.PROF_CONV)
     cats = {n: eng.profile_read(c) for n, c in (("conv", L.PROF_CONV), ("detect_aux", L.PROF_DETECT_AUX),
@@ -213,7 +274,7 @@ def main():
     traffic, traffic_src = None, None
     for rnd in ("r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
-        if os.path.exists(tp):
+        if args.workload == "s640-bf16" and os.path.exists(tp):
             with open(tp) as f:
                 traffic, traffic_src = json.load(f)["conv_all"]["hbm_bytes_per_launch"], f"profiles/{rnd}_pmc_traffic.json"
             break
@@ -227,45 +288,61 @@ def main():
     n_meas_steps = max(conv_timed["launches"] / max(conv["launches"] / 2.0, 1.0), 1e-9)      # timed steps covered by the event pool
     flops_step, bytes_step = conv_timed["flops"] / n_meas_steps, conv_timed["bytes"] / n_meas_steps
     mfma_tflops, hbm_gbs = flops_step / step_s / 1e12, bytes_step / step_s / 1e9
-    mfma_frac, hbm_frac = mfma_tflops / PEAK_BF16_TFLOPS, hbm_gbs / PEAK_HBM_GBS
+    mfma_frac, hbm_frac = mfma_tflops / peak_tflops, hbm_gbs / PEAK_HBM_GBS
     overlapped = conv_timed["flops"] / (conv_timed["ms"] * 1e-3) / 1e12 if conv_timed["ms"] > 0 else 0.0
     hbm_bound = hbm_frac > mfma_frac
     roofline = {
         "bound": "hbm" if hbm_bound else "mfma",
-        "achieved": hbm_gbs if hbm_bound else mfma_tflops, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+        "achieved": hbm_gbs if hbm_bound else mfma_tflops, "peak": PEAK_HBM_GBS if hbm_bound else peak_tflops,
         "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": max(hbm_frac, mfma_frac), "traffic": traffic,
-        "mfma_frac": mfma_frac, "mfma_tflops": mfma_tflops, "hbm_frac": hbm_frac, "hbm_gbs": hbm_gbs,
+        "mfma_frac": mfma_frac, "mfma_tflops": mfma_tflops, "mfma_peak_tflops": peak_tflops, "hbm_frac": hbm_frac, "hbm_gbs": hbm_gbs,
         "time_base": "wall clock of the timed region: algorithmic conv work per step / ms_per_step",
-        "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all YOLOv5s + ReID conv launches of a step)",
+        "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / reid_stem_pool_kernel (all detector + ReID conv launches of a step)",
         "launches_per_step": conv["launches"] / 2.0,
         "algorithmic_gflop_per_step": flops_step / 1e9, "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
         "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),
         "avg_launch_note": "HIP start/stop timestamps of every conv dispatch of the timed steps (hipExtLaunchKernel); launches of the detector and ReID streams overlap, so launches_per_step x avg_launch_us may exceed ms_per_step",
-        "achieved_sum_of_overlapped_durations_tflops": overlapped, "frac_sum_of_overlapped_durations": overlapped / PEAK_BF16_TFLOPS,
+        "achieved_sum_of_overlapped_durations_tflops": overlapped, "frac_sum_of_overlapped_durations": overlapped / peak_tflops,
         "achieved_isolated_tflops": isolated,
         "conv_running_frac_of_timed_window": conv_union_ms / conv_span_ms if conv_span_ms > 0 else None,
         "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of event pairs
-        "traffic_note": "HBM bytes per conv launch from %s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes of this command)" % traffic_src,
+        "traffic_note": ("HBM bytes per conv launch from %s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes of this command)" % traffic_src) if traffic_src else None,
     }
 
+    out = None
     if rank == 0:
         out = {
-            "metric": "end-to-end frames/sec (detect+NMS+ReID+track), YOLOv5s 640px",
+            "metric": "end-to-end frames/sec (detect+NMS+ReID+track), YOLOv5s 640px" if args.workload == "s640-bf16" else
+                      "end-to-end frames/sec (detect+NMS+ReID+track), " + wl["desc"],
             "value": world * args.steps * B / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])",
-                       "frames_per_step": B, "frame_hw": [H, W], "num_classes": NC, "det_per_frame": ndet_total[0] / max(ndet_total[1], 1),
-                       "weights": "seeded synthetic (no checkpoints available)", "streams": world,
-                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(nrows_total[0]),
-                       "counting_postpass_ms_total": post_ms},
+            "dtype": wl["precision"], "data": "synthetic",
+            "config": {"workload": wl["desc"], "workload_id": args.workload,
+                       "frames_per_step": B, "frame_hw": [st.H, st.W], "clip_frames": st.clip, "objects": wl["n_obj"], "num_classes": NC,
+                       "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "detection_injection": bool(wl["inject"]),
+                       "weights": "seeded synthetic (no checkpoints available)", "streams": world, "ranks": world,
+                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(st.nrows),
+                       "counting_postpass_ms_total": post_ms, "tracker": "device-resident (one kernel per batch, no host round trip per frame)"},
             "roofline": roofline,
             "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+    ysd, rsd, frames = st.ysd, st.rsd, st.frames
+    eng.close()
+    del st
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.workload == "s640-bf16" and not args.no_extras:
+        # other operating points of SURVEY.md 8(d), short runs of the same pipeline (extra keys; `value` above is the headline)
+        out["extra_points"] = {
+            "K32_injected": quick_point(wl, rank, local, dev, world, n_obj=32, inject=32, clip=256),
+            "K256_injected": quick_point(wl, rank, local, dev, world, n_obj=256, inject=256, B=32, clip=128, steps=6),
+        }
+        hp = quick_point(wl, rank, local, dev, world, host=True, steps=12, warmup=3)
+        out["value_host_frames"] = hp["value"]
+        out["value_host_frames_note"] = "same workload with the frames in pinned host memory: every batch is copied over PCIe inside the timed region (vc_stream_submit_host, copy overlapped with the detector of the previous batch)"
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "s640-bf16":
             out["cpu_baseline"] = cpu_baseline(ysd, rsd, frames, args.cpu_frames)
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -155,6 +155,10 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
 /* vc_stream_submit enqueues the detector for a batch and returns at once (at most two outstanding); vc_stream_run consumes
  * submissions in order (submitting itself when none is pending), so `submit(i+1); run(i)` overlaps detect(i+1) with track(i). */
 int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w);
+/* The same for frames in (pinned) HOST memory, as the reference's loader delivers them (modules/datasets.py:47-61): the batch is copied
+ * to a device staging slot on the engine's copy stream, overlapped with the detector of the previous batch; *frames_dev_out is the
+ * device address to hand to vc_stream_run / vc_stream_run_async for this batch (valid until its rows have been collected). */
+int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out);
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);
 
@@ -165,8 +169,8 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
 int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                         int cap_rows_per_frame);
 int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b);
-/* Detection injection for throughput studies: replaces the detector's NMS output of the next
- * vc_stream_run frames with caller boxes after the conv stack has run. NULL clears. */
+/* Detection injection for throughput studies: replaces the detector's NMS output of the batches SUBMITTED from now on
+ * (vc_stream_submit / vc_stream_submit_host capture it) with caller boxes after the conv stack has run. NULL clears. */
 int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vc_stream_run": [_vp, _pi, _i, _vp, _i, _i, _i, _pl, _i, _pi, _pi],
     "vc_stream_inject": [_vp, _pf, _pi, _i, _i],
     "vc_stream_submit": [_vp, _vp, _i, _i, _i],
+    "vc_stream_submit_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],
     "vc_profile_enable": [_vp, _i],

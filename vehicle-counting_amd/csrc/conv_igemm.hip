@@ -895,14 +895,15 @@ double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * 
 // 16-wave workgroups on 256 x 256 tiles: half the staged bytes (and LDS-DMA instructions, ~150 issue cycles each) per MFMA of the
 // 128 x 128 tile and a 3- or 4-deep ring in 96 / 128 KB (measured per 128 frames: 3x3/s2 128->256 at 80^2 213 -> 169 us, 256->512
 // 202 -> 148 us, 1x1 512->512 at 20^2 67 -> 56 us; 256 x 128, 512 x 128 and 512 x 64 tiles with 8 / 16 waves gained nothing)
-#define VC_CONV_BIG_CFGS(X) X(40, 256, 256, 4, 4, 4, 2) X(41, 256, 256, 4, 4, 4, 3) X(42, 256, 256, 4, 4, 4, 4)
+// 43: the same tile on 128-byte rows (2 x 64 KB): the only 256 x 256 tile of the fp8 path (its K = 128 MFMA step needs KC = 8)
+#define VC_CONV_BIG_CFGS(X) X(40, 256, 256, 4, 4, 4, 2) X(41, 256, 256, 4, 4, 4, 3) X(42, 256, 256, 4, 4, 4, 4) X(43, 256, 256, 4, 4, 8, 2)
 struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
 // weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
 #define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 3; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35) and the 16-wave 256 x 256 tiles (40-42)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35) and the 16-wave 256 x 256 tiles (40-42)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 template <class K>

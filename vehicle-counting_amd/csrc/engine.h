@@ -121,6 +121,11 @@ struct vc_engine {
     int* h_det_count2[2] = {nullptr, nullptr};
     float* h_geom = nullptr;                     // pinned [2][max_batch][5]
     unsigned geom_seq = 0, submit_seq = 0;
+    // host-frame ingest (vc_stream_submit_host): copy stream + four device staging slots
+    hipStream_t cstream = nullptr;
+    uint8_t* d_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned ingest_seq = 0;
     // stream path: three feature / crop buffers -- the batch being tracked (possibly by the worker thread), the batch
     // whose ReID is running, and the one after it
     float* d_feat2[3] = {nullptr, nullptr, nullptr};
@@ -134,6 +139,7 @@ struct vc_engine {
         int fslot = 0;                   // feature / crop buffer of this batch
         std::vector<FrameDets> fd;       // per frame, as VideoTracker.run sees them
         std::vector<int> row0;           // first feature row of each frame
+        std::vector<float> inj_det; std::vector<int> inj_cnt; int inj_b = 0, inj_n = 0;   // detection injection captured at submit time
     };
     std::vector<Pending> pending;
     // asynchronous tracking (vc_stream_run_async / vc_stream_collect): a batch's tracker work is one kernel on the tracker stream;

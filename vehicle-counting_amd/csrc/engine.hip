@@ -727,6 +727,7 @@ int vc_engine_destroy(vc_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->dstream) hipStreamSynchronize(e->dstream);
     if (e->rstream) hipStreamSynchronize(e->rstream);
+    if (e->cstream) hipStreamSynchronize(e->cstream);
     for (void* p : e->allocs) hipFree(p);
     for (void* p : e->host_allocs) hipHostFree(p);
     for (auto& pp : e->prof_pairs) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
@@ -738,6 +739,8 @@ int vc_engine_destroy(vc_engine* e) {
     for (hipEvent_t ev : e->ev_det) if (ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_reid) if (ev) hipEventDestroy(ev);
     for (vc::TrackStage& ts : e->tstage) if (ts.done) hipEventDestroy(ts.done);
+    for (hipEvent_t ev : e->ev_ingest) if (ev) hipEventDestroy(ev);
+    if (e->cstream) hipStreamDestroy(e->cstream);
     delete e;
     return VC_OK;
 }

@@ -86,8 +86,38 @@ int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w) 
     VC_HIP(hipEventRecord(e->ev_det[slot], e->dstream));
     vc_engine::Pending pd{};
     pd.frames = frames_dev; pd.b = b; pd.h = h; pd.w = w; pd.slot = slot;
+    if (e->inject_b > 0) { pd.inj_det = e->inject_det; pd.inj_cnt = e->inject_count; pd.inj_b = e->inject_b; pd.inj_n = e->inject_n; }   // this batch's own rectangles
     e->pending.push_back(std::move(pd));
     return VC_OK;
+}
+
+// Ingest from host memory (the reference decodes on the host and hands numpy frames over, modules/datasets.py:47-61):
+// the batch is copied into one of four device staging slots on the engine's copy stream while the detector works on the batch
+// before it, and the detector is enqueued behind the copy.  *frames_dev_out receives the device address to pass to
+// vc_stream_run / vc_stream_run_async for this batch.  `frames_host` should be pinned (hipHostMalloc / hipHostRegister / torch
+// pin_memory) for the copy to overlap; it may be reused as soon as the call returns only if it is pinned AND the caller keeps
+// it untouched until the batch's rows have been collected -- plain pageable memory is copied synchronously by the runtime.
+int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out) {
+    VC_CHECK(e && frames_host && frames_dev_out, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "engine not finalized");
+    VC_CHECK(e->pending.size() < 2, VC_ERR_STATE, "two submissions are already in flight: call vc_stream_run first");
+    VC_CHECK(b >= 1 && b <= e->cfg.max_batch && h >= 1 && w >= 1 && h <= e->cfg.max_frame_h && w <= e->cfg.max_frame_w, VC_ERR_CAPACITY,
+             "batch of %d frames %dx%d exceeds max_batch / max_frame_h / max_frame_w", b, h, w);
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const size_t bytes = (size_t)b * h * w * 3, slot_bytes = (size_t)e->cfg.max_batch * e->cfg.max_frame_h * e->cfg.max_frame_w * 3;
+    if (!e->cstream) {
+        VC_HIP(hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) {
+            VC_TRY(dev_alloc(e, (void**)&e->d_ingest[i], slot_bytes));
+            VC_HIP(hipEventCreateWithFlags(&e->ev_ingest[i], hipEventDisableTiming));
+        }
+    }
+    const int slot = (int)(e->ingest_seq++ & 3);       // <= 2 submissions + <= 2 uncollected batches are alive: the fifth reuses the first's slot
+    VC_HIP(hipMemcpyAsync(e->d_ingest[slot], frames_host, bytes, hipMemcpyHostToDevice, e->cstream));
+    VC_HIP(hipEventRecord(e->ev_ingest[slot], e->cstream));
+    VC_HIP(hipStreamWaitEvent(e->dstream, e->ev_ingest[slot], 0));
+    *frames_dev_out = e->d_ingest[slot];
+    return vc_stream_submit(e, e->d_ingest[slot], b, h, w);
 }
 
 }  // extern "C"
@@ -103,11 +133,11 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
     pd.fd.assign(b, FrameDets{});
     pd.row0.assign(b, 0);
     for (int f = 0; f < b; ++f) {
-        VC_CHECK(h_cnt[f] >= 0 || e->inject_b > 0, VC_ERR_CAPACITY, "frame %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates", f,
+        VC_CHECK(h_cnt[f] >= 0 || pd.inj_b > 0, VC_ERR_CAPACITY, "frame %d: more than max_candidates (%d) boxes passed conf_thres; raise vc_engine_config.max_candidates", f,
                  e->cfg.max_candidates);
-        if (e->inject_b > 0) {
-            const int fi = f % e->inject_b;
-            marshal(e->inject_det.data() + (size_t)fi * e->inject_n * 6, e->inject_count[fi], pd.fd[f]);
+        if (pd.inj_b > 0) {
+            const int fi = f % pd.inj_b;
+            marshal(pd.inj_det.data() + (size_t)fi * pd.inj_n * 6, pd.inj_cnt[fi], pd.fd[f]);
         } else {
             marshal(h_det + (size_t)f * md * 6, h_cnt[f], pd.fd[f]);
         }

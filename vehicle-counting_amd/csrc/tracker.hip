@@ -100,7 +100,7 @@ int tracker_init_pool(vc_engine* e) {
     const int ctl[2] = {(int)T, 0};
     VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(ctl), hipMemcpyHostToDevice));
     // hoisted appearance dots (track_kernels.hip): table arena, row bookkeeping
-    e->dot_arena_floats = getenv("VC_DOT_ARENA_MB") ? (size_t)atol(getenv("VC_DOT_ARENA_MB")) * 262144 : (size_t)64 << 20;   // 256 MB by default
+    e->dot_arena_floats = getenv("VC_DOT_ARENA_MB") ? (size_t)atol(getenv("VC_DOT_ARENA_MB")) * 262144 : (size_t)256 << 20;   // 1 GB by default (288 GB of HBM)
     VC_TRY(dev_alloc(e, (void**)&e->d_dot_arena, e->dot_arena_floats * sizeof(float)));
     e->row_src_cap = (int)std::min<size_t>(T * S, (size_t)1 << 24);
     VC_TRY(dev_alloc(e, (void**)&e->d_row_src, (size_t)e->row_src_cap * sizeof(int)));

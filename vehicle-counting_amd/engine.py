@@ -246,6 +246,13 @@ class Engine:
         """Enqueue the detector for a batch (returns immediately); the matching stream_run consumes it."""
         L.check(L.lib().vc_stream_submit(self._h, C.c_void_p(frames_dev_ptr), b, h, w))
 
+    def stream_submit_host(self, frames_host_ptr, b, h, w):
+        """Enqueue the host-to-device copy of a batch of (pinned) host frames and the detector behind it; returns the device
+        address to pass to stream_run / stream_run_async for this batch."""
+        out = C.c_void_p()
+        L.check(L.lib().vc_stream_submit_host(self._h, C.c_void_p(frames_host_ptr), b, h, w, C.byref(out)))
+        return out.value
+
     def stream_inject(self, det6=None, counts=None):
         if det6 is None:
             L.check(L.lib().vc_stream_inject(self._h, None, None, 0, 0))
