@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 import vehicle_counting_amd.engine as E  # noqa: E402
 from vehicle_counting_amd import _lib as L  # noqa: E402
 from vehicle_counting_amd import parallel  # noqa: E402
-from vehicle_counting_amd.counting import count_directions, csv_records  # noqa: E402
+from vehicle_counting_amd.counting import NativeCounter, count_directions, csv_records  # noqa: E402
 from vehicle_counting_amd.synth import synth_frames, synth_tracks  # noqa: E402
 from vehicle_counting_amd.track import VideoCounting  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
@@ -124,7 +124,13 @@ class Stream:
         self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region
         self.clip = clip
         self.inject = injected_detections(clip, self.H, inject, 1702 + rank) if inject else None
-        self.counter = VideoCounting([str(c) for c in range(NC)], ZONE)
+        self.counter = VideoCounting([str(c) for c in range(NC)], ZONE)     # per-track box lists for the CSV artefact
+        self.ncounter = NativeCounter(ZONE, NC)                              # the count tensor behind the C ABI (vc_counter_* / vc_counts)
+        self.gather_via = None
+        try:                                                                 # bring the RCCL communicator up before anything is timed
+            parallel.allgather_counts_native(self.eng, np.zeros((1, len(self.ncounter.direction_keys), NC), np.int32))
+        except L.VcError as ex:
+            print(f"bench.py: vc_comm_init failed ({ex})", file=sys.stderr)
         self.ndet = [0, 0]
         self.nrows = 0
         self.host = None
@@ -158,8 +164,9 @@ class Stream:
             self.ndet[0] += int(nd.sum()); self.ndet[1] += self.B
             self.nrows += len(rows)
             # VideoCounting's zone filter + per-track lists for one batch, on the host while the GPU works on the next batches
-            self.counter.run((i * self.B + 1 + fidx).tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]),
-                             finalize=False)
+            fr = i * self.B + 1 + fidx
+            self.counter.run(fr.tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]), finalize=False)
+            self.ncounter.add(fr, rows[:, 4], rows[:, 5], rows[:, :4])
 
     def run_steps(self, first, n, record):
         """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker kernel of batch i
@@ -191,13 +198,23 @@ class Stream:
         t_post = time.perf_counter()
         td = self.counter.run([], [], [], np.zeros((0, 4), np.int64))      # every batch was appended as it was collected: directions only
         rows = csv_records(td)
-        dirs = list(self.counter.directions.keys())
-        local_counts = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)[None]
-        all_counts = parallel.allgather_counts(local_counts, device=self.dev if world > 1 else None)
+        local_counts = self.ncounter.counts()[None]                        # int32 [1 camera][n_dir][n_cls]
+        try:                                                               # the one collective: ncclAllGather on the engine's stream (C ABI)
+            all_counts = parallel.allgather_counts_native(self.eng, local_counts)
+            self.gather_via = "vc_allgather_counts (RCCL, C ABI)"
+        except L.VcError as ex:                                            # loud, recorded in the JSON line -- never silent
+            print(f"bench.py: C-ABI count all-gather failed ({ex}); using torch.distributed.all_gather", file=sys.stderr)
+            all_counts = parallel.allgather_counts(local_counts, device=self.dev if world > 1 else None)
+            self.gather_via = f"torch.distributed.all_gather (vc_allgather_counts failed: {ex})"
         self.sync(world)
         dt = time.perf_counter() - t0
         gc.enable()
-        return dt, (time.perf_counter() - t_post) * 1e3, all_counts
+        post_ms = (time.perf_counter() - t_post) * 1e3
+        dirs = list(self.counter.directions.keys())                         # outside the timed region: the two counters must agree
+        ref = parallel.counts_to_tensor(count_directions(rows, dirs, NC), dirs, NC)
+        if not np.array_equal(ref, local_counts[0]):
+            raise SystemExit("bench.py: vc_counts disagrees with VideoCounting + count_directions")
+        return dt, post_ms, all_counts
 
 
 def quick_point(wl, rank, local, dev, world, **kw):
@@ -321,7 +338,7 @@ def main():
                        "frames_per_step": B, "frame_hw": [st.H, st.W], "clip_frames": st.clip, "objects": wl["n_obj"], "num_classes": NC,
                        "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "detection_injection": bool(wl["inject"]),
                        "weights": "seeded synthetic (no checkpoints available)", "streams": world, "ranks": world,
-                       "counts_allgather_shape": list(all_counts.shape), "tracked_rows": int(st.nrows),
+                       "counts_allgather_shape": list(all_counts.shape), "counts_allgather_via": st.gather_via, "tracked_rows": int(st.nrows),
                        "counting_postpass_ms_total": post_ms, "tracker": "device-resident (one kernel per batch, no host round trip per frame)"},
             "roofline": roofline,
             "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},

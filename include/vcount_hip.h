@@ -173,6 +173,24 @@ int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, 
  * (vc_stream_submit / vc_stream_submit_host capture it) with caller boxes after the conv stack has run. NULL clears. */
 int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);
 
+/* ---- counting: VideoCounting.run + count_frame_directions, and the one collective of the multi-GPU design -------------------- */
+/* modules/track.py:81-137 (zone filter: any box corner inside the polygon; per (label, track) first / last box; direction =
+ * utilities/counting/utils.py:139-152 find_best_match_direction) and utilities/counting/utils.py:276-297 (count[direction][label] += 1
+ * at each track's last frame).  dir_lines: n_dir x (x0, y0, x1, y1) in the order of the zone file's direction shapes. */
+typedef struct vc_counter vc_counter;
+int vc_counter_create(const double* polygon_xy, int n_points, const double* dir_lines, int n_dir, int num_classes, vc_counter** out);
+int vc_counter_destroy(vc_counter* c);
+int vc_counter_add(vc_counter* c, const int64_t* frames, const int64_t* track_ids, const int64_t* labels, const int64_t* boxes_xyxy, int n);
+int vc_counter_tracks(const vc_counter* c, int* n);
+int vc_counts(const vc_counter* c, int32_t* out /* n_dir x num_classes */);
+/* One all-gather of the per-camera count tensors over RCCL / xGMI on the engine's stream.  Rank 0 creates the 128-byte
+ * id (vc_comm_unique_id) and hands it to the other ranks by any side channel (the Python shim broadcasts it with torch.distributed);
+ * every rank then calls vc_comm_init.  out receives world x n values, rank-major. */
+int vc_comm_unique_id(void* out128);
+int vc_comm_init(vc_engine* e, int rank, int world, const void* id128);
+int vc_comm_destroy(vc_engine* e);
+int vc_allgather_counts(vc_engine* e, const int32_t* local, int n, int32_t* out);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 #define VC_PROF_CONV 0       /* all implicit-GEMM conv launches */
 #define VC_PROF_DETECT_AUX 1 /* letterbox, pools, upsample, decode, NMS */

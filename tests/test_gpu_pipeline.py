@@ -99,3 +99,16 @@ def test_async_stream_same_rows_and_errors():
         np.testing.assert_array_equal(f0, f1)
         np.testing.assert_array_equal(r0, r1)
     eng.close()
+
+
+def test_count_allgather_through_the_c_abi():
+    """vc_comm_unique_id / vc_comm_init / vc_allgather_counts with one rank: RCCL on the engine's stream gathers the tensor with
+    itself (the N-rank path is the same calls with world > 1; the driver's scaling run exercises it)."""
+    from vehicle_counting_amd import parallel
+    eng = E.Engine(None, synth_reid(1702), precision="bf16", max_crops=8, max_frame_hw=(64, 64), max_tracks=16, nn_budget_cap=4)
+    x = np.arange(2 * 3 * 5, dtype=np.int32).reshape(2, 3, 5)
+    out = parallel.allgather_counts_native(eng, x)
+    np.testing.assert_array_equal(out, x)
+    out = parallel.allgather_counts_native(eng, x + 7)           # communicator is reused
+    np.testing.assert_array_equal(out, x + 7)
+    eng.close()

@@ -159,3 +159,32 @@ def test_fold_yolo_state_dict_roundtrip():
                    sd["model.3.bn.running_var"], 1e-3)
     np.testing.assert_array_equal(f["model.3.conv.weight"], w)
     np.testing.assert_array_equal(f["model.24.m.1.bias"], sd["model.24.m.1.bias"])
+
+
+def test_native_counter_equals_videocounting(golden_dir):
+    """vc_counter_* / vc_counts (C ABI) against the Python VideoCounting + count_directions on the reference's own zone file:
+    random integer boxes and track ids fed in two batches, zero-length tracks (first == last box) included."""
+    from vehicle_counting_amd.counting import NativeCounter, count_directions, csv_records
+    from vehicle_counting_amd.track import VideoCounting
+    zone = os.path.join(golden_dir, "cam_04.json")
+    rng = np.random.default_rng(5)
+    nc, n = 4, 3000
+    frames = np.sort(rng.integers(1, 200, n))
+    tracks = rng.integers(1, 60, n)
+    labels = rng.integers(0, nc, n)
+    x1, y1 = rng.integers(0, 1200, n), rng.integers(0, 650, n)
+    boxes = np.stack([x1, y1, x1 + rng.integers(5, 120, n), y1 + rng.integers(5, 120, n)], 1).astype(np.int64)
+    boxes[:40] = boxes[0]                                        # many rows of one stationary track: direction vector (0, 0)
+    tracks[:40], labels[:40] = 7, 1
+    vcn = VideoCounting([str(i) for i in range(nc)], zone)
+    td = vcn.run(frames.tolist(), tracks.tolist(), labels.tolist(), boxes)
+    rows = csv_records(td)
+    dirs = list(vcn.directions.keys())
+    ref = np.array([count_directions(rows, dirs, nc)[d] for d in dirs], np.int32)
+    nat = NativeCounter(zone, nc)
+    assert nat.direction_keys == dirs
+    nat.add(frames[:1700], tracks[:1700], labels[:1700], boxes[:1700])
+    nat.add(frames[1700:], tracks[1700:], labels[1700:], boxes[1700:])
+    np.testing.assert_array_equal(nat.counts(), ref)
+    assert ref.sum() > 100
+    nat.close()

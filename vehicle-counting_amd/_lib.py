@@ -83,6 +83,15 @@ SIGNATURES = {
     "vc_stream_submit_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],
+    "vc_counter_create": [_pd, _i, _pd, _i, _i, _P(_vp)],
+    "vc_counter_destroy": [_vp],
+    "vc_counter_add": [_vp, _pl, _pl, _pl, _pl, _i],
+    "vc_counter_tracks": [_vp, _pi],
+    "vc_counts": [_vp, _pi],
+    "vc_comm_unique_id": [_vp],
+    "vc_comm_init": [_vp, _i, _i, _vp],
+    "vc_comm_destroy": [_vp],
+    "vc_allgather_counts": [_vp, _pi, _i, _pi],
     "vc_profile_enable": [_vp, _i],
     "vc_profile_conv_busy": [_vp, _pd, _pd],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],

@@ -150,3 +150,52 @@ def count_directions(rows, direction_keys, num_classes):
         if r["lframe"] == r["frame_id"]:
             counts[r["direction"]][r["label"]] += 1
     return counts
+
+
+class NativeCounter:
+    """VideoCounting's end state behind the C ABI (vc_counter_* / vc_counts): zone filter, per-track first / last box, direction
+    assignment and the per-(direction, class) counts, fed batch by batch.  Same arithmetic as the functions above; the full
+    track_dict / CSV (with every box of every track) stays with VideoCounting -- this is the tensor the all-gather merges."""
+
+    def __init__(self, zone_path, num_classes):
+        import ctypes as C
+
+        from . import _lib as L
+        polygon, directions = load_zone_anno(zone_path)
+        self.direction_keys = list(directions.keys())
+        self.num_classes = num_classes
+        poly = np.ascontiguousarray(np.asarray(polygon, np.float64).reshape(-1, 2))
+        lines = np.ascontiguousarray(np.asarray([directions[k] for k in self.direction_keys], np.float64).reshape(-1, 4))
+        self._h = C.c_void_p()
+        L.check(L.lib().vc_counter_create(L.ptr(poly, C.c_double), len(poly), L.ptr(lines, C.c_double), len(lines), num_classes, C.byref(self._h)))
+
+    def add(self, frames, tracks, labels, boxes):
+        import ctypes as C
+
+        from . import _lib as L
+        f = np.ascontiguousarray(frames, dtype=np.int64).reshape(-1)
+        t = np.ascontiguousarray(tracks, dtype=np.int64).reshape(-1)
+        lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
+        b = np.ascontiguousarray(boxes, dtype=np.int64).reshape(-1, 4)
+        L.check(L.lib().vc_counter_add(self._h, L.ptr(f, C.c_int64), L.ptr(t, C.c_int64), L.ptr(lab, C.c_int64), L.ptr(b, C.c_int64), len(f)))
+
+    def counts(self):
+        """int32 (n_dir, n_cls), rows in the order of the zone file's direction shapes."""
+        import ctypes as C
+
+        from . import _lib as L
+        out = np.zeros((len(self.direction_keys), self.num_classes), np.int32)
+        L.check(L.lib().vc_counts(self._h, L.ptr(out, C.c_int)))
+        return out
+
+    def close(self):
+        from . import _lib as L
+        if self._h:
+            L.lib().vc_counter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

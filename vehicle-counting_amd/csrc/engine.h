@@ -177,6 +177,10 @@ struct vc_engine {
     float* d_feat_in = nullptr;                  // features handed in from the host (vc_tracker_step)
     int det_cap = 0;
 
+    // ---- count all-gather (counting.hip): RCCL communicator of the engine's process group ----------------------
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+    void* d_comm_buf = nullptr; size_t comm_buf_bytes = 0;
+
     // ---- measurement ----------------------------------------------------------------------------------
     bool profiling = false;
     // in-flight conv profiling (vc_profile_enable(e, 2)): event pairs recorded on the launch stream WITHOUT synchronising, so the

@@ -724,6 +724,7 @@ int vc_engine_destroy(vc_engine* e) {
     if (!e) return VC_OK;
     tune_cache_save(e);
     hipSetDevice(e->cfg.device);
+    vc_comm_destroy(e);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->dstream) hipStreamSynchronize(e->dstream);
     if (e->rstream) hipStreamSynchronize(e->rstream);

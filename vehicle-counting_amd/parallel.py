@@ -49,6 +49,44 @@ def allgather_counts(local_counts, device=None):
     return torch.cat(out, 0).cpu().numpy()
 
 
+def allgather_counts_native(engine, local_counts):
+    """The same all-gather through the C ABI (vc_comm_init / vc_allgather_counts: ncclAllGather on the engine's stream, RCCL over
+    xGMI).  The 128-byte RCCL id travels over the torch.distributed group the ranks already share; a single process gathers with
+    itself.  Returns int32 (world * n_cam_local, n_dir, n_cls), rank-major."""
+    import ctypes as C
+
+    from . import _lib as L
+    t = np.ascontiguousarray(local_counts, dtype=np.int32)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if not getattr(engine, "_comm_ready", False):
+        # RCCL prints a version banner on stdout when it is first used in a process: keep stdout clean for callers that print
+        # machine-readable lines (bench.py's one JSON line) by pointing fd 1 at stderr while the communicator comes up
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            idbuf = (C.c_ubyte * 128)()
+            if rank == 0:
+                L.check(L.lib().vc_comm_unique_id(idbuf))
+            if world > 1:
+                obj = [bytes(idbuf)]
+                dist.broadcast_object_list(obj, src=0)
+                idbuf = (C.c_ubyte * 128).from_buffer_copy(obj[0])
+            L.check(L.lib().vc_comm_init(engine._h, rank, world, idbuf))
+            warm = np.zeros(1, np.int32)                                  # first collective of the communicator (lazy set-up inside RCCL)
+            L.check(L.lib().vc_allgather_counts(engine._h, L.ptr(warm, C.c_int), 1, L.ptr(np.zeros(world, np.int32), C.c_int)))
+        finally:
+            C.CDLL(None).fflush(None)                                     # the banner sits in libc's stdout buffer: flush it while fd 1 is stderr
+            os.dup2(saved, 1)
+            os.close(saved)
+        engine._comm_ready = True
+    out = np.zeros((world,) + t.shape, np.int32)
+    L.check(L.lib().vc_allgather_counts(engine._h, L.ptr(t.reshape(-1), C.c_int), t.size, L.ptr(out.reshape(-1), C.c_int)))
+    return out.reshape((world * t.shape[0],) + t.shape[1:])
+
+
 def shard_streams(n_streams, rank, world):
     """Stream i is owned by rank i % world (whole streams only: tracker state never shards below a camera)."""
     return [i for i in range(n_streams) if i % world == rank]
