@@ -8,7 +8,7 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 rows = list(c.execute(f"select start, end, name, {qcol or '0'} from kernels order by start"))
 t0, t1 = rows[0][0], rows[-1][1]
 # steady state = between the 30th and 70th percentile of the tracker launches (the timed steps of bench.py)
-tk = [r[0] for r in rows if "track_step_kernel" in r[2]]
+tk = [r[0] for r in rows if "track_batch_kernel" in r[2]]
 lo, hi = tk[int(len(tk) * 0.3)], tk[int(len(tk) * 0.7)]
 sel = [r for r in rows if r[0] >= lo and r[1] <= hi]
 def union(iv):
