@@ -169,6 +169,60 @@ VC_HD int lsap_core(Lanes L, int nr, int nc, const double* cost, const LapWork& 
     return 0;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same solver for problems with at most 64 rows and 64 columns, state in registers: lane j owns column j (v, spc, path,
+// row4col, its position in the `remaining` list, SC) and lane i owns row i (u, col4row, SR); scalars move with wave shuffles, the
+// cost matrix is read from `cost` (LDS for the small problems this is used for).  Same scan order, same tie-breaking, same dual
+// updates as lsap_core above (remaining[it] = nc - it - 1 initially, swap-remove on selection), hence the same assignment; what
+// it saves are the LDS round trips and wave-level synchronisations between the dependent steps of the search.
+__device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const double* cost, int* col4row_out) {
+    const double INF = (double)INFINITY;
+    double u = 0.0, v = 0.0;
+    int col4row = -1, row4col = -1, path = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0, spc = INF;
+        int i = cur, num_remaining = nc, sink = -1;
+        int pos = lane < nc ? nc - 1 - lane : -1;          // column `lane` sits at list position nc - 1 - lane
+        bool SR = false, SC = false;
+        while (sink == -1) {
+            if (lane == i) SR = true;
+            const double ui = __shfl(u, i);
+            Best b = {INF, 0, INT_MAX};
+            if (pos >= 0) {
+                const double r = minVal + cost[(size_t)i * nc + lane] - ui - v;
+                if (r < spc) { path = i; spc = r; }
+                b.v = spc; b.un = row4col == -1 ? 1 : 0; b.it = pos;
+            }
+            const Lanes L{lane, 64};
+            b = wave_best(L, b);
+            minVal = b.v;
+            if (minVal == INF) return -1;
+            const int jstar = __ffsll((unsigned long long)__ballot(pos == b.it && pos >= 0)) - 1;
+            const int rj = __shfl(row4col, jstar);
+            if (pos == num_remaining - 1) pos = b.it;      // swap-remove: the list's last entry takes the freed position ...
+            if (lane == jstar) { pos = -1; SC = true; }    // ... and the chosen column leaves the list
+            --num_remaining;
+            if (rj == -1) sink = jstar; else i = rj;
+        }
+        const double spc_of_my_col = __shfl(spc, col4row >= 0 ? col4row : 0);
+        if (lane == cur) u += minVal;
+        else if (SR && lane < nr) u += minVal - spc_of_my_col;
+        if (SC) v -= minVal - spc;
+        int j = sink;                                        // augment along the alternating path
+        while (true) {
+            const int r = __shfl(path, j);
+            const int prev = __shfl(col4row, r);
+            if (lane == j) row4col = r;
+            if (lane == r) col4row = j;
+            j = prev;
+            if (r == cur) break;
+        }
+    }
+    if (lane < nr) col4row_out[lane] = col4row;
+    return 0;
+}
+#endif
+
 // per-step work arrays (LDS on the device), each with room for `cap` entries
 struct StepWork {
     int cap;
@@ -222,6 +276,10 @@ VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc,
             tbuf[(size_t)j * nr + i] = c[e];
         }
         wave_sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (nr <= 64) { if (lsap_core_wave64(L.lane, nc, nr, tbuf, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
+        else
+#endif
         if (lsap_core(L, nc, nr, tbuf, w.lap) != 0) { err = TERR_LAP; return 0; }
         int* r2c = w.lap.path;                               // free again after the solve: original row -> original column
         for (int i = L.lane; i < nr; i += L.n) r2c[i] = -1;
@@ -232,6 +290,10 @@ VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc,
         wave_sync();
         return np;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nc <= 64) { if (lsap_core_wave64(L.lane, nr, nc, c, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
+    else
+#endif
     if (lsap_core(L, nr, nc, c, w.lap) != 0) { err = TERR_LAP; return 0; }
     for (int i = L.lane; i < nr; i += L.n) { w.ri[i] = i; w.ci[i] = w.lap.col4row[i]; }
     wave_sync();
@@ -276,8 +338,17 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
 // Tracker._match on the step's cost rows (cost_app: gated appearance rows of the confirmed tracks, cost_iou: IoU rows of the IoU
 // candidates; both [T][D], rows of other tracks are never read).  Outputs: matches in w.match_t / w.match_d, missed tracks in
 // w.un_tracks, the detections that start new tracks in *newdets (one of w.left / w.un_cols), all in the reference's list order.
+VC_HD long long tc_clock() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return wall_clock64();
+#else
+    return 0;
+#endif
+}
+
 VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, int D, const double* cost_app, const double* cost_iou,
-                      double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err) {
+                      double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err, long long* prof = nullptr) {
+    if (prof && L.lane == 0) prof[0] = tc_clock();
     const int n_conf = compact(L, T, [&](int t) { return w.state[t] == CONFIRMED; }, [&](int pos, int t) { w.confirmed[pos] = t; });
     const int n_unconf = compact(L, T, [&](int t) { return w.state[t] != CONFIRMED; }, [&](int pos, int t) { w.unconfirmed[pos] = t; });
     int mt = 0;
@@ -289,6 +360,7 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
     int* other = w.un_cols;
     int n_left = D;
     n_match = 0;
+    if (prof && L.lane == 0) prof[1] = tc_clock();
     // matching_cascade: level = time_since_update - 1, most recently seen tracks first.  Only the levels that hold a track are
     // visited (a 64-bit presence mask for the first 64 levels, a plain scan above).
     unsigned long long lm = 0;
@@ -334,6 +406,7 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
         n_left = n_uc;
         wave_sync();
     }
+    if (prof && L.lane == 0) prof[2] = tc_clock();
     // IoU stage (tracker.py:118-127): unconfirmed tracks + confirmed tracks that were missed for exactly one frame
     for (int q = L.lane; q < n_unconf; q += L.n) w.rows[q] = w.unconfirmed[q];
     const int n_recent = compact(L, n_conf, [&](int q) { const int t = w.confirmed[q]; return !w.matched[t] && w.tsu[t] == 1; },
@@ -349,6 +422,7 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
     newdets = other;
     n_new = n_uc;
     wave_sync();
+    if (prof && L.lane == 0) prof[3] = tc_clock();
 }
 
 // Track.update / mark_missed / _initiate_track bookkeeping + Tracker.update's list maintenance, after the Kalman and gallery

@@ -414,6 +414,9 @@ extern __shared__ __attribute__((aligned(16))) char track_dyn_lds[];
 
 __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a) {
     __shared__ TrackShared sh;
+    // Serial, latency-bound work next to the detector's MFMA-heavy waves on the same CUs: highest issue priority, so that a step's
+    // chain of dependent instructions does not queue behind them (the tracker's ~50 workgroups take a negligible share of issue slots)
+    __builtin_amdgcn_s_setprio(3);
     // Work arrays: in LDS for steps with up to a.cap tracks + detections (what the host expects from the trackers' recent sizes),
     // in the workgroup's global scratch for the rare larger step (same code, L2 latency instead of LDS latency) up to TC_HARD_CAP.
     StepWork w_lds, w_glb;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
     const Lanes L{lane, 64};
     const TrackPool& tp = a.pool;
 
-#define VC_TTS(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)task * 8 + (i)] = wall_clock64(); } while (0)
+#define VC_TTS(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)task * 16 + (i)] = wall_clock64(); } while (0)
     for (int task = plan.task_begin; task < plan.task_end; ++task) {
         VC_TTS(0);
         const TrackTask tk = a.tasks[task];
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
         if (wave == 0) {
             int n_match = 0, n_un = 0, n_new = 0, err = TERR_NONE;
             int* newdets = nullptr;
-            match_step(L, w, *hdr, T, D, cost_app, cost_iou, cbuf, tbuf, n_match, n_un, newdets, n_new, err);
+            match_step(L, w, *hdr, T, D, cost_app, cost_iou, cbuf, tbuf, n_match, n_un, newdets, n_new, err, a.dbg ? a.dbg + (size_t)task * 16 + 8 : nullptr);
             if (err == TERR_NONE && n_new > 0 && !pool_take(a, n_new, w.newslot, lane)) err = TERR_POOL;
             if (lane == 0) { sh.ctl[0] = n_match; sh.ctl[1] = n_un; sh.ctl[2] = n_new; sh.ctl[3] = newdets == w.left ? 1 : 0; sh.ctl[4] = err; }
         }
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
         }
         __syncthreads();
         VC_TTS(5);
-        if (a.dbg && threadIdx.x == 0) { a.dbg[(size_t)task * 8 + 6] = T; a.dbg[(size_t)task * 8 + 7] = D; }
+        if (a.dbg && threadIdx.x == 0) { a.dbg[(size_t)task * 16 + 6] = T; a.dbg[(size_t)task * 16 + 7] = D; }
     }
 #undef VC_TTS
 }

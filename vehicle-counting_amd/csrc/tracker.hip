@@ -275,13 +275,13 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back
     static const bool dbg_on = getenv("VC_TRACK_DBG") != nullptr;        // diagnostics: phase times of every task, printed per batch
     long long* dbg = nullptr;
-    if (dbg_on && hipMalloc((void**)&dbg, (size_t)n_tasks * 64) == hipSuccess) { hipMemsetAsync(dbg, 0, (size_t)n_tasks * 64, ts); a.dbg = dbg; }
+    if (dbg_on && hipMalloc((void**)&dbg, (size_t)n_tasks * 128) == hipSuccess) { hipMemsetAsync(dbg, 0, (size_t)n_tasks * 128, ts); a.dbg = dbg; }
     {
         ProfScope ps(e, VC_PROF_TRACK);
         VC_TRY(launch_track_batch(a, n_wg, ts));
     }
     if (dbg) {
-        std::vector<long long> h((size_t)n_tasks * 8);
+        std::vector<long long> h((size_t)n_tasks * 16);
         hipStreamSynchronize(ts);
         hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         hipFree(dbg);
@@ -289,15 +289,15 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         int maxwg = 0;
         for (const TrackWgPlan& pl : plans) maxwg = std::max(maxwg, pl.task_end - pl.task_begin);
         for (int k = 0; k < n_tasks; ++k) {
-            for (int i = 0; i < 5; ++i) acc[i] += (double)(h[(size_t)k * 8 + i + 1] - h[(size_t)k * 8 + i]) / 100.0;
-            sumT += (double)h[(size_t)k * 8 + 6]; sumD += (double)h[(size_t)k * 8 + 7];
+            for (int i = 0; i < 5; ++i) acc[i] += (double)(h[(size_t)k * 16 + i + 1] - h[(size_t)k * 16 + i]) / 100.0;
+            sumT += (double)h[(size_t)k * 16 + 6]; sumD += (double)h[(size_t)k * 16 + 7];
         }
         fprintf(stderr, "[vc track dbg] %d tasks in %d workgroups (longest %d tasks), LDS cap %d; us per task: predict %.1f cost %.1f match %.1f apply %.1f finish %.1f; mean T %.1f D %.1f\n",
                 n_tasks, n_wg, maxwg, cap, acc[0] / n_tasks, acc[1] / n_tasks, acc[2] / n_tasks, acc[3] / n_tasks, acc[4] / n_tasks, sumT / n_tasks, sumD / n_tasks);
         long long t_lo = INT64_MAX, t_hi = 0;
         double worst = 0; const TrackWgPlan* wp = nullptr;
         for (const TrackWgPlan& pl : plans) {
-            const long long b0 = h[(size_t)pl.task_begin * 8], b1 = h[(size_t)(pl.task_end - 1) * 8 + 5];
+            const long long b0 = h[(size_t)pl.task_begin * 16], b1 = h[(size_t)(pl.task_end - 1) * 16 + 5];
             t_lo = std::min(t_lo, b0); t_hi = std::max(t_hi, b1);
             if ((double)(b1 - b0) > worst) { worst = (double)(b1 - b0); wp = &pl; }
         }
@@ -305,10 +305,14 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
             double a2[5] = {0, 0, 0, 0, 0}, sT = 0, sD = 0, gaps = 0;
             const int nt = wp->task_end - wp->task_begin;
             for (int k = wp->task_begin; k < wp->task_end; ++k) {
-                for (int i = 0; i < 5; ++i) a2[i] += (double)(h[(size_t)k * 8 + i + 1] - h[(size_t)k * 8 + i]) / 100.0;
-                sT += (double)h[(size_t)k * 8 + 6]; sD += (double)h[(size_t)k * 8 + 7];
-                if (k > wp->task_begin) gaps += (double)(h[(size_t)k * 8] - h[(size_t)(k - 1) * 8 + 5]) / 100.0;
+                for (int i = 0; i < 5; ++i) a2[i] += (double)(h[(size_t)k * 16 + i + 1] - h[(size_t)k * 16 + i]) / 100.0;
+                sT += (double)h[(size_t)k * 16 + 6]; sD += (double)h[(size_t)k * 16 + 7];
+                if (k > wp->task_begin) gaps += (double)(h[(size_t)k * 16] - h[(size_t)(k - 1) * 16 + 5]) / 100.0;
             }
+            double mp[3] = {0, 0, 0};
+            for (int k = wp->task_begin; k < wp->task_end; ++k)
+                for (int i = 0; i < 3; ++i) mp[i] += (double)(h[(size_t)k * 16 + 9 + i] - h[(size_t)k * 16 + 8 + i]) / 100.0;
+            fprintf(stderr, "[vc track dbg]   match split of that workgroup, us per task: setup %.1f cascade %.1f iou stage %.1f\n", mp[0] / nt, mp[1] / nt, mp[2] / nt);
             fprintf(stderr, "[vc track dbg]   kernel span %.0f us; slowest workgroup (tracker %d): %d tasks, %.0f us, per task predict %.1f cost %.1f match %.1f apply %.1f finish %.1f gap %.1f; mean T %.1f D %.1f\n",
                     (double)(t_hi - t_lo) / 100.0, wp->tracker, nt, worst / 100.0, a2[0] / nt, a2[1] / nt, a2[2] / nt, a2[3] / nt, a2[4] / nt, gaps / nt, sT / nt, sD / nt);
         }
