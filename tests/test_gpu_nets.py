@@ -132,3 +132,25 @@ def test_embed_crops(frames, precision):
     else:
         assert (y * ref).sum(1).min() >= 0.999
     eng.close()
+
+
+@pytest.mark.parametrize("hw", [(640, 640), (360, 640), (480, 352)])
+def test_front_fused_layers_0_1_bit_identical(hw):
+    """front_fused.hip (stem + 3x3/s2 conv in one kernel, layer 0 kept in LDS; used by the stream path on u8 frames) against the
+    two separate launches of vc_detect on the same frames: layer 1 identical bit for bit, letterbox padding rows included."""
+    import torch
+    H, W = hw
+    nc = 8
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0)
+    fr = synth_frames(3, H, W, n_obj=6, seed=5)
+    eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=3, max_frame_hw=(H, W))
+    eng.detect([f[:, :, ::-1] for f in fr])                      # host RGB frames: letterbox kernel + stem kernel + conv kernel
+    a1, a2 = eng.debug_layer(1, batch=3), eng.debug_layer(2, batch=3)
+    dev = torch.from_numpy(fr).cuda()
+    eng.stream_submit(dev.data_ptr(), 3, H, W)                    # device BGR frames: letterbox + layers 0 and 1 in front_fused_kernel
+    eng.sync()
+    b1, b2 = eng.debug_layer(1, batch=3), eng.debug_layer(2, batch=3)
+    assert a1.shape == b1.shape and np.abs(a1).max() > 0.5
+    np.testing.assert_array_equal(a1, b1)
+    np.testing.assert_array_equal(a2, b2)
+    eng.close()

@@ -112,3 +112,44 @@ def test_count_allgather_through_the_c_abi():
     out = parallel.allgather_counts_native(eng, x + 7)           # communicator is reused
     np.testing.assert_array_equal(out, x + 7)
     eng.close()
+
+
+def test_host_frames_ingest_same_rows():
+    """vc_stream_submit_host (pinned host frames copied on the engine's copy stream, four staging slots) returns exactly the rows
+    of the device-resident path, batch after batch, with the copies of later batches overlapping the work of earlier ones."""
+    import torch
+    B, H, W, NB = 8, 360, 640, 6
+    frames = synth_frames(B * NB, H, W, n_obj=8, seed=13)
+    ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+    out = {}
+    for mode in ("device", "host"):
+        eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W), max_crops=B * 64, max_tracks=2048, nn_budget_cap=60)
+        trk = [eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
+               for _ in range(NC)]
+        dev = torch.from_numpy(frames).cuda()
+        host = torch.from_numpy(frames).pin_memory()
+        ptrs = {}
+
+        def submit(i):
+            if mode == "host":
+                ptrs[i] = eng.stream_submit_host(host[i * B:(i + 1) * B].data_ptr(), B, H, W)
+            else:
+                ptrs[i] = dev[i * B:(i + 1) * B].data_ptr()
+                eng.stream_submit(ptrs[i], B, H, W)
+
+        got = []
+        submit(0)
+        for i in range(NB):
+            if i + 1 < NB:
+                submit(i + 1)
+            eng.stream_run_async(trk, ptrs[i], B, H, W)
+            if i > 0:
+                got.append(eng.stream_collect())
+        got.append(eng.stream_collect())
+        out[mode] = got
+        eng.close()
+    assert sum(len(r[0]) for r in out["device"]) > 20
+    for (r0, f0, n0), (r1, f1, n1) in zip(out["device"], out["host"]):
+        np.testing.assert_array_equal(n0, n1)
+        np.testing.assert_array_equal(f0, f1)
+        np.testing.assert_array_equal(r0, r1)

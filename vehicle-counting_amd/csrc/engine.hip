@@ -440,7 +440,20 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 conv_timer_arm(e, cp, fl, by);
                 if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only the u8 stem can run it
                     VC_CHECK(stem_direct_on && stem_u8_applicable(cp, e->stem_geom), VC_ERR_STATE, "letterbox fold-in: the direct stem does not apply");
-                if (stem_direct_on && stem_direct_applicable(cp)) {          // YOLO stem, bf16: direct convolution (stem_direct.hip)
+                static const int front_fused_mode = getenv("VC_FRONT_FUSED") ? atoi(getenv("VC_FRONT_FUSED")) : 1;   // 0 off, 1 stream path, 2 always
+                const bool fuse_front = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv) &&
+                                        (front_fused_mode == 2 || (e->stem_src && cp.in == e->ybuf["in"].ptr));
+                if (fuse_front) {                                             // YOLO layers 0 + 1 in one kernel (front_fused.hip): layer 0 never reaches HBM
+                    const Op& o1 = *nx;
+                    const double fl1 = 2.0 * o1.conv.M * (double)o1.conv.Cout * o1.C;
+                    const double by01 = ((double)cp.B * cp.H * cp.W * cp.Cin + (double)cp.Cout * cp.K + (double)o1.conv.Cout * o1.conv.K) * es + (double)o1.conv.M * o1.conv.Cout * es;
+                    cp.cfg = 102;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = fl + fl1; e->prof_pairs[e->prof_used - 1].bytes = by01; }   // the pair armed above now times both layers
+                    ProfScope ps(e, VC_PROF_CONV, fl + fl1, by01, s);
+                    const bool u8 = e->stem_src && cp.in == e->ybuf["in"].ptr;
+                    VC_TRY(launch_front_fused(cp, o1.conv, u8 ? e->stem_src : nullptr, e->stem_geom, s));
+                    ++oi;                                                     // the 3x3 conv is done
+                } else if (stem_direct_on && stem_direct_applicable(cp)) {   // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                     if (e->stem_src && cp.in == e->ybuf["in"].ptr) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s));   // letterbox folded in

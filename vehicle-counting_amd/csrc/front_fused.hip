@@ -1,0 +1,252 @@
+// YOLOv5 layers 0 + 1 in one kernel (bf16): the 6x6 / stride-2 stem and the 3x3 / stride-2 conv that follows it
+// (models/yolov5s.yaml v6.0: [-1, 1, Conv, [64, 6, 2, 2]], [-1, 1, Conv, [128, 3, 2]] at width 0.5 -> 32 and 64 channels), reached
+// from /root/reference/networks/yolo.py:70.
+//
+// Unfused, the stem's output (B x 320 x 320 x 32 bf16 = 839 MB per 128 frames) is written to HBM and read straight back: both
+// layers sit on the HBM roof and together move 2.3 GB per 128 frames.  Here a workgroup owns a 16 x 16 tile of layer-1 output,
+// computes the 33 x 33 layer-0 pixels it needs (halo recomputed: +6 % stem FLOPs) into LDS and convolves them from there:
+// HBM traffic = the u8 frames in (157 MB) + layer 1 out (419 MB).  Eight waves (two per SIMD) share one 16 x 16 output tile: the stem's
+// weights live in registers (32 x 160 -> 10 fragments), the conv's (64 x 288 -> 36 fragments) in LDS in fragment order, the patch
+// of the next tile travels through registers while the current tile is computed (as in stem_direct.hip).
+//
+// Layer-0 tile in LDS: two planes by column parity (the stride-2 taps of one output row then read 16 CONSECUTIVE pixels of a plane),
+// 64 bytes per pixel, 16-byte chunks XOR-swizzled with conv3x3_halo_kernel's formula (conflict-free for any base pixel).
+// MFMA operand order and k order equal conv_igemm_kernel's for both layers: bit-identical to the unfused path.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace vc {
+
+typedef float f32x4f __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
+union ChunkF { uint4 u; bf16x8f h; };
+
+#define FF_TH 16                  // layer-1 output tile
+#define FF_NW 8                   // waves per workgroup
+#define FF_TW 16
+#define FF_RH (2 * FF_TH + 1)     // layer-0 region rows (33)
+#define FF_PW (FF_TW + 1)         // layer-0 pixels per parity plane row (17: columns 0, 2, .., 32 / 1, 3, .., 31 + one unused)
+#define FF_PLANE (FF_RH * FF_PW)  // 561
+#define FF_NPIX (2 * FF_PLANE)    // 1122 layer-0 pixel slots
+#define FF_NT0 ((FF_NPIX + 15) / 16)   // 71 stem pixel tiles
+#define FF_PR (2 * FF_RH + 4)     // input patch rows (70)
+#define FF_PC (2 * FF_TW + 1 + 2) // input patch pixel pairs per row (35)
+#define FF_PP 36                  // LDS row pitch of the patch in 16-byte chunks
+
+__device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
+
+template <bool U8>
+__global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
+                                                             const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
+                                                             int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
+                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g) {
+    __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
+    __shared__ uint4 l0t[FF_NT0 * 16 * 4];                 // 72.7 KB: [pixel slot][4 chunks], swizzled
+    __shared__ uint4 w1s[9 * 4 * 64];                      // 36.9 KB: layer-1 weights, [tap][channel tile][lane] = one fragment load per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    // weights in registers for the whole launch
+    ChunkF wf0[5][2];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) wf0[s][ct].u = w0[(size_t)(ct * 16 + col) * kw8_0 + 4 * s + kq];
+    for (int i = threadIdx.x; i < 9 * 4 * 64; i += FF_NW * 64) {     // fragment (tap t, channel tile ct) of lane l = chunk 4t + l/16 of channel 16ct + l%16
+        const int l = i & 63, ct = (i >> 6) & 3, t = i >> 8;
+        w1s[i] = w1[(size_t)(ct * 16 + (l & 15)) * kw8_1 + 4 * t + (l >> 4)];
+    }
+    float4 bv0[2], bv1[4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bv0[ct] = *(const float4*)(b0 + ct * 16 + kq * 4);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv1[ct] = *(const float4*)(b1 + ct * 16 + kq * 4);
+    int koff[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int q = min(4 * s + kq, 17);                  // padded chunks multiply zero weights
+        koff[s] = (q / 3) * FF_PP + (q % 3);
+    }
+    const int ntiles = B * tiles_y * tiles_x;
+    constexpr int NT = FF_NW * 64;
+    constexpr int NPRE = (FF_PR * FF_PC + NT - 1) / NT;    // 5 chunks per thread
+    uint4 pre[NPRE];
+    auto fetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int gy0 = 2 * ty * FF_TH - 1, gx0 = 2 * tx * FF_TW - 1;          // first layer-0 row / column of the region
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * NT;
+            const int pr = i / FF_PC, pc = i - pr * FF_PC;
+            const int iy = 2 * gy0 - 2 + pr, ip = gx0 - 1 + pc;
+            pre[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < FF_PR * FF_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
+                if constexpr (!U8) {
+                    pre[k] = x[((size_t)b * H + iy) * Wp + ip];
+                } else {
+                    const int uy = iy - g.top, ux = 2 * ip - g.left;
+                    int pv[6] = {114, 114, 114, 114, 114, 114};
+                    if (uy >= 0 && uy < g.unpad_h && ux >= 0 && ux + 1 < g.unpad_w) {
+                        const uint16_t* q = (const uint16_t*)(src8 + (((size_t)b * g.src_h + uy) * g.src_w + ux) * 3);
+                        const uint32_t h0 = q[0], h1 = q[1], h2 = q[2];
+                        pv[0] = h0 & 255; pv[1] = h0 >> 8; pv[2] = h1 & 255; pv[3] = h1 >> 8; pv[4] = h2 & 255; pv[5] = h2 >> 8;
+                    }
+                    const int a0 = g.swap_rb ? pv[2] : pv[0], a2 = g.swap_rb ? pv[0] : pv[2];
+                    const int c0 = g.swap_rb ? pv[5] : pv[3], c2 = g.swap_rb ? pv[3] : pv[5];
+                    pre[k].x = pack2_bf16(div255_exact((float)a0), div255_exact((float)pv[1]));
+                    pre[k].y = pack2_bf16(div255_exact((float)a2), 0.f);
+                    pre[k].z = pack2_bf16(div255_exact((float)c0), div255_exact((float)pv[4]));
+                    pre[k].w = pack2_bf16(div255_exact((float)c2), 0.f);
+                }
+            }
+        }
+    };
+    typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2f __attribute__((ext_vector_type(2)));
+    const bool odd = (kq & 1) != 0;
+    char* l0b = (char*)l0t;
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int oy0 = ty * FF_TH, ox0 = tx * FF_TW;
+        const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;
+        __syncthreads();                                    // the previous tile's LDS reads are done
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (i < FF_PR * FF_PC) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = pre[k]; }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        // ---- layer 0 on the region: pixel slot n -> plane n / 289, row (n % 289) / 17, column 2 * ((n % 289) % 17) + plane ----------
+        for (int tb = wave * 2; tb < FF_NT0; tb += 2 * FF_NW) {     // two pixel tiles per pass and wave
+            int ly[2], lx[2], slot[2];
+            bool live[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n = (tb + q) * 16 + col;
+                const int pl = n >= FF_PLANE ? 1 : 0, rem = n - pl * FF_PLANE;
+                ly[q] = min(rem / FF_PW, FF_RH - 1);
+                lx[q] = 2 * (rem % FF_PW) + pl;
+                slot[q] = n;
+                live[q] = tb + q < FF_NT0 && n < FF_NPIX && lx[q] <= 2 * FF_TW;       // column 33 of the odd plane does not exist
+                lx[q] = min(lx[q], 2 * FF_TW);
+            }
+            f32x4f acc[2][2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                ChunkF xf[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xf[q].u = patch[(2 * ly[q]) * FF_PP + lx[q] + koff[s]];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[s][ct].h, xf[q].h, acc[ct][q], 0, 0, 0);
+            }
+            // bias + SiLU + bf16; lane pairs swap halves across the two pixel tiles (conv_epilogue_bf16): 16 bytes = 8 channels of one pixel
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                uint2 P[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[4] = {acc[ct][q][0] + bv0[ct].x, acc[ct][q][1] + bv0[ct].y, acc[ct][q][2] + bv0[ct].z, acc[ct][q][3] + bv0[ct].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
+                    // layer 1 pads layer 0 with ZEROS: region pixels outside the layer-0 map hold 0, not SiLU(bias)
+                    const int gy = gy0 + ly[q], gx = gx0 + lx[q];
+                    const bool inside = gy >= 0 && gy < H0 && gx >= 0 && gx < W0;
+                    const bf16x2f p0 = {(__bf16)(inside ? v[0] : 0.f), (__bf16)(inside ? v[1] : 0.f)}, p1 = {(__bf16)(inside ? v[2] : 0.f), (__bf16)(inside ? v[3] : 0.f)};
+                    P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
+                }
+                const u32x2f sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
+                const u32x2f sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+                const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
+                const int q = odd ? 1 : 0;                   // even lanes keep tile 0's pixel, odd lanes tile 1's (same `col`)
+                // the pair (lane, lane ^ 16) shares `col`, hence the same pixel of each tile; liveness and slot are per lane's own tile
+                if (live[q]) *(uint4*)(l0b + ff_l0_addr(slot[q], ct * 2 + (kq >> 1))) = o4;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 from the LDS tile: wave w owns output rows 2w, 2w + 1 (one pixel tile each), all 64 channels; weights from LDS ---
+        {
+            f32x4f acc[4][2];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int r = tp / 3, s = tp % 3;
+                ChunkF xf[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int oyl = wave * 2 + q;
+                    const int px = (s & 1) * FF_PLANE + (2 * oyl + r) * FF_PW + col + (s >> 1);
+                    xf[q].u = *(const uint4*)(l0b + ff_l0_addr(px, kq));
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    ChunkF wv;
+                    wv.u = w1s[(tp * 4 + ct) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv.h, xf[q].h, acc[ct][q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                uint2 P[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float v[4] = {acc[ct][q][0] + bv1[ct].x, acc[ct][q][1] + bv1[ct].y, acc[ct][q][2] + bv1[ct].z, acc[ct][q][3] + bv1[ct].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
+                    const bf16x2f p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
+                    P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
+                }
+                const u32x2f sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
+                const u32x2f sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+                const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
+                const int oy = oy0 + wave * 2 + (odd ? 1 : 0), ox = ox0 + col;
+                if (oy < H1 && ox < W1)
+                    *(uint4*)(y + (((size_t)b * H1 + oy) * W1 + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
+            }
+        }
+    }
+}
+
+// p0 = the stem as launch_conv sees it (stem_direct_applicable), p1 = the conv that consumes its output
+bool front_fused_applicable(const ConvP& p0, const ConvP& p1) {
+    if (!stem_direct_applicable(p0) || p0.Cout != 32) return false;
+    return p1.prec == PREC_BF16 && p1.in == p0.out && p1.in_cs == p0.out_cs && p1.in_co == p0.out_co && p1.Cin == 32 && p1.Cout == 64 && p1.kh == 3 &&
+           p1.kw == 3 && p1.sh == 2 && p1.sw == 2 && p1.ph == 1 && p1.pw == 1 && p1.act == ACT_SILU && p1.res_mode == RES_NONE && !p1.out_f32 && p1.split == 0 &&
+           p1.B == p0.B && p1.H == p0.Ho && p1.W == p0.Wo && p1.K == 288 && p1.out_cs % 8 == 0 && p1.out_co % 8 == 0;
+}
+
+int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, const LetterboxGeom& g, hipStream_t s) {
+    if (!front_fused_applicable(p0, p1)) return VC_ERR_ARG;
+    const int tiles_x = (p1.Wo + FF_TW - 1) / FF_TW, tiles_y = (p1.Ho + FF_TH - 1) / FF_TH;
+    const int ntiles = p1.B * tiles_x * tiles_y;
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
+    static const int slots_hw = [] {
+        int per_cu = 1, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_fused_kernel<true>, FF_NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        return per_cu * cus;
+    }();
+    const int grid = std::min(ntiles, std::max(64, slots_hw - slots_reserve));   // persistent: every workgroup walks tiles
+    const uint4* x = (const uint4*)p0.in;
+    uint16_t* y = (uint16_t*)p1.out;
+    if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
+                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g);
+    else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
+                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace vc

@@ -155,6 +155,9 @@ struct LetterboxGeom;
 // the same with the letterbox folded into the patch fetch: reads the u8 frames directly (no-resize geometry, even source width)
 bool stem_u8_applicable(const ConvP& p, const LetterboxGeom& g);
 int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s);
+// front_fused.hip: YOLO layers 0 + 1 (stem + 3x3 / s2) in one kernel, the stem's output never leaves the CU
+bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
+int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
 int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s);
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
