@@ -925,10 +925,10 @@ static int launch_one(ConvP p, hipStream_t s) {
     static const int dyn_lds = getenv("VC_CONV_DYN_LDS") ? atoi(getenv("VC_CONV_DYN_LDS")) : 0;   // diagnostics: caps workgroups per CU
     static const bool persist = !(getenv("VC_CONV_PERSIST") && atoi(getenv("VC_CONV_PERSIST")) == 0);
     const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;        // tests: force long tile walks
-    // A persistent grid that fills every workgroup slot of the chip leaves no room for the tracker stream's small per-frame
-    // kernels, which then wait for a conv launch to end: 64 slots are left free (measured: +4..10 % end to end, conv time
-    // unchanged; 256 free slots cost 9 % of conv time).
-    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
+    // A persistent grid that fills every workgroup slot of the chip leaves no room for the kernels of the other streams (ReID next to the
+    // detector, the tracker walk), which then wait for a conv launch to end: 64 slots are left free (round 2, 128-frame steps:
+    // 0 / 32 / 64 / 96 / 128 free slots = 14.9 / 15.1 / 15.6 / 15.6 / 15.4 k frames/s; 256 free slots cost 9 % of conv time).
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     if (p.prec == PREC_F32) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
@@ -1010,7 +1010,7 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
     const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
     const int need = (nblk * ng + 3) / 4;
     static const int slots_hw = resident_workgroups(conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>);
-    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;
     const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
     p.ntiles = nblk * ng;

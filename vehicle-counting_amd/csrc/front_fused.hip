@@ -230,7 +230,7 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     if (!front_fused_applicable(p0, p1)) return VC_ERR_ARG;
     const int tiles_x = (p1.Wo + FF_TW - 1) / FF_TW, tiles_y = (p1.Ho + FF_TH - 1) / FF_TH;
     const int ntiles = p1.B * tiles_x * tiles_y;
-    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 32;
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     static const int slots_hw = [] {
         int per_cu = 1, dev = 0, cus = 256;
         hipDeviceProp_t prop;

@@ -137,6 +137,7 @@ struct TrackBatchArgs {
     size_t scratch_per_wg;           // transpose (4 x 65536 doubles) + the work arrays of steps too large for the LDS
     int cap;                         // tracks + detections per step whose work arrays live in LDS (a multiple of 8, <= 512)
     int frame_w, frame_h;
+    int all_tables;                  // host-side bound: every tracker's appearance table fits the arena (lean kernel instance)
     int dbg_costs;                   // 1: keep the cost rows in the global scratch (vc_tracker_debug_costs reads them back)
     long long* dbg;                  // diagnostics (VC_TRACK_DBG): per task 8 timestamps (100 MHz): start, predict, cost rows, match, apply, finish
 };

@@ -23,7 +23,7 @@ namespace vc {
 namespace tc {
 
 enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
-enum { TERR_NONE = 0, TERR_TRACK_CAP = 1, TERR_POOL = 2, TERR_ROWS = 3, TERR_LAP = 4 };
+enum { TERR_NONE = 0, TERR_TRACK_CAP = 1, TERR_POOL = 2, TERR_ROWS = 3, TERR_LAP = 4, TERR_TABLE = 5 };
 // most live tracks + detections one tracker step can hold; a step's cost matrices are [T][D] with T + D <= TC_HARD_CAP, i.e. at
 // most TC_MAT = (TC_HARD_CAP / 2)^2 entries
 enum { TC_HARD_CAP = 512, TC_MAT = 256 * 256 };
@@ -172,13 +172,54 @@ VC_HD int lsap_core(Lanes L, int nr, int nc, const double* cost, const LapWork& 
 #if defined(__HIP_DEVICE_COMPILE__)
 // The same solver for problems with at most 64 rows and 64 columns, state in registers: lane j owns column j (v, spc, path,
 // row4col, its position in the `remaining` list, SC) and lane i owns row i (u, col4row, SR); scalars move with wave shuffles, the
-// cost matrix is read from `cost` (LDS for the small problems this is used for).  Same scan order, same tie-breaking, same dual
-// updates as lsap_core above (remaining[it] = nc - it - 1 initially, swap-remove on selection), hence the same assignment; what
-// it saves are the LDS round trips and wave-level synchronisations between the dependent steps of the search.
-__device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const double* cost, int* col4row_out) {
+// cost matrix comes from cost(i, lane) = entry (row i, column `lane`), evaluated by every lane (lanes >= nc: any finite or
+// infinite value, ignored).  Same scan order, same tie-breaking, same dual updates as lsap_core above (remaining[it] = nc - it - 1
+// initially, swap-remove on selection), hence the same assignment; what it saves are the LDS round trips and wave-level
+// synchronisations between the dependent steps of the search.  The scan's total order (value, unassigned, list position) is
+// carried as (value, key) with key = unassigned ? 64 + position : 63 - position, larger key wins among equal values; the
+// reduction runs over the pow2(nc) lanes that can hold a column and lane 0 broadcasts.
+// On return lane i < nr holds col4row (every row is assigned) and lane j < nc holds row4col (-1: unassigned).
+struct BestK { double v; int key; };
+__device__ __forceinline__ bool better_k(const BestK& a, const BestK& b) {
+    if (a.v < b.v) return true;
+    if (a.v > b.v) return false;
+    return a.key > b.key;
+}
+// Values of a wave-uniform lane: v_readlane (a few cycles) instead of a trip through the LDS crossbar (ds_bpermute, ~100 cycles in a
+// dependent chain -- and the search below is one long dependent chain).
+__device__ __forceinline__ int lane_get(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double lane_get(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// one reduction step with the partner chosen by a DPP control: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140 -- after the four of them every lane of a 16-lane row holds the row's best
+template <int CTRL>
+__device__ __forceinline__ void best_step_dpp(BestK& b) {
+    BestK y;
+    y.v = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(b.v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(b.v), CTRL, 0xf, 0xf, true));
+    y.key = __builtin_amdgcn_mov_dpp(b.key, CTRL, 0xf, 0xf, true);
+    if (better_k(y, b)) b = y;
+}
+// best over lanes [0, width), width a power of two; valid in lane 0
+__device__ __forceinline__ void best_reduce(BestK& b, int width) {
+    if (width > 1) best_step_dpp<0xB1>(b);
+    if (width > 2) best_step_dpp<0x4E>(b);
+    if (width > 4) best_step_dpp<0x141>(b);
+    if (width > 8) best_step_dpp<0x140>(b);
+    for (int o = 16; o < width; o <<= 1) {
+        BestK y;
+        y.v = __shfl_xor(b.v, o); y.key = __shfl_xor(b.key, o);
+        if (better_k(y, b)) b = y;
+    }
+}
+template <class CostFn>
+__device__ __forceinline__ int lsap_reg(int lane, int nr, int nc, CostFn cost, int& col4row, int& row4col) {
     const double INF = (double)INFINITY;
     double u = 0.0, v = 0.0;
-    int col4row = -1, row4col = -1, path = -1;
+    int path = -1;
+    col4row = -1; row4col = -1;
+    int width = 1;
+    while (width < nc) width <<= 1;
     for (int cur = 0; cur < nr; ++cur) {
         double minVal = 0, spc = INF;
         int i = cur, num_remaining = nc, sink = -1;
@@ -186,20 +227,22 @@ __device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const 
         bool SR = false, SC = false;
         while (sink == -1) {
             if (lane == i) SR = true;
-            const double ui = __shfl(u, i);
-            Best b = {INF, 0, INT_MAX};
+            const double ui = lane_get(u, i);
+            const double cij = cost(i, lane);
+            BestK b = {INF, INT_MIN};
             if (pos >= 0) {
-                const double r = minVal + cost[(size_t)i * nc + lane] - ui - v;
+                const double r = minVal + cij - ui - v;
                 if (r < spc) { path = i; spc = r; }
-                b.v = spc; b.un = row4col == -1 ? 1 : 0; b.it = pos;
+                b.v = spc; b.key = row4col == -1 ? 64 + pos : 63 - pos;
             }
-            const Lanes L{lane, 64};
-            b = wave_best(L, b);
-            minVal = b.v;
+            best_reduce(b, width);
+            minVal = lane_get(b.v, 0);
+            const int key = lane_get(b.key, 0);
             if (minVal == INF) return -1;
-            const int jstar = __ffsll((unsigned long long)__ballot(pos == b.it && pos >= 0)) - 1;
-            const int rj = __shfl(row4col, jstar);
-            if (pos == num_remaining - 1) pos = b.it;      // swap-remove: the list's last entry takes the freed position ...
+            const int it = key >= 64 ? key - 64 : 63 - key;
+            const int jstar = __ffsll((unsigned long long)__ballot(pos == it)) - 1;
+            const int rj = lane_get(row4col, jstar);
+            if (pos == num_remaining - 1) pos = it;        // swap-remove: the list's last entry takes the freed position ...
             if (lane == jstar) { pos = -1; SC = true; }    // ... and the chosen column leaves the list
             --num_remaining;
             if (rj == -1) sink = jstar; else i = rj;
@@ -210,15 +253,22 @@ __device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const 
         if (SC) v -= minVal - spc;
         int j = sink;                                        // augment along the alternating path
         while (true) {
-            const int r = __shfl(path, j);
-            const int prev = __shfl(col4row, r);
+            const int r = lane_get(path, j);
+            const int prev = lane_get(col4row, r);
             if (lane == j) row4col = r;
             if (lane == r) col4row = j;
             j = prev;
             if (r == cur) break;
         }
     }
-    if (lane < nr) col4row_out[lane] = col4row;
+    return 0;
+}
+// cost row-major [nr][nc] in memory (LDS for the small problems this is used for); col4row_out[0..nr)
+__device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const double* cost, int* col4row_out) {
+    int c4r, r4c;
+    const int cl = lane < nc ? lane : 0;
+    if (lsap_reg(lane, nr, nc, [&](int i, int) { return cost[(size_t)i * nc + cl]; }, c4r, r4c) != 0) return -1;
+    if (lane < nr) col4row_out[lane] = c4r;
     return 0;
 }
 #endif
@@ -335,6 +385,106 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
     wave_sync();
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the same matching for steps with at most 64 tracks and 64 detections: every list lives in registers -----------------------
+// A list is one register per lane (lane p = list position p); lists are built by PUSHING: lane l sends its value to lane `dst`
+// (ds_permute), lanes with nothing to send aim at a position the list does not use.
+__device__ __forceinline__ int lane_push(int dst, int value) { return __builtin_amdgcn_ds_permute(dst << 2, value); }
+
+// min_cost_matching (linear_assignment.py:52-77) on rows (track indices, nr of them) x cols (detection indices, nc of them) with
+// cost_at(track, detection).  Accepted pairs are appended to w.match_t / w.match_d in row order (n_match advances); acc_row: this
+// lane's row was matched; un_rows / un_cols: the reference's unmatched lists (unassigned entries in list order, then the rejected
+// pairs in row order).
+template <class CostAt>
+__device__ __forceinline__ int mcm_reg(int lane, int rows, int nr, int cols, int nc, CostAt cost_at, double max_cost, const StepWork& w,
+                                       int& n_match, int& un_rows, int& n_ur, int& un_cols, int& n_uc, bool& acc_row) {
+    acc_row = false;
+    if (nr == 0 || nc == 0) { un_rows = rows; n_ur = nr; un_cols = cols; n_uc = nc; return TERR_NONE; }
+    auto clampc = [&](double v) { return v > max_cost ? max_cost + 1e-5 : v; };
+    int acol, arow;                                         // row lane: position of its column (-1 none); column lane: of its row
+    if (nr <= nc) {
+        int c4r, r4c;
+        if (lsap_reg(lane, nr, nc, [&](int i, int) { return clampc(cost_at(lane_get(rows, i), cols)); }, c4r, r4c) != 0) return TERR_LAP;
+        acol = lane < nr ? c4r : -1; arow = lane < nc ? r4c : -1;
+    } else {                                                // SciPy transposes so that rows <= columns
+        int c4r, r4c;
+        if (lsap_reg(lane, nc, nr, [&](int i, int) { return clampc(cost_at(rows, lane_get(cols, i))); }, c4r, r4c) != 0) return TERR_LAP;
+        arow = lane < nc ? c4r : -1; acol = lane < nr ? r4c : -1;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int my_det = __shfl(cols, acol >= 0 ? acol : 0);                       // row lanes: detection of the assigned column
+    const bool is_row = lane < nr, is_col = lane < nc;
+    const bool rej_row = is_row && acol >= 0 && clampc(cost_at(rows, my_det)) > max_cost;
+    acc_row = is_row && acol >= 0 && !rej_row;
+    const bool un_row = is_row && acol < 0, un_col = is_col && arow < 0;
+    const unsigned long long m_ur = __ballot(un_row), m_rej = __ballot(rej_row), m_acc = __ballot(acc_row), m_uc = __ballot(un_col);
+    const int n_ur0 = __popcll(m_ur), nrej = __popcll(m_rej), n_uc0 = __popcll(m_uc);
+    const int rank_rej = __popcll(m_rej & lt);
+    un_rows = lane_push(un_row ? __popcll(m_ur & lt) : rej_row ? n_ur0 + rank_rej : 63, rows);      // lane 63 is past the list unless all 64 lanes send
+    const int uc_a = lane_push(un_col ? __popcll(m_uc & lt) : 63, cols);
+    const int uc_b = lane_push(rej_row ? n_uc0 + rank_rej : (n_uc0 > 0 ? 0 : 63), my_det);
+    un_cols = lane < n_uc0 ? uc_a : uc_b;
+    if (acc_row) { const int k = n_match + __popcll(m_acc & lt); w.match_t[k] = rows; w.match_d[k] = my_det; }
+    n_match += __popcll(m_acc);
+    n_ur = n_ur0 + nrej; n_uc = n_uc0 + nrej;
+    if (lane >= n_ur) un_rows = 0;
+    if (lane >= n_uc) un_cols = 0;
+    return TERR_NONE;
+}
+
+__device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, const TrackerHdr& h, int T, int D, const double* cost_app,
+                                                  const double* cost_iou, int& n_match, int& n_un, int*& newdets, int& n_new, int& err, long long* prof) {
+    if (prof && lane == 0) prof[0] = wall_clock64();
+    const int st = lane < T ? w.state[lane] : -1, tsu = lane < T ? w.tsu[lane] : 0;
+    const bool conf = st == CONFIRMED;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int left = lane < D ? lane : 0, n_left = D;
+    bool matched = false;
+    n_match = 0;
+    const Lanes L{lane, 64};
+    const int n_levels = imin(h.max_age, wave_max(L, conf ? tsu : 0));
+    if (prof && lane == 0) prof[1] = wall_clock64();
+    auto app_at = [&](int t, int d) { return cost_app[(size_t)t * D + d]; };
+    auto iou_at = [&](int t, int d) { return cost_iou[(size_t)t * D + d]; };
+    // matching_cascade (linear_assignment.py:80-145): level = time_since_update - 1, most recently seen tracks first
+    for (int level = 0; level < n_levels && n_left > 0; ++level) {
+        const unsigned long long rm = __ballot(conf && tsu == 1 + level);
+        if (rm == 0) continue;
+        const int nl = __popcll(rm), rank = __popcll(rm & lt);
+        const bool in = (rm >> lane) & 1ull;
+        int rows = lane_push(in ? rank : 63, lane);
+        if (lane >= nl) rows = 0;
+        int un_rows, n_ur, un_cols, n_uc;
+        bool acc;
+        const int e = mcm_reg(lane, rows, nl, left, n_left, app_at, h.max_dist, w, n_match, un_rows, n_ur, un_cols, n_uc, acc);
+        if (e != TERR_NONE) { err = e; return; }
+        const bool mine = __shfl((int)acc, in ? rank : 0) != 0;
+        if (in && mine) matched = true;
+        left = un_cols; n_left = n_uc;
+    }
+    if (prof && lane == 0) prof[2] = wall_clock64();
+    // IoU stage (tracker.py:118-127): unconfirmed tracks, then the confirmed tracks missed for exactly one frame
+    const unsigned long long um = __ballot(lane < T && !conf), rcm = __ballot(conf && !matched && tsu == 1), unm = __ballot(conf && !matched && tsu != 1);
+    const int n_unconf = __popcll(um), nr = n_unconf + __popcll(rcm);
+    const bool is_u = (um >> lane) & 1ull, is_r = (rcm >> lane) & 1ull;
+    int rows = lane_push(is_u ? __popcll(um & lt) : is_r ? n_unconf + __popcll(rcm & lt) : 63, lane);
+    if (lane >= nr) rows = 0;
+    if ((unm >> lane) & 1ull) w.un_tracks[__popcll(unm & lt)] = lane;
+    n_un = __popcll(unm);
+    int un_rows, n_ur, un_cols, n_uc;
+    bool acc;
+    const int e = mcm_reg(lane, rows, nr, left, n_left, iou_at, h.max_iou_distance, w, n_match, un_rows, n_ur, un_cols, n_uc, acc);
+    if (e != TERR_NONE) { err = e; return; }
+    if (lane < n_ur) w.un_tracks[n_un + lane] = un_rows;
+    n_un += n_ur;
+    if (lane < n_uc) w.left[lane] = un_cols;
+    newdets = w.left;
+    n_new = n_uc;
+    wave_sync();
+    if (prof && lane == 0) prof[3] = wall_clock64();
+}
+#endif
+
 // Tracker._match on the step's cost rows (cost_app: gated appearance rows of the confirmed tracks, cost_iou: IoU rows of the IoU
 // candidates; both [T][D], rows of other tracks are never read).  Outputs: matches in w.match_t / w.match_d, missed tracks in
 // w.un_tracks, the detections that start new tracks in *newdets (one of w.left / w.un_cols), all in the reference's list order.
@@ -348,6 +498,9 @@ VC_HD long long tc_clock() {
 
 VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, int D, const double* cost_app, const double* cost_iou,
                       double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err, long long* prof = nullptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (T <= 64 && D <= 64) { match_step_wave64(L.lane, w, h, T, D, cost_app, cost_iou, n_match, n_un, newdets, n_new, err, prof); return; }
+#endif
     if (prof && L.lane == 0) prof[0] = tc_clock();
     const int n_conf = compact(L, T, [&](int t) { return w.state[t] == CONFIRMED; }, [&](int pos, int t) { w.confirmed[pos] = t; });
     const int n_unconf = compact(L, T, [&](int t) { return w.state[t] != CONFIRMED; }, [&](int pos, int t) { w.unconfirmed[pos] = t; });

@@ -101,13 +101,14 @@ __device__ __forceinline__ void kalman_update_wave(double* m, double* P, const d
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define VC_SMALL_D 12       // detections per step up to which the appearance rows run one wave per track (appearance_row_wave)
+#define VC_TRACK_MAX_WAVES 8
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
     float smax[4][16];
     int featrow[16];                 // feature rows / xyah of the 16 detections being scored
     double xyah[16][4];
-    double kbuf[4][32];              // Kalman gain rows, one block per wave (kalman_update_wave)
+    double kbuf[VC_TRACK_MAX_WAVES][32];   // Kalman gain rows, one block per wave (kalman_update_wave)
     double small_c[256], small_t[256];   // small assignment problems stay in LDS (StepWork::small_c / small_t)
     double cost_small[2][512];           // the step's appearance / IoU rows when T x D <= 512 (else the workgroup's global scratch)
     int ctl[8];                      // P1 -> P2/P3 hand-over: n_match, n_un, n_new, newdets is w.left, error
@@ -366,24 +367,26 @@ __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, co
         project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
         chol4(Sg, Lc);
     }
+    // lanes = (sample group, detection): with D detections the wave splits into 64 / pow2(D) sample groups, each lane walks every
+    // SL-th ring entry (independent loads, all in flight together) and the groups are merged with a few lane exchanges -- a step of
+    // a light scene (D ~ 6, S ~ 60) is 8 table reads per lane behind one memory latency instead of 60 behind fifteen
     for (int d0 = 0; d0 < D; d0 += 64) {
-        const int d = d0 + lane;
-        const bool ok = d < D;
+        const int nd = min(64, D - d0);
+        int sh = 0;
+        while ((1 << sh) < nd) ++sh;
+        const int DL = 1 << sh, SL = 64 >> sh, dl = lane & (DL - 1), sg = lane >> sh;
+        const bool ok = dl < nd;
+        const int* grow = a.gal_row + (size_t)jb.slot * SC;
+        const float* col = tab + det_local0 + d0 + min(dl, nd - 1);
         float best = -INFINITY;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int my = s0 + lane < S ? a.gal_row[(size_t)jb.slot * SC + s0 + lane] : 0;
-            const int ns = min(64, S - s0);
-#pragma unroll 4
-            for (int s = 0; s < ns; ++s) {
-                const int rid = __shfl(my, s);
-                if (ok) best = fmaxf(best, tab[(size_t)rid * dp.n_dets + det_local0 + d]);
-            }
-        }
-        if (ok) {
-            const int g = jb.det_off + d;
+#pragma unroll 8
+        for (int s = sg; s < S; s += SL) best = fmaxf(best, col[(size_t)grow[s] * dp.n_dets]);
+        for (int o = DL; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o));
+        if (ok && sg == 0) {
+            const int g = jb.det_off + d0 + dl;
             const float cosv = best * (1.0f / sqrtf(a.det_ss[g]));
             const double g2 = maha4(m, Lc, a.det_xyah + (size_t)g * 4);
-            out[jb.out_off + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+            out[jb.out_off + d0 + dl] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
         }
     }
 }
@@ -412,7 +415,10 @@ __device__ __forceinline__ void report_error(const TrackBatchArgs& a, TrackerHdr
 
 extern __shared__ __attribute__((aligned(16))) char track_dyn_lds[];
 
-__global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a) {
+// NW waves per workgroup; TABLE: every tracker of the launch has its appearance dots in the precomputed table (the normal case) --
+// that instance carries no MFMA code and no fallback paths, which is what lets it run 8 waves (one track per wave in P0 / P2).
+template <int NW, bool TABLE>
+__global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchArgs a) {
     __shared__ TrackShared sh;
     // Serial, latency-bound work next to the detector's MFMA-heavy waves on the same CUs: highest issue priority, so that a step's
     // chain of dependent instructions does not queue behind them (the tracker's ~50 workgroups take a negligible share of issue slots)
@@ -435,6 +441,10 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Lanes L{lane, 64};
     const TrackPool& tp = a.pool;
+    if (TABLE && !dp.use_table && plan.det_n > 0 && hdr->err == TERR_NONE) {      // cannot happen (the host's bound covers the plan kernel's need)
+        if (threadIdx.x == 0) report_error(a, hdr, TERR_TABLE, plan.tracker, plan.task_begin);
+        __syncthreads();
+    }
 
 #define VC_TTS(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)task * 16 + (i)] = wall_clock64(); } while (0)
     for (int task = plan.task_begin; task < plan.task_end; ++task) {
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             continue;
         }
         // ---- P0: Track.predict (track.py:112-124) + cost rows -------------------------------------------------------------
-        for (int t = wave; t < T; t += 4) {
+        for (int t = wave; t < T; t += NW) {
             const int slot = list[t];
             if (lane == 0) {
                 TrackRecD& r = a.recs[slot];
@@ -469,15 +479,15 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
         }
         __syncthreads();
         VC_TTS(1);
-        if (D > 0 && (dp.use_table || D <= VC_SMALL_D)) {
+        if (D > 0 && (TABLE || dp.use_table || D <= VC_SMALL_D)) {
             // one wave per track, no workgroup barriers: rows from the precomputed dot table (the normal case), or computed here
             // for a few detections when the table did not fit the arena
-            for (int t = wave; t < T; t += 4) {
+            for (int t = wave; t < T; t += NW) {
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    if (dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane);
-                    else appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
+                    if (TABLE || dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane);
+                    else if constexpr (!TABLE) appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
                 }
                 if (!(st == CONFIRMED && tsu != 1)) {
                     double b[4];
@@ -486,12 +496,12 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
                         cost_iou[(size_t)t * D + d] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + d) * 4);
                 }
             }
-        } else if (D > 0) {
+        } else if (!TABLE && D > 0) {
             for (int t = 0; t < T; ++t) {                               // block-uniform
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    appearance_row_dev(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, sh);
+                    if constexpr (!TABLE) appearance_row_dev(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, sh);
                 }
                 if (!(st == CONFIRMED && tsu != 1)) {                   // IoU candidates only (tracker.py:118-120)
                     double b[4];
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(256) void track_batch_kernel(const TrackBatchArgs a
             continue;
         }
         // ---- P2: Kalman update / initiate + gallery ring writes, one wave per operation ------------------------------------------
-        for (int k = wave; k < n_match + n_new; k += 4) {
+        for (int k = wave; k < n_match + n_new; k += NW) {
             if (k < n_match) {                                           // Track.update (track.py:126-145)
                 const int t = w.match_t[k], g = tk.det_off + w.match_d[k], slot = w.slot[t];
                 kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave]);
@@ -595,7 +605,8 @@ int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
         hipLaunchKernelGGL(track_dots_kernel, dim3(std::min(2048, std::max(64, a.n_det_total))), dim3(256), 0, s, a, n_wg);
         VC_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(track_batch_kernel, dim3(n_wg), dim3(256), lds, s, a);
+    if (a.all_tables) hipLaunchKernelGGL((track_batch_kernel<8, true>), dim3(n_wg), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((track_batch_kernel<4, false>), dim3(n_wg), dim3(256), lds, s, a);
     VC_HIP(hipGetLastError());
     hipLaunchKernelGGL(merge_free_kernel, dim3(1), dim3(256), 0, s, a.free_top, a.free_stack, a.freed_count, a.freed);
     VC_HIP(hipGetLastError());

@@ -178,6 +178,11 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     for (int k = 0; k < n_tasks; ++k) s.dev_index[order[k]] = k;
     std::vector<TrackWgPlan> plans;
     int need = 8, n_dets = 0;
+    // Do the appearance tables of ALL trackers fit the arena for certain?  Bound from what the host knows: a tracker holds at most
+    // known_tracks (last collected batch) + pending_dets (detections of batches still in flight) tracks at the start of this batch,
+    // each with a full gallery.  Then the lean kernel instance (no fallback code, 8 waves) runs.
+    long long table_floats = 0, table_rows = 0;
+    bool all_tables = true;
     for (int k = 0; k < n_tasks;) {
         const int tr = s.tasks[order[k]].tracker;
         int k1 = k, dets = 0, dmax = 0;
@@ -189,6 +194,13 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
             ++k1;
         }
         plans.push_back(TrackWgPlan{tr, k, k1, det_begin, dets, 0, 0, 0});
+        {
+            const Tracker& tk = *e->trackers[tr];
+            const long long old_rows = (long long)(tk.known_tracks + tk.pending_dets) * std::min(e->pool.budget_cap, tk.p.nn_budget);
+            const long long need_f = (old_rows + dets) * dets;
+            if (need_f >= (1ll << 31)) all_tables = false;
+            table_floats += need_f; table_rows += old_rows;
+        }
         // LDS capacity from the tracker's recent size (the kernel falls back to global-memory work arrays for a larger step)
         need = std::max(need, 2 * e->trackers[tr]->known_tracks + 2 * dmax + 16);
         s.tracker_dets.emplace_back(tr, dets);
@@ -272,6 +284,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.task_ntracks = (int*)(s.hd_out + ol.ntracks); a.task_T = (int*)(s.hd_out + ol.tT);
     a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
     a.scratch = e->d_track_scratch; a.scratch_per_wg = track_scratch_per_wg(); a.cap = cap; a.frame_w = W; a.frame_h = H;
+    a.all_tables = all_tables && table_floats <= (long long)e->dot_arena_floats && table_rows <= (long long)e->row_src_cap ? 1 : 0;
     a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back
     static const bool dbg_on = getenv("VC_TRACK_DBG") != nullptr;        // diagnostics: phase times of every task, printed per batch
     long long* dbg = nullptr;
@@ -345,6 +358,7 @@ int track_collect(vc_engine* e, int st, int64_t* out_rows6, int cap_rows_per_fra
         const char* what = status[0] == TERR_TRACK_CAP ? "live tracks + detections exceed the per-tracker capacity (vc_engine_config.tracks_per_tracker)"
                          : status[0] == TERR_POOL     ? "track pool exhausted (vc_engine_config.max_tracks)"
                          : status[0] == TERR_ROWS     ? "more output rows than the caller's buffers hold (cap_rows)"
+                         : status[0] == TERR_TABLE    ? "appearance table missing although the host's bound said it fits (internal)"
                                                       : "infeasible assignment problem";
         set_error("tracker %d: %s; the tracker is stopped until vc_tracker_reset", status[1], what);
         return VC_ERR_CAPACITY;
