@@ -74,7 +74,7 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
         const int slot = h.list[t];
         TrackRecD& r = h.recs[slot];
         r.age += 1; r.tsu += 1;
-        w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = r.tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head;
+        w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = r.tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head; w.hits[t] = r.hits; w.id[t] = r.id;
         double* m = &h.mean[(size_t)slot * 8];
         double* P = &h.cov[(size_t)slot * 64];
         kalman_predict_dev(m, P);
@@ -122,7 +122,8 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
         gallery_store(&h.gallery[((size_t)slot * S + 0) * FEAT], feat + (size_t)d * FEAT);
     }
     const int n = finish_step(L, w, &h.hdr, h.list.data(), h.recs.data(), T, n_match, n_un, n_new, [&](const int* slots, int nd) { for (int i = 0; i < nd; ++i) h.free_stack.push_back(slots[i]); });
-    h.n_rows = emit_rows(L, h.list.data(), h.recs.data(), h.mean.data(), n, W, H, label,
+    (void)n;
+    h.n_rows = emit_rows(L, w, h.mean.data(), T, W, H, label,
                          [&](int pos, const long long* row) { memcpy(&h.rows[(size_t)pos * 6], row, 6 * sizeof(long long)); });
     return 0;
 }

@@ -13,6 +13,8 @@
 // 64 bytes per pixel, 16-byte chunks XOR-swizzled with conv3x3_halo_kernel's formula (conflict-free for any base pixel).
 // MFMA operand order and k order equal conv_igemm_kernel's for both layers: bit-identical to the unfused path.
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "kernels.h"
 
@@ -40,7 +42,7 @@ template <bool U8>
 __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
                                                              const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
-                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g) {
+                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg) {
     __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
     __shared__ uint4 l0t[FF_NT0 * 16 * 4];                 // 72.7 KB: [pixel slot][4 chunks], swizzled
     __shared__ uint4 w1s[9 * 4 * 64];                      // 36.9 KB: layer-1 weights, [tap][channel tile][lane] = one fragment load per wave
@@ -70,6 +72,9 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
     const int ntiles = B * tiles_y * tiles_x;
     constexpr int NT = FF_NW * 64;
     constexpr int NPRE = (FF_PR * FF_PC + NT - 1) / NT;    // 5 chunks per thread
+    // The next tile's patch travels through registers while this tile is computed.  U8: the registers hold the RAW source bytes
+    // (three 16-bit loads per pixel pair) and the conversion (pad 114, R/B swap, exact /255, RNE to bf16) happens when the patch is
+    // written to LDS one tile later -- converting at fetch time would make every wave wait for its loads right there.
     uint4 pre[NPRE];
     auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
@@ -79,27 +84,34 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
             const int i = threadIdx.x + k * NT;
             const int pr = i / FF_PC, pc = i - pr * FF_PC;
             const int iy = 2 * gy0 - 2 + pr, ip = gx0 - 1 + pc;
-            pre[k] = make_uint4(0u, 0u, 0u, 0u);
+            pre[k] = make_uint4(0u, 0u, 0u, 0u);                            // .w = 0: outside the network input (zero padding)
             if (i < FF_PR * FF_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
                 if constexpr (!U8) {
                     pre[k] = x[((size_t)b * H + iy) * Wp + ip];
                 } else {
                     const int uy = iy - g.top, ux = 2 * ip - g.left;
-                    int pv[6] = {114, 114, 114, 114, 114, 114};
+                    pre[k].w = 1u;                                          // inside the input, letterbox padding (114) unless the bytes say otherwise
                     if (uy >= 0 && uy < g.unpad_h && ux >= 0 && ux + 1 < g.unpad_w) {
                         const uint16_t* q = (const uint16_t*)(src8 + (((size_t)b * g.src_h + uy) * g.src_w + ux) * 3);
-                        const uint32_t h0 = q[0], h1 = q[1], h2 = q[2];
-                        pv[0] = h0 & 255; pv[1] = h0 >> 8; pv[2] = h1 & 255; pv[3] = h1 >> 8; pv[4] = h2 & 255; pv[5] = h2 >> 8;
+                        pre[k].x = q[0]; pre[k].y = q[1]; pre[k].z = q[2]; pre[k].w = 2u;
                     }
-                    const int a0 = g.swap_rb ? pv[2] : pv[0], a2 = g.swap_rb ? pv[0] : pv[2];
-                    const int c0 = g.swap_rb ? pv[5] : pv[3], c2 = g.swap_rb ? pv[3] : pv[5];
-                    pre[k].x = pack2_bf16(div255_exact((float)a0), div255_exact((float)pv[1]));
-                    pre[k].y = pack2_bf16(div255_exact((float)a2), 0.f);
-                    pre[k].z = pack2_bf16(div255_exact((float)c0), div255_exact((float)pv[4]));
-                    pre[k].w = pack2_bf16(div255_exact((float)c2), 0.f);
                 }
             }
         }
+    };
+    auto patch_chunk = [&](const uint4& r) -> uint4 {
+        if constexpr (!U8) return r;
+        if (r.w == 0u) return make_uint4(0u, 0u, 0u, 0u);
+        int pv[6] = {114, 114, 114, 114, 114, 114};
+        if (r.w == 2u) { pv[0] = r.x & 255; pv[1] = r.x >> 8; pv[2] = r.y & 255; pv[3] = r.y >> 8; pv[4] = r.z & 255; pv[5] = r.z >> 8; }
+        const int a0 = g.swap_rb ? pv[2] : pv[0], a2 = g.swap_rb ? pv[0] : pv[2];
+        const int c0 = g.swap_rb ? pv[5] : pv[3], c2 = g.swap_rb ? pv[3] : pv[5];
+        uint4 o;
+        o.x = pack2_bf16(div255_exact((float)a0), div255_exact((float)pv[1]));
+        o.y = pack2_bf16(div255_exact((float)a2), 0.f);
+        o.z = pack2_bf16(div255_exact((float)c0), div255_exact((float)pv[4]));
+        o.w = pack2_bf16(div255_exact((float)c2), 0.f);
+        return o;
     };
     typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2f __attribute__((ext_vector_type(2)));
@@ -110,13 +122,16 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int oy0 = ty * FF_TH, ox0 = tx * FF_TW;
         const int gy0 = 2 * oy0 - 1, gx0 = 2 * ox0 - 1;
+        long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        if (dbg) ts0 = wall_clock64();
         __syncthreads();                                    // the previous tile's LDS reads are done
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int i = threadIdx.x + k * NT;
-            if (i < FF_PR * FF_PC) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = pre[k]; }
+            if (i < FF_PR * FF_PC) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = patch_chunk(pre[k]); }
         }
         __syncthreads();
+        if (dbg) ts1 = wall_clock64();
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
         // ---- layer 0 on the region: pixel slot n -> plane n / 289, row (n % 289) / 17, column 2 * ((n % 289) % 17) + plane ----------
         for (int tb = wave * 2; tb < FF_NT0; tb += 2 * FF_NW) {     // two pixel tiles per pass and wave
@@ -170,6 +185,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 if (live[q]) *(uint4*)(l0b + ff_l0_addr(slot[q], ct * 2 + (kq >> 1))) = o4;
             }
         }
+        if (dbg) ts2 = wall_clock64();
         __syncthreads();
         // ---- layer 1 from the LDS tile: wave w owns output rows 2w, 2w + 1 (one pixel tile each), all 64 channels; weights from LDS ---
         {
@@ -215,6 +231,11 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                     *(uint4*)(y + (((size_t)b * H1 + oy) * W1 + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
         }
+        if (dbg && lane == 0) {                            // VC_FF_DBG: per-wave phase sums (100 MHz ticks): patch, stem, barrier wait, conv
+            ts3 = wall_clock64();
+            long long* d = dbg + ((size_t)blockIdx.x * FF_NW + wave) * 4;
+            d[0] += ts1 - ts0; d[1] += ts2 - ts1; d[2] += 0; d[3] += ts3 - ts2;
+        }
     }
 }
 
@@ -238,14 +259,27 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_fused_kernel<true>, FF_NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         return per_cu * cus;
     }();
-    const int grid = std::min(ntiles, std::max(64, slots_hw - slots_reserve));   // persistent: every workgroup walks tiles
+    const int grid = std::min(ntiles, std::max(256, slots_hw - slots_reserve));   // persistent: every workgroup walks tiles; at one workgroup per CU nothing is held back (as in launch_one)
     const uint4* x = (const uint4*)p0.in;
     uint16_t* y = (uint16_t*)p1.out;
+    static const bool dbg_on = getenv("VC_FF_DBG") != nullptr;
+    long long* dbg = nullptr;
+    if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 32) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 32, s);
     if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
-                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g);
+                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg);
     else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
-                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g);
+                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg);
     VC_HIP(hipGetLastError());
+    if (dbg) {
+        hipStreamSynchronize(s);
+        std::vector<long long> h((size_t)grid * FF_NW * 4);
+        hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        hipFree(dbg);
+        double a[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); ++i) a[i & 3] += (double)h[i];
+        const double per = (double)ntiles / grid * grid * FF_NW;      // (tiles per workgroup) x waves
+        fprintf(stderr, "[vc ff dbg] %d tiles on %d workgroups; us per tile and wave: patch %.2f stem %.2f conv %.2f\n", ntiles, grid, a[0] / per / 100.0, a[1] / per / 100.0, a[3] / per / 100.0);
+    }
     return VC_OK;
 }
 

@@ -100,6 +100,7 @@ struct TrackWgPlan { int tracker, task_begin, task_end, det_begin, det_n, pad0, 
 // can hold during the batch is either a sample it held when the batch began or the normalised feature of one of the batch's own
 // detections, so <sample, detection feature> for ALL pairs is state-independent and is computed up front by a grid-wide kernel.
 // table[row * n_dets + d]: rows [0, n_old_rows) = the old samples (track order, ring position), rows n_old_rows + e = detection e.
+#define VC_ROW_CHUNK 128          // rows of the output arena a tracker workgroup reserves at a time
 struct TrackDotPlan { long long table_off; int n_old_rows, n_dets, row_src_off, tile_begin, tiles, det_tiles, use_table, pad; };
 struct TrackBatchArgs {
     TrackPool pool;

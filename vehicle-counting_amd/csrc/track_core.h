@@ -177,7 +177,9 @@ VC_HD int lsap_core(Lanes L, int nr, int nc, const double* cost, const LapWork& 
 // initially, swap-remove on selection), hence the same assignment; what it saves are the LDS round trips and wave-level
 // synchronisations between the dependent steps of the search.  The scan's total order (value, unassigned, list position) is
 // carried as (value, key) with key = unassigned ? 64 + position : 63 - position, larger key wins among equal values; the
-// reduction runs over the pow2(nc) lanes that can hold a column and lane 0 broadcasts.
+// reduction runs over the pow2(nc) lanes that can hold a column and lane 0 broadcasts.  (Loading a lane's column of a small matrix
+// into registers up front -- eight reads behind one latency instead of one dependent read per scan -- was measured slower: the
+// select chain per scan costs more than the LDS read it replaces; 14.0 vs 12.9 us of matching per step.)
 // On return lane i < nr holds col4row (every row is assigned) and lane j < nc holds row4col (-1: unassigned).
 struct BestK { double v; int key; };
 __device__ __forceinline__ bool better_k(const BestK& a, const BestK& b) {
@@ -276,7 +278,8 @@ __device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const 
 // per-step work arrays (LDS on the device), each with room for `cap` entries
 struct StepWork {
     int cap;
-    int *slot, *state, *tsu, *galc, *galh;                        // per live track (list position t)
+    int *slot, *state, *tsu, *galc, *galh, *hits;                 // per live track (list position t)
+    long long* id;
     int *confirmed, *unconfirmed, *left, *rows, *un_rows, *un_cols, *un_tracks, *match_t, *match_d, *ri, *ci, *newslot;
     unsigned char *row_used, *col_used, *matched;
     LapWork lap;
@@ -285,7 +288,7 @@ struct StepWork {
 };
 
 // bytes of one StepWork with capacity cap (all arrays 8-byte aligned: cap is a multiple of 8)
-VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (5 + 12 + 4) + 8 * 3 + 5); }
+VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (6 + 12 + 4) + 8 * 4 + 5); }
 
 VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     char* p = (char*)base;
@@ -295,8 +298,9 @@ VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     auto I = [&](int*& q) { q = (int*)p; p += (size_t)cap * 4; };
     auto B = [&](unsigned char*& q) { q = (unsigned char*)p; p += (size_t)cap; };
     D(w.lap.u); D(w.lap.v); D(w.lap.spc);
+    w.id = (long long*)p; p += (size_t)cap * 8;
     I(w.lap.path); I(w.lap.row4col); I(w.lap.remaining); I(w.lap.col4row);
-    I(w.slot); I(w.state); I(w.tsu); I(w.galc); I(w.galh);
+    I(w.slot); I(w.state); I(w.tsu); I(w.galc); I(w.galh); I(w.hits);
     I(w.confirmed); I(w.unconfirmed); I(w.left); I(w.rows); I(w.un_rows); I(w.un_cols); I(w.un_tracks); I(w.match_t); I(w.match_d);
     I(w.ri); I(w.ci); I(w.newslot);
     B(w.lap.SR); B(w.lap.SC); B(w.row_used); B(w.col_used); B(w.matched);
@@ -452,6 +456,42 @@ __device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, c
         if (rm == 0) continue;
         const int nl = __popcll(rm), rank = __popcll(rm & lt);
         const bool in = (rm >> lane) & 1ull;
+        if (nl == 1 || n_left == 1) {
+            // One track in the level, or one detection left (most levels of a light scene): the assignment is the minimum of a
+            // vector, smallest index among equal minima (SciPy's scan keeps the LAST unassigned minimum of a list that holds the
+            // columns in descending order; for one column it solves the transpose), and min_cost_matching's list handling
+            // reduces to removing the column when the pair is accepted or moving it to the END of the list when it is rejected
+            // (linear_assignment.py:69-76 appends the rejected pairs after the unassigned entries).
+            const int t1 = __ffsll(rm) - 1;                                   // nl == 1: the track
+            const int d1 = lane_get(left, 0);                                 // n_left == 1: the detection
+            const int n = nl == 1 ? n_left : nl;
+            // nl == 1: lane e scores detection left[e]; n_left == 1: the lane of track t scores itself (key = -rank keeps list order)
+            const bool cand = nl == 1 ? lane < n_left : in;
+            const double v = cost_app[(size_t)(nl == 1 ? t1 : (in ? lane : 0)) * D + (nl == 1 ? left : d1)];
+            BestK b = {(double)INFINITY, INT_MIN};
+            if (cand) { b.v = v > h.max_dist ? h.max_dist + 1e-5 : v; b.key = -(nl == 1 ? lane : rank); }
+            int width = 1;
+            while (width < (nl == 1 ? n : T)) width <<= 1;
+            best_reduce(b, width);
+            const double bv = lane_get(b.v, 0);
+            const int bi = -lane_get(b.key, 0);                               // list position (nl == 1) / rank in the level (n_left == 1)
+            const bool accepted = !(bv > h.max_dist);
+            const int ci = nl == 1 ? bi : 0;                                  // position of the column in `left`
+            const int col = lane_get(left, ci);
+            int trk = t1;
+            if (nl != 1) trk = __ffsll((unsigned long long)__ballot(in && rank == bi)) - 1;
+            const int nxt = __shfl_down(left, 1);
+            if (lane >= ci && lane < n_left - 1) left = nxt;                   // the column leaves its position ...
+            if (!accepted && lane == n_left - 1) left = col;                  // ... and goes to the end when the pair was rejected
+            if (accepted) {
+                if (lane == 0) { w.match_t[n_match] = trk; w.match_d[n_match] = col; }
+                if (lane == trk) matched = true;
+                ++n_match; --n_left;
+                if (lane >= n_left) left = 0;
+            }
+            (void)n;
+            continue;
+        }
         int rows = lane_push(in ? rank : 63, lane);
         if (lane >= nl) rows = 0;
         int un_rows, n_ur, un_cols, n_uc;
@@ -587,12 +627,12 @@ VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, Tr
     const TrackerHdr h = *hdr;
     for (int k = L.lane; k < n_match; k += L.n) {            // Track.update (track.py:126-145); a track is matched at most once
         const int t = w.match_t[k];
-        TrackRecD& r = recs[w.slot[t]];
-        r.hits += 1;
+        const int hits = w.hits[t] + 1;                      // the record's counters were loaded into the work arrays with the step
+        w.hits[t] = hits;
         w.tsu[t] = 0;
         w.galh[t] = (w.galh[t] + 1) % h.nn_budget;
         w.galc[t] = imin(w.galc[t] + 1, h.nn_budget);
-        if (w.state[t] == TENTATIVE && r.hits >= h.n_init) w.state[t] = CONFIRMED;
+        if (w.state[t] == TENTATIVE && hits >= h.n_init) w.state[t] = CONFIRMED;
     }
     for (int k = L.lane; k < n_un; k += L.n) {               // Track.mark_missed (track.py:147-153)
         const int t = w.un_tracks[k];
@@ -602,7 +642,7 @@ VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, Tr
     wave_sync();
     for (int t = L.lane; t < T; t += L.n) {                  // write the counters back (age and time_since_update were advanced at load)
         TrackRecD& r = recs[w.slot[t]];
-        r.state = w.state[t]; r.tsu = w.tsu[t]; r.gal_count = w.galc[t]; r.gal_head = w.galh[t];
+        r.state = w.state[t]; r.tsu = w.tsu[t]; r.gal_count = w.galc[t]; r.gal_head = w.galh[t]; r.hits = w.hits[t];
     }
     const int n_surv = compact(L, T, [&](int t) { return w.state[t] != DELETED; }, [&](int pos, int t) { list[pos] = w.slot[t]; });
     const int n_del = compact(L, T, [&](int t) { return w.state[t] == DELETED; }, [&](int pos, int t) { w.rows[pos] = w.slot[t]; });
@@ -620,20 +660,21 @@ VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, Tr
 }
 
 // deep_sort.py:46-58 + 97-108: rows [x1, y1, x2, y2, id, label] of the confirmed tracks seen within the last frame (box = Kalman
-// posterior, int() truncation, clamped to the frame), in list order.  emit(position, row6) receives them; returns the count.
+// posterior, int() truncation, clamped to the frame), in list order.  Works on the step's arrays after finish_step (positions of the
+// step's START: survivors keep their order and the tracks born in this step are tentative, so this is the list order of the rows).
+// emit(position, row6) receives them; returns the count.
 template <class Emit>
-VC_HD int emit_rows(Lanes L, const int* list, const TrackRecD* recs, const double* mean_pool, int n_tracks, int W, int H, int label, Emit emit) {
-    return compact(L, n_tracks, [&](int t) { const TrackRecD& r = recs[list[t]]; return r.state == CONFIRMED && r.tsu <= 1; },
+VC_HD int emit_rows(Lanes L, const StepWork& w, const double* mean_pool, int T, int W, int H, int label, Emit emit) {
+    return compact(L, T, [&](int t) { return w.state[t] == CONFIRMED && w.tsu[t] <= 1; },
                    [&](int pos, int t) {
-                       const int slot = list[t];
-                       const double* m = mean_pool + (size_t)slot * 8;
-                       const double w = m[2] * m[3], h = m[3];                       // track.py:82-96 to_tlwh
-                       const double x = m[0] - w / 2, y = m[1] - h / 2;
+                       const double* m = mean_pool + (size_t)w.slot[t] * 8;
+                       const double bw = m[2] * m[3], bh = m[3];                     // track.py:82-96 to_tlwh
+                       const double x = m[0] - bw / 2, y = m[1] - bh / 2;
                        long long row[6];
-                       const long long x1 = (long long)x, y1 = (long long)y, x2 = (long long)(x + w), y2 = (long long)(y + h);
+                       const long long x1 = (long long)x, y1 = (long long)y, x2 = (long long)(x + bw), y2 = (long long)(y + bh);
                        row[0] = x1 > 0 ? x1 : 0; row[1] = y1 > 0 ? y1 : 0;
                        row[2] = x2 < W - 1 ? x2 : W - 1; row[3] = y2 < H - 1 ? y2 : H - 1;
-                       row[4] = recs[slot].id; row[5] = label;
+                       row[4] = w.id[t]; row[5] = label;
                        emit(pos, row);
                    });
 }

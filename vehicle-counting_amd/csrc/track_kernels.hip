@@ -102,6 +102,7 @@ __device__ __forceinline__ void kalman_update_wave(double* m, double* P, const d
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define VC_SMALL_D 12       // detections per step up to which the appearance rows run one wave per track (appearance_row_wave)
 #define VC_TRACK_MAX_WAVES 8
+#define VC_TRACK_DYN_LDS (96 * 1024)   // dynamic LDS the tracker kernels may ask for (step_work_bytes(512) = 62.5 KB)
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
@@ -112,6 +113,10 @@ struct TrackShared {
     double small_c[256], small_t[256];   // small assignment problems stay in LDS (StepWork::small_c / small_t)
     double cost_small[2][512];           // the step's appearance / IoU rows when T x D <= 512 (else the workgroup's global scratch)
     int ctl[8];                      // P1 -> P2/P3 hand-over: n_match, n_un, n_new, newdets is w.left, error
+    // the tracker's header and track list live here for the whole walk (global copies are refreshed when the walk ends): a step
+    // then starts and finishes without a dependent global-memory round trip for either
+    TrackerHdr hdr;
+    int list[TC_HARD_CAP];
 };
 
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
@@ -409,7 +414,7 @@ __device__ __forceinline__ bool pool_take(const TrackBatchArgs& a, int n, int* o
 }
 
 __device__ __forceinline__ void report_error(const TrackBatchArgs& a, TrackerHdr* hdr, int code, int tracker, int task) {
-    hdr->err = code;
+    hdr->err = code;                 // the workgroup's copy (sh.hdr); written back with the header when the walk ends
     if (__hip_atomic_exchange(a.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { a.status[1] = tracker; a.status[2] = task; }
 }
 
@@ -429,8 +434,16 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
     step_work_carve(w_lds, track_dyn_lds, a.cap);
     const TrackWgPlan plan = a.plans[blockIdx.x];
     const TrackDotPlan dp = a.dot_plans[blockIdx.x];
-    TrackerHdr* hdr = a.hdrs + plan.tracker;
-    int* list = a.lists + (size_t)plan.tracker * a.list_cap;
+    TrackerHdr* const ghdr = a.hdrs + plan.tracker;
+    int* const glist = a.lists + (size_t)plan.tracker * a.list_cap;
+    TrackerHdr* hdr = &sh.hdr;
+    int* list = sh.list;
+    if (threadIdx.x == 0) sh.hdr = *ghdr;
+    {
+        const int n0 = min(ghdr->n_tracks, (int)TC_HARD_CAP);
+        for (int t = threadIdx.x; t < n0; t += NW * 64) sh.list[t] = glist[t];
+    }
+    __syncthreads();
     char* wg_scratch = (char*)a.scratch + (size_t)blockIdx.x * a.scratch_per_wg;
     double* const cost_app_g = (double*)wg_scratch;         // 4 matrices of TC_MAT doubles: T x D <= TC_MAT whenever T + D <= TC_HARD_CAP
     double* const cost_iou_g = cost_app_g + TC_MAT;
@@ -447,9 +460,12 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
     }
 
 #define VC_TTS(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)task * 16 + (i)] = wall_clock64(); } while (0)
+    int row_base = 0, row_left = 0;                          // wave 0: the part of the row arena this workgroup has reserved
+    TrackTask tk_next = a.tasks[plan.task_begin];
     for (int task = plan.task_begin; task < plan.task_end; ++task) {
         VC_TTS(0);
-        const TrackTask tk = a.tasks[task];
+        const TrackTask tk = tk_next;
+        if (task + 1 < plan.task_end) tk_next = a.tasks[task + 1];       // in flight during this step
         const int T = hdr->n_tracks, D = tk.det_n;
         const int prior = hdr->err;
         const StepWork& w = T + D <= a.cap ? w_lds : w_glb;
@@ -474,6 +490,7 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 const int age = r.age + 1, tsu = r.tsu + 1;
                 r.age = age; r.tsu = tsu;
                 w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head;
+                w.hits[t] = r.hits; w.id[t] = r.id;
             }
             kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane);
         }
@@ -561,14 +578,20 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 pos = __shfl(pos, 0);
                 for (int i = lane; i < nd; i += 64) a.freed[pos + i] = slots[i];
             });
-            const int m = compact(L, n, [&](int t) { const TrackRecD& r = a.recs[list[t]]; return r.state == CONFIRMED && r.tsu <= 1; }, [](int, int) {});
-            int base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add(a.row_cursor, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = __shfl(base, 0);
+            // rows: the arena is handed out in chunks (one atomic per VC_ROW_CHUNK rows instead of one per step)
+            const int m = compact(L, T, [&](int t) { return w.state[t] == CONFIRMED && w.tsu[t] <= 1; }, [](int, int) {});
+            if (m > row_left) {
+                const int grab = max(m, VC_ROW_CHUNK);
+                int b0 = 0;
+                if (lane == 0) b0 = __hip_atomic_fetch_add(a.row_cursor, grab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                row_base = __shfl(b0, 0); row_left = grab;
+            }
+            const int base = row_base;
+            row_base += m; row_left -= m;
             if (base + m > a.rows_cap) {
                 if (lane == 0) { report_error(a, hdr, TERR_ROWS, plan.tracker, task); a.task_row_n[task] = 0; a.task_row_off[task] = 0; }
             } else {
-                emit_rows(L, list, a.recs, tp.mean, n, a.frame_w, a.frame_h, tk.label, [&](int pos, const long long* row) {
+                emit_rows(L, w, tp.mean, T, a.frame_w, a.frame_h, tk.label, [&](int pos, const long long* row) {
                     long long* o = a.rows + (size_t)(base + pos) * 6;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) o[c] = row[c];
@@ -580,6 +603,12 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
         __syncthreads();
         VC_TTS(5);
         if (a.dbg && threadIdx.x == 0) { a.dbg[(size_t)task * 16 + 6] = T; a.dbg[(size_t)task * 16 + 7] = D; }
+    }
+    // the walk is over: header and list go back to global memory (every path above ends in a workgroup barrier)
+    {
+        const int n1 = min(sh.hdr.n_tracks, (int)TC_HARD_CAP);
+        for (int t = threadIdx.x; t < n1; t += NW * 64) glist[t] = sh.list[t];
+        if (threadIdx.x == 0) *ghdr = sh.hdr;
     }
 #undef VC_TTS
 }
@@ -597,7 +626,12 @@ size_t track_scratch_per_wg() { return ((size_t)4 * TC_MAT * sizeof(double) + st
 int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
     if (n_wg <= 0) return VC_OK;
     const size_t lds = step_work_bytes(a.cap);
-    VC_CHECK(a.cap % 8 == 0 && a.cap <= TC_HARD_CAP && lds <= 64 * 1024 - 4096, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
+    static const bool lds_ok = [] {                          // dynamic LDS beyond 64 KB (cap = 512) has to be allowed per kernel
+        return hipFuncSetAttribute((const void*)track_batch_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VC_TRACK_DYN_LDS) == hipSuccess &&
+               hipFuncSetAttribute((const void*)track_batch_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VC_TRACK_DYN_LDS) == hipSuccess;
+    }();
+    VC_CHECK(lds_ok, VC_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the tracker kernel");
+    VC_CHECK(a.cap % 8 == 0 && a.cap <= TC_HARD_CAP && lds <= VC_TRACK_DYN_LDS, VC_ERR_CAPACITY, "tracker step capacity %d does not fit the workgroup's LDS", a.cap);
     VC_CHECK(a.scratch_per_wg >= track_scratch_per_wg(), VC_ERR_ARG, "tracker scratch too small");
     if (a.n_det_total > 0) {
         hipLaunchKernelGGL(track_plan_kernel, dim3(n_wg), dim3(256), 0, s, a);
@@ -688,7 +722,8 @@ __global__ __launch_bounds__(64) void kat_lap_kernel(const double* cost, int nr,
 
 int launch_kat_lap(const double* cost, int nr, int nc, double* tbuf, int* out_rows, int* out_cols, int* out_n, hipStream_t s) {
     const int cap = (std::max(nr, nc) + 7) / 8 * 8;
-    VC_CHECK(step_work_bytes(cap) <= 60 * 1024, VC_ERR_CAPACITY, "lap: at most 512 rows / columns");
+    static const bool lds_ok = hipFuncSetAttribute((const void*)kat_lap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VC_TRACK_DYN_LDS) == hipSuccess;
+    VC_CHECK(lds_ok && step_work_bytes(cap) <= VC_TRACK_DYN_LDS, VC_ERR_CAPACITY, "lap: at most 512 rows / columns");
     hipLaunchKernelGGL(kat_lap_kernel, dim3(1), dim3(64), step_work_bytes(cap), s, cost, nr, nc, cap, tbuf, out_rows, out_cols, out_n);
     VC_HIP(hipGetLastError());
     return VC_OK;

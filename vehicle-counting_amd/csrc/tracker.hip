@@ -220,6 +220,8 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     const size_t o_tlwh = p; p = align16(p + (size_t)n_dets * 32);
     const size_t o_xyah = p; p = align16(p + (size_t)n_dets * 32);
     const size_t o_frow = p; p = align16(p + (size_t)n_dets * 4);
+    rows_cap += n_wg * VC_ROW_CHUNK;                          // the kernel reserves rows in chunks: one unfinished chunk per workgroup
+    s.rows_cap = rows_cap;
     const OutLayout ol = out_layout(n_tasks, rows_cap);
     VC_TRY(stage_reserve(e, s, p, ol.total));
     TrackTask* ht = (TrackTask*)(s.h_in + o_tasks);
