@@ -191,6 +191,14 @@ int vc_comm_init(vc_engine* e, int rank, int world, const void* id128);
 int vc_comm_destroy(vc_engine* e);
 int vc_allgather_counts(vc_engine* e, const int32_t* local, int n, int32_t* out);
 
+/* ---- visualisation egress (off the hot path) --------------------------------------------------------- */
+/* utilities/counting/utils.py:299-331 visualize_merged: draws the annotation overlay into b BGR u8 frames (h x w x 3) in device
+ * memory.  prims12: n x 12 int32 [type, x0, y0, x1, y1, t, colour (B | G << 8 | R << 16), glyph bits lo, glyph bits hi, 0, 0, 0] with
+ * type 0 line (thickness t), 1 disc (radius t), 2 rectangle outline (thickness t), 3 filled box, 4 glyph (5 x 7 bitmap, scale t);
+ * frame f owns prims [frame_first[f], frame_first[f + 1]) and paints them in order.  The host side (overlay.py) builds the lists
+ * the way the reference's draw_* helpers are called.  Pixel parity with OpenCV's rasteriser / fonts is not claimed. */
+int vc_overlay(vc_engine* e, void* frames_dev, int b, int h, int w, const int32_t* prims12, const int32_t* frame_first);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 #define VC_PROF_CONV 0       /* all implicit-GEMM conv launches */
 #define VC_PROF_DETECT_AUX 1 /* letterbox, pools, upsample, decode, NMS */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vc_comm_init": [_vp, _i, _i, _vp],
     "vc_comm_destroy": [_vp],
     "vc_allgather_counts": [_vp, _pi, _i, _pi],
+    "vc_overlay": [_vp, _vp, _i, _i, _i, _pi, _pi],
     "vc_profile_enable": [_vp, _i],
     "vc_profile_conv_busy": [_vp, _pd, _pd],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],

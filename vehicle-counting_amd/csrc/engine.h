@@ -180,6 +180,7 @@ struct vc_engine {
     // ---- count all-gather (counting.hip): RCCL communicator of the engine's process group ----------------------
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     void* d_comm_buf = nullptr; size_t comm_buf_bytes = 0;
+    void* d_overlay = nullptr; size_t overlay_bytes = 0;      // primitive lists of vc_overlay (overlay.hip)
 
     // ---- measurement ----------------------------------------------------------------------------------
     bool profiling = false;
