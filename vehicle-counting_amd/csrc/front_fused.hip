@@ -31,11 +31,19 @@ union ChunkF { uint4 u; bf16x8f h; };
 #define FF_PW (FF_TW + 1)         // layer-0 pixels per parity plane row (17: columns 0, 2, .., 32 / 1, 3, .., 31 + one unused)
 #define FF_PLANE (FF_RH * FF_PW)  // 561
 #define FF_NPIX (2 * FF_PLANE)    // 1122 layer-0 pixel slots
-#define FF_NT0 ((FF_NPIX + 15) / 16)   // 71 stem pixel tiles
+#define FF_NT0 ((FF_NPIX + 15) / 16)   // 71 pixel-tile slots of the LDS tile
+#define FF_NT0R (2 * FF_RH + (FF_RH + 15) / 16)   // 69 row-aligned stem pixel tiles
 #define FF_PR (2 * FF_RH + 4)     // input patch rows (70)
 #define FF_PC (2 * FF_TW + 1 + 2) // input patch pixel pairs per row (35)
 #define FF_PP 36                  // LDS row pitch of the patch in 16-byte chunks
 
+typedef float f32x2f __attribute__((ext_vector_type(2)));
+// SiLU of two values: the multiplies and the add as packed fp32 operations (same IEEE results as the scalar forms)
+__device__ __forceinline__ f32x2f ff_silu2(f32x2f x) {
+    const f32x2f t = x * (f32x2f){-1.442695040888963387f, -1.442695040888963387f};
+    const f32x2f d = (f32x2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + (f32x2f){1.0f, 1.0f};
+    return x * (f32x2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 __device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
 
 template <bool U8>
@@ -133,19 +141,24 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         __syncthreads();
         if (dbg) ts1 = wall_clock64();
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
-        // ---- layer 0 on the region: pixel slot n -> plane n / 289, row (n % 289) / 17, column 2 * ((n % 289) % 17) + plane ----------
-        for (int tb = wave * 2; tb < FF_NT0; tb += 2 * FF_NW) {     // two pixel tiles per pass and wave
+        // ---- layer 0 on the region.  Pixel tiles are ROW-ALIGNED so that a tile's coordinates cost no division: tile r < 33 = row r,
+        // even columns 0 .. 30; tile 33 + r = row r, odd columns 1 .. 31; tiles 66 .. 68 = the 33 pixels of column 32, one row per lane.
+        // LDS slot of a pixel: plane (column parity) * 561 + row * 17 + column / 2, as before. ------------------------------------------
+        const bool interior = gy0 >= 0 && gy0 + FF_RH <= H0 && gx0 >= 0 && gx0 + 2 * FF_TW + 1 <= W0;     // block-uniform: no zero padding of layer 0 in this tile
+        for (int tb = wave * 2; tb < FF_NT0R; tb += 2 * FF_NW) {    // two pixel tiles per pass and wave
             int ly[2], lx[2], slot[2];
             bool live[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int n = (tb + q) * 16 + col;
-                const int pl = n >= FF_PLANE ? 1 : 0, rem = n - pl * FF_PLANE;
-                ly[q] = min(rem / FF_PW, FF_RH - 1);
-                lx[q] = 2 * (rem % FF_PW) + pl;
-                slot[q] = n;
-                live[q] = tb + q < FF_NT0 && n < FF_NPIX && lx[q] <= 2 * FF_TW;       // column 33 of the odd plane does not exist
-                lx[q] = min(lx[q], 2 * FF_TW);
+                const int tq = tb + q;
+                if (tq < 2 * FF_RH) {
+                    const int pl = tq >= FF_RH ? 1 : 0;
+                    ly[q] = tq - pl * FF_RH; lx[q] = 2 * col + pl; live[q] = true;
+                } else {
+                    const int r = (tq - 2 * FF_RH) * 16 + col;
+                    ly[q] = min(r, FF_RH - 1); lx[q] = 2 * FF_TW; live[q] = tq < FF_NT0R && r < FF_RH;
+                }
+                slot[q] = (lx[q] & 1) * FF_PLANE + ly[q] * FF_PW + (lx[q] >> 1);
             }
             f32x4f acc[2][2];
 #pragma unroll
@@ -163,19 +176,24 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                     for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[s][ct].h, xf[q].h, acc[ct][q], 0, 0, 0);
             }
             // bias + SiLU + bf16; lane pairs swap halves across the two pixel tiles (conv_epilogue_bf16): 16 bytes = 8 channels of one pixel
+            bool inside[2] = {true, true};
+            if (!interior) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // layer 1 pads layer 0 with ZEROS: region pixels outside the layer-0 map hold 0, not SiLU(bias)
+                    const int gy = gy0 + ly[q], gx = gx0 + lx[q];
+                    inside[q] = gy >= 0 && gy < H0 && gx >= 0 && gx < W0;
+                }
+            }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float v[4] = {acc[ct][q][0] + bv0[ct].x, acc[ct][q][1] + bv0[ct].y, acc[ct][q][2] + bv0[ct].z, acc[ct][q][3] + bv0[ct].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
-                    // layer 1 pads layer 0 with ZEROS: region pixels outside the layer-0 map hold 0, not SiLU(bias)
-                    const int gy = gy0 + ly[q], gx = gx0 + lx[q];
-                    const bool inside = gy >= 0 && gy < H0 && gx >= 0 && gx < W0;
-                    const bf16x2f p0 = {(__bf16)(inside ? v[0] : 0.f), (__bf16)(inside ? v[1] : 0.f)}, p1 = {(__bf16)(inside ? v[2] : 0.f), (__bf16)(inside ? v[3] : 0.f)};
-                    P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
+                    const f32x2f lo = ff_silu2((f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv0[ct].x, bv0[ct].y});
+                    const f32x2f hi = ff_silu2((f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv0[ct].z, bv0[ct].w});
+                    const bf16x2f p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
+                    P[q].x = inside[q] ? __builtin_bit_cast(uint32_t, p0) : 0u; P[q].y = inside[q] ? __builtin_bit_cast(uint32_t, p1) : 0u;
                 }
                 const u32x2f sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
                 const u32x2f sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
@@ -217,10 +235,9 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float v[4] = {acc[ct][q][0] + bv1[ct].x, acc[ct][q][1] + bv1[ct].y, acc[ct][q][2] + bv1[ct].z, acc[ct][q][3] + bv1[ct].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
-                    const bf16x2f p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
+                    const f32x2f lo = ff_silu2((f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv1[ct].x, bv1[ct].y});
+                    const f32x2f hi = ff_silu2((f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv1[ct].z, bv1[ct].w});
+                    const bf16x2f p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
                     P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
                 }
                 const u32x2f sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
@@ -233,8 +250,8 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         }
         if (dbg && lane == 0) {                            // VC_FF_DBG: per-wave phase sums (100 MHz ticks): patch, stem, barrier wait, conv
             ts3 = wall_clock64();
-            long long* d = dbg + ((size_t)blockIdx.x * FF_NW + wave) * 4;
-            d[0] += ts1 - ts0; d[1] += ts2 - ts1; d[2] += 0; d[3] += ts3 - ts2;
+            long long* d = dbg + ((size_t)blockIdx.x * FF_NW + wave) * 8;
+            d[0] += ts1 - ts0; d[1] += ts2 - ts1; d[3] += ts3 - ts2;
         }
     }
 }
@@ -264,7 +281,7 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     uint16_t* y = (uint16_t*)p1.out;
     static const bool dbg_on = getenv("VC_FF_DBG") != nullptr;
     long long* dbg = nullptr;
-    if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 32) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 32, s);
+    if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 64) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 64, s);
     if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
                            p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg);
     else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
@@ -272,11 +289,11 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     VC_HIP(hipGetLastError());
     if (dbg) {
         hipStreamSynchronize(s);
-        std::vector<long long> h((size_t)grid * FF_NW * 4);
+        std::vector<long long> h((size_t)grid * FF_NW * 8);
         hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         hipFree(dbg);
-        double a[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < h.size(); ++i) a[i & 3] += (double)h[i];
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); ++i) a[i & 7] += (double)h[i];
         const double per = (double)ntiles / grid * grid * FF_NW;      // (tiles per workgroup) x waves
         fprintf(stderr, "[vc ff dbg] %d tiles on %d workgroups; us per tile and wave: patch %.2f stem %.2f conv %.2f\n", ntiles, grid, a[0] / per / 100.0, a[1] / per / 100.0, a[3] / per / 100.0);
     }
