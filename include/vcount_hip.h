@@ -183,6 +183,11 @@ int vc_counter_destroy(vc_counter* c);
 int vc_counter_add(vc_counter* c, const int64_t* frames, const int64_t* track_ids, const int64_t* labels, const int64_t* boxes_xyxy, int n);
 int vc_counter_tracks(const vc_counter* c, int* n);
 int vc_counts(const vc_counter* c, int32_t* out /* n_dir x num_classes */);
+/* utilities/counting/utils.py:154-198 save_tracking_to_csv as columns (colour excluded, Q10): one row per (track, frame) that passed
+ * the zone filter, ordered by label, then by the track's first appearance, then by arrival.  direction = index of the direction line. */
+int vc_counter_rows_count(const vc_counter* c, int64_t* n);
+int vc_counter_rows(const vc_counter* c, int64_t cap, int64_t* track_id, int64_t* frame_id, int64_t* box4, int64_t* label, int32_t* direction,
+                    double* fpoint2, double* lpoint2, int64_t* fframe, int64_t* lframe);
 /* One all-gather of the per-camera count tensors over RCCL / xGMI on the engine's stream.  Rank 0 creates the 128-byte
  * id (vc_comm_unique_id) and hands it to the other ranks by any side channel (the Python shim broadcasts it with torch.distributed);
  * every rank then calls vc_comm_init.  out receives world x n values, rank-major. */

@@ -187,4 +187,11 @@ def test_native_counter_equals_videocounting(golden_dir):
     nat.add(frames[1700:], tracks[1700:], labels[1700:], boxes[1700:])
     np.testing.assert_array_equal(nat.counts(), ref)
     assert ref.sum() > 100
+    # the CSV table (save_tracking_to_csv, colour excluded): same rows, same order, same values
+    got = nat.records()
+    assert len(got) == len(rows) > 1000
+    for g, r in zip(got, rows):
+        assert g == {**r, "color": ""}
+    tab = nat.table()
+    assert tab["box"].shape == (len(rows), 4) and tab["direction"][0] == rows[0]["direction"]
     nat.close()

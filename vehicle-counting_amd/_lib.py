@@ -88,6 +88,8 @@ SIGNATURES = {
     "vc_counter_add": [_vp, _pl, _pl, _pl, _pl, _i],
     "vc_counter_tracks": [_vp, _pi],
     "vc_counts": [_vp, _pi],
+    "vc_counter_rows_count": [_vp, _pl],
+    "vc_counter_rows": [_vp, C.c_int64, _pl, _pl, _pl, _pl, _pi, _pd, _pd, _pl, _pl],
     "vc_comm_unique_id": [_vp],
     "vc_comm_init": [_vp, _i, _i, _vp],
     "vc_comm_destroy": [_vp],

@@ -154,8 +154,8 @@ def count_directions(rows, direction_keys, num_classes):
 
 class NativeCounter:
     """VideoCounting's end state behind the C ABI (vc_counter_* / vc_counts): zone filter, per-track first / last box, direction
-    assignment and the per-(direction, class) counts, fed batch by batch.  Same arithmetic as the functions above; the full
-    track_dict / CSV (with every box of every track) stays with VideoCounting -- this is the tensor the all-gather merges."""
+    assignment, the per-(direction, class) counts (the tensor the all-gather merges) and the CSV table, fed batch by batch.  Same
+    arithmetic and row order as VideoCounting + csv_records above, which the tests hold it equal to."""
 
     def __init__(self, zone_path, num_classes):
         import ctypes as C
@@ -187,6 +187,42 @@ class NativeCounter:
         out = np.zeros((len(self.direction_keys), self.num_classes), np.int32)
         L.check(L.lib().vc_counts(self._h, L.ptr(out, C.c_int)))
         return out
+
+    def table(self):
+        """save_tracking_to_csv's table as columns (numpy arrays, CSV row order); `direction` holds the reference's keys ('01', ...)."""
+        import ctypes as C
+
+        from . import _lib as L
+        n = C.c_int64()
+        L.check(L.lib().vc_counter_rows_count(self._h, C.byref(n)))
+        n = n.value
+        t = {"track_id": np.zeros(n, np.int64), "frame_id": np.zeros(n, np.int64), "box": np.zeros((n, 4), np.int64), "label": np.zeros(n, np.int64),
+             "fpoint": np.zeros((n, 2), np.float64), "lpoint": np.zeros((n, 2), np.float64), "fframe": np.zeros(n, np.int64), "lframe": np.zeros(n, np.int64)}
+        d = np.zeros(n, np.int32)
+        L.check(L.lib().vc_counter_rows(self._h, n, L.ptr(t["track_id"], C.c_int64), L.ptr(t["frame_id"], C.c_int64), L.ptr(t["box"], C.c_int64),
+                                        L.ptr(t["label"], C.c_int64), L.ptr(d, C.c_int), L.ptr(t["fpoint"], C.c_double), L.ptr(t["lpoint"], C.c_double),
+                                        L.ptr(t["fframe"], C.c_int64), L.ptr(t["lframe"], C.c_int64)))
+        t["direction_index"] = d
+        t["direction"] = np.asarray(self.direction_keys, dtype=object)[d] if n else np.zeros(0, dtype=object)
+        return t
+
+    def records(self):
+        """The same rows as csv_records(VideoCounting(...).run(...)) (list of dicts; colour omitted)."""
+        t = self.table()
+        box, fp, lp = t["box"].tolist(), t["fpoint"].tolist(), t["lpoint"].tolist()
+        return [{"track_id": int(t["track_id"][i]), "frame_id": int(t["frame_id"][i]), "box": box[i], "color": "", "label": int(t["label"][i]),
+                 "direction": t["direction"][i], "fpoint": (fp[i][0], fp[i][1]), "lpoint": (lp[i][0], lp[i][1]),
+                 "fframe": int(t["fframe"][i]), "lframe": int(t["lframe"][i])} for i in range(len(box))]
+
+    def save_csv(self, filename):
+        rows = self.records()
+        with open(filename, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(COLUMNS)
+            for r in rows:
+                w.writerow([r["track_id"], r["frame_id"], str(r["box"]), r["color"], r["label"], r["direction"],
+                            str(r["fpoint"]), str(r["lpoint"]), r["fframe"], r["lframe"]])
+        return rows
 
     def close(self):
         from . import _lib as L

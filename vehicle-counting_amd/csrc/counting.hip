@@ -19,9 +19,34 @@ struct vc_counter {
     std::vector<double> polygon;             // x0, y0, x1, y1, ...
     std::vector<double> dirs;                // per direction x0, y0, x1, y1
     int num_classes = 0;
-    struct Rec { int64_t fbox[4], lbox[4], lframe; int at_last; };
-    std::vector<std::map<int64_t, Rec>> tracks;   // per label: track id -> record (counts do not depend on the order)
+    // per label: the tracks in order of first appearance (the reference's dict insertion order = the CSV's row order), every
+    // (frame, box) row of a track in arrival order
+    struct Rec { int64_t id; std::vector<int64_t> frames, boxes; int at_last; };
+    std::vector<std::vector<Rec>> tracks;
+    std::vector<std::map<int64_t, size_t>> index;  // per label: track id -> position in tracks[label]
+    size_t n_rows = 0;
 };
+
+// utilities/counting/utils.py:139-152 find_best_match_direction on the centres of a track's first and last box: index of the
+// direction with the largest cosine, strict '>' from 0, the first direction as fallback (Q11)
+static int best_direction(const vc_counter* c, const int64_t* fbox, const int64_t* lbox, double* fpoint, double* lpoint) {
+    const double fx = (double)(fbox[2] + fbox[0]) / 2, fy = (double)(fbox[3] + fbox[1]) / 2;
+    const double lx = (double)(lbox[2] + lbox[0]) / 2, ly = (double)(lbox[3] + lbox[1]) / 2;
+    if (fpoint) { fpoint[0] = fx; fpoint[1] = fy; }
+    if (lpoint) { lpoint[0] = lx; lpoint[1] = ly; }
+    const double ax = lx - fx, ay = ly - fy;
+    const int nd = (int)(c->dirs.size() / 4);
+    double best = 0;
+    int bi = 0;
+    for (int d = 0; d < nd; ++d) {
+        const double* p = &c->dirs[(size_t)d * 4];
+        const double bx = p[2] - p[0], by = p[3] - p[1];
+        const double den = std::sqrt(ax * ax + ay * ay) * std::sqrt(bx * bx + by * by);
+        const double score = (ax * bx + ay * by) / den;           // 0/0 -> NaN, x/0 -> +-inf, like the reference's numpy division
+        if (score > best) { best = score; bi = d; }
+    }
+    return bi;
+}
 
 using namespace vc;
 
@@ -34,6 +59,7 @@ int vc_counter_create(const double* polygon_xy, int n_points, const double* dir_
     c->dirs.assign(dir_lines, dir_lines + (size_t)n_dir * 4);
     c->num_classes = num_classes;
     c->tracks.resize(num_classes);
+    c->index.resize(num_classes);
     *out = c;
     return VC_OK;
 }
@@ -51,19 +77,23 @@ int vc_counter_add(vc_counter* c, const int64_t* frames, const int64_t* track_id
     for (int i = 0; i < n; ++i) {
         if (!inside[i]) continue;
         VC_CHECK(labels[i] >= 0 && labels[i] < c->num_classes, VC_ERR_ARG, "row %d: label %lld outside [0, %d)", i, (long long)labels[i], c->num_classes);
-        auto& m = c->tracks[labels[i]];
-        auto it = m.find(track_ids[i]);
-        if (it == m.end()) {
-            vc_counter::Rec r{};
-            std::copy(boxes_xyxy + (size_t)i * 4, boxes_xyxy + (size_t)i * 4 + 4, r.fbox);
-            std::copy(r.fbox, r.fbox + 4, r.lbox);
-            r.lframe = frames[i]; r.at_last = 1;
-            m.emplace(track_ids[i], r);
+        auto& idx = c->index[labels[i]];
+        auto& v = c->tracks[labels[i]];
+        auto it = idx.find(track_ids[i]);
+        if (it == idx.end()) {
+            idx.emplace(track_ids[i], v.size());
+            v.emplace_back();
+            vc_counter::Rec& r = v.back();
+            r.id = track_ids[i]; r.at_last = 1;
+            r.frames.push_back(frames[i]);
+            r.boxes.insert(r.boxes.end(), boxes_xyxy + (size_t)i * 4, boxes_xyxy + (size_t)i * 4 + 4);
         } else {
-            vc_counter::Rec& r = it->second;
-            std::copy(boxes_xyxy + (size_t)i * 4, boxes_xyxy + (size_t)i * 4 + 4, r.lbox);
-            if (frames[i] == r.lframe) r.at_last += 1; else { r.lframe = frames[i]; r.at_last = 1; }
+            vc_counter::Rec& r = v[it->second];
+            if (frames[i] == r.frames.back()) r.at_last += 1; else r.at_last = 1;
+            r.frames.push_back(frames[i]);
+            r.boxes.insert(r.boxes.end(), boxes_xyxy + (size_t)i * 4, boxes_xyxy + (size_t)i * 4 + 4);
         }
+        c->n_rows += 1;
     }
     return VC_OK;
 }
@@ -71,7 +101,7 @@ int vc_counter_add(vc_counter* c, const int64_t* frames, const int64_t* track_id
 int vc_counter_tracks(const vc_counter* c, int* n) {
     VC_CHECK(c && n, VC_ERR_ARG, "null argument");
     size_t t = 0;
-    for (const auto& m : c->tracks) t += m.size();
+    for (const auto& v : c->tracks) t += v.size();
     *n = (int)t;
     return VC_OK;
 }
@@ -82,21 +112,36 @@ int vc_counts(const vc_counter* c, int32_t* out) {
     const int nd = (int)(c->dirs.size() / 4);
     std::fill(out, out + (size_t)nd * c->num_classes, 0);
     for (int label = 0; label < c->num_classes; ++label)
-        for (const auto& kv : c->tracks[label]) {
-            const vc_counter::Rec& r = kv.second;
-            const double fx = (double)(r.fbox[2] + r.fbox[0]) / 2, fy = (double)(r.fbox[3] + r.fbox[1]) / 2;
-            const double lx = (double)(r.lbox[2] + r.lbox[0]) / 2, ly = (double)(r.lbox[3] + r.lbox[1]) / 2;
-            const double ax = lx - fx, ay = ly - fy;
-            double best = 0;
-            int bi = 0;
-            for (int d = 0; d < nd; ++d) {
-                const double* p = &c->dirs[(size_t)d * 4];
-                const double bx = p[2] - p[0], by = p[3] - p[1];
-                const double den = std::sqrt(ax * ax + ay * ay) * std::sqrt(bx * bx + by * by);
-                const double score = (ax * bx + ay * by) / den;           // 0/0 -> NaN, x/0 -> +-inf, like the reference's numpy division
-                if (score > best) { best = score; bi = d; }
-            }
+        for (const vc_counter::Rec& r : c->tracks[label]) {
+            const int bi = best_direction(c, r.boxes.data(), r.boxes.data() + r.boxes.size() - 4, nullptr, nullptr);
             out[(size_t)bi * c->num_classes + label] += r.at_last;
+        }
+    return VC_OK;
+}
+
+int vc_counter_rows_count(const vc_counter* c, int64_t* n) {
+    VC_CHECK(c && n, VC_ERR_ARG, "null argument");
+    *n = (int64_t)c->n_rows;
+    return VC_OK;
+}
+
+// The table of save_tracking_to_csv (utilities/counting/utils.py:154-198) as columns: one row per (track, frame), ordered by label,
+// then by the track's first appearance, then by arrival.  direction = index into the direction lines given at creation.
+int vc_counter_rows(const vc_counter* c, int64_t cap, int64_t* track_id, int64_t* frame_id, int64_t* box4, int64_t* label, int32_t* direction,
+                    double* fpoint2, double* lpoint2, int64_t* fframe, int64_t* lframe) {
+    VC_CHECK(c && track_id && frame_id && box4 && label && direction && fpoint2 && lpoint2 && fframe && lframe, VC_ERR_ARG, "null argument");
+    VC_CHECK(cap >= (int64_t)c->n_rows, VC_ERR_CAPACITY, "%lld rows, room for %lld", (long long)c->n_rows, (long long)cap);
+    size_t k = 0;
+    for (int lab = 0; lab < c->num_classes; ++lab)
+        for (const vc_counter::Rec& r : c->tracks[lab]) {
+            double fp[2], lp[2];
+            const int d = best_direction(c, r.boxes.data(), r.boxes.data() + r.boxes.size() - 4, fp, lp);
+            for (size_t i = 0; i < r.frames.size(); ++i, ++k) {
+                track_id[k] = r.id; frame_id[k] = r.frames[i]; label[k] = lab; direction[k] = d;
+                std::copy(r.boxes.begin() + i * 4, r.boxes.begin() + i * 4 + 4, box4 + k * 4);
+                fpoint2[k * 2] = fp[0]; fpoint2[k * 2 + 1] = fp[1]; lpoint2[k * 2] = lp[0]; lpoint2[k * 2 + 1] = lp[1];
+                fframe[k] = r.frames.front(); lframe[k] = r.frames.back();
+            }
         }
     return VC_OK;
 }
