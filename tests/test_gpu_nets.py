@@ -134,6 +134,23 @@ def test_embed_crops(frames, precision):
     eng.close()
 
 
+def test_crop_resize_per_crop_kernel(frames):
+    """crop_resize_wg_kernel (one workgroup per crop, tap tables in LDS, exact two-instruction /255) against the per-pixel kernel it
+    replaces in the bf16 path: identical embeddings bit for bit (same crops: resized, clamped at the frame border, exactly 50 x 50)."""
+    sd = synth_reid(1702)
+    eng = E.Engine(None, sd, precision="bf16", max_crops=16, max_frame_hw=(360, 640))
+    boxes = np.array([[100.3, 80.7, 60.2, 90.9], [320.0, 200.0, 50.0, 50.0], [10.0, 12.0, 40.0, 60.0], [630.0, 350.0, 80.0, 70.0],
+                      [300.5, 180.5, 101.0, 33.0], [200.0, 100.0, 7.0, 160.0], [400.0, 300.0, 200.0, 3.0]])
+    a = eng.embed(frames[0], boxes)
+    os.environ["VC_CROP_PER_PIXEL"] = "1"
+    try:
+        b = eng.embed(frames[0], boxes)
+    finally:
+        del os.environ["VC_CROP_PER_PIXEL"]
+    assert np.array_equal(a, b)
+    eng.close()
+
+
 @pytest.mark.parametrize("hw", [(640, 640), (360, 640), (480, 352)])
 def test_front_fused_layers_0_1_bit_identical(hw):
     """front_fused.hip (stem + 3x3/s2 conv in one kernel, layer 0 kept in LDS; used by the stream path on u8 frames) against the

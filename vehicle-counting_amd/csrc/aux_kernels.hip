@@ -536,8 +536,68 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
     }
 }
 
+// The same arithmetic with one workgroup per crop (the throughput path: bf16, 8 channels per pixel): the interpolation taps and
+// weights of the 50 columns and 50 rows are computed once per crop into LDS (two fp64 divisions each) instead of once per
+// output pixel, u8 / 255 is the two-instruction exact form (div255_exact, vc_common.h), a pixel leaves as one 16-byte store.
+// Bit-identical to crop_resize_kernel<false> (tests/test_gpu_nets.py::test_crop_resize_per_crop_kernel).
+__global__ __launch_bounds__(256) void crop_resize_wg_kernel(const uint8_t* __restrict__ frames, int H, int W, const int* __restrict__ crops5,
+                                                            uint4* __restrict__ dst) {
+    constexpr int S = VC_REID_SIZE;
+    __shared__ int tap[2][S][2];
+    __shared__ float wgt[2][S][2];
+    const int n = blockIdx.x;
+    const int* cr = crops5 + n * 5;
+    const int x1 = cr[1], y1 = cr[2], cw = cr[3] - cr[1], chh = cr[4] - cr[2];
+    uint4* out = dst + (size_t)n * S * S;
+    if (!(cw > 0 && chh > 0)) {
+        for (int i = threadIdx.x; i < S * S; i += blockDim.x) out[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    if (threadIdx.x < 2 * S) {
+        const int axis = threadIdx.x / S, d = threadIdx.x - axis * S;
+        int s0, s1; float c0, c1;
+        if (axis == 0) lin_coef_f(d, cw, 1.0 / ((double)S / (double)cw), s0, s1, c0, c1, true);
+        else lin_coef_f(d, chh, 1.0 / ((double)S / (double)chh), s0, s1, c0, c1, false);
+        tap[axis][d][0] = s0; tap[axis][d][1] = s1; wgt[axis][d][0] = c0; wgt[axis][d][1] = c1;
+    }
+    __syncthreads();
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const uint8_t* im = frames + ((size_t)cr[0] * H + y1) * W * 3 + (size_t)x1 * 3;
+    const bool same = cw == S && chh == S;
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+        const int y = i / S, x = i - y * S;
+        float v[3];
+        if (same) {
+            const uint8_t* q = im + ((size_t)y * W + x) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = div255_exact((float)q[c]);
+        } else {
+            const int sx0 = tap[0][x][0], sx1 = tap[0][x][1], sy0 = tap[1][y][0], sy1 = tap[1][y][1];
+            const float a0 = wgt[0][x][0], a1 = wgt[0][x][1], b0 = wgt[1][y][0], b1 = wgt[1][y][1];
+            const uint8_t* r0 = im + (size_t)sy0 * W * 3;
+            const uint8_t* r1 = im + (size_t)sy1 * W * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p00 = div255_exact((float)r0[sx0 * 3 + c]), p01 = div255_exact((float)r0[sx1 * 3 + c]);
+                const float p10 = div255_exact((float)r1[sx0 * 3 + c]), p11 = div255_exact((float)r1[sx1 * 3 + c]);
+                const float h0 = __fadd_rn(__fmul_rn(p00, a0), __fmul_rn(p01, a1));
+                const float h1 = __fadd_rn(__fmul_rn(p10, a0), __fmul_rn(p11, a1));
+                v[c] = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+            }
+        }
+        const uint32_t o0 = f32_to_bf16((v[0] - mean[0]) / stdv[0]), o1 = f32_to_bf16((v[1] - mean[1]) / stdv[1]), o2 = f32_to_bf16((v[2] - mean[2]) / stdv[2]);
+        out[i] = make_uint4(o0 | (o1 << 16), o2, 0u, 0u);
+    }
+}
+
 int launch_crop_resize(const uint8_t* frames, int H, int W, const int* crops5, int k, void* dst, int cpad, int prec, hipStream_t s) {
     if (k <= 0) return VC_OK;
+    const bool per_pixel = getenv("VC_CROP_PER_PIXEL") != nullptr;                 // tests: the per-pixel instance of the bf16 path (read per call)
+    if (prec != PREC_F32 && cpad == 8 && !per_pixel) {
+        hipLaunchKernelGGL(crop_resize_wg_kernel, dim3(k), dim3(256), 0, s, frames, H, W, crops5, (uint4*)dst);
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     const long total = (long)k * VC_REID_SIZE * VC_REID_SIZE;
     if (prec == PREC_F32) hipLaunchKernelGGL(crop_resize_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, H, W, crops5, k, dst, cpad);
     else hipLaunchKernelGGL(crop_resize_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, H, W, crops5, k, dst, cpad);
