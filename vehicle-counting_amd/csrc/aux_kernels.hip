@@ -286,36 +286,37 @@ __device__ __forceinline__ uint32_t kmax(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
-template <bool F32>
+template <bool F32, int WS>        // WS 32-bit words of a pixel per workgroup (32: 128-byte slices; 16: 64-byte slices, two workgroups per CU)
 __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
     constexpr int ES = F32 ? 4 : 2;
-    constexpr int CW = 128 / ES;                                         // channels per workgroup
-    extern __shared__ __attribute__((aligned(16))) uint32_t smw[];       // two planes of [H*W][32] words
+    constexpr int CW = WS * 4 / ES;                                      // channels per workgroup
+    constexpr int NPG = 1024 / WS;                                       // positions per pass (16 waves hide the LDS latency)
+    extern __shared__ __attribute__((aligned(16))) uint32_t smw[];       // two planes of [H*W][WS] words
     const int groups = C / CW;
     const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * CW;
     const int H = cat.H, W = cat.W, n = H * W;
     uint32_t* P = smw;
-    uint32_t* T = smw + (size_t)n * 32;
-    const int w = threadIdx.x & 31, pg = threadIdx.x >> 5;               // word of the slice, position group (32 per pass: 16 waves hide the LDS latency)
+    uint32_t* T = smw + (size_t)n * WS;
+    const int w = threadIdx.x % WS, pg = threadIdx.x / WS;               // word of the slice, position group
     char* base = (char*)cat.ptr + (((size_t)b * n) * cat.cs + cat.co + c0) * ES + w * 4;
     const size_t pstride = (size_t)cat.cs * ES;
-    for (int i = pg; i < n; i += 32) P[i * 32 + w] = to_key<F32>(*(const uint32_t*)(base + i * pstride));
+    for (int i = pg; i < n; i += NPG) P[i * WS + w] = to_key<F32>(*(const uint32_t*)(base + i * pstride));
     __syncthreads();
     const uint32_t NEG = 0u;                                             // smallest key (below -inf)
     for (int round = 1; round <= 3; ++round) {
-        for (int i = pg; i < n; i += 32) {                                // row pass
+        for (int i = pg; i < n; i += NPG) {                               // row pass
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = kmax<F32>(m, P[(y * W + xx) * 32 + w]);
-            T[i * 32 + w] = m;
+            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = kmax<F32>(m, P[(y * W + xx) * WS + w]);
+            T[i * WS + w] = m;
         }
         __syncthreads();
-        for (int i = pg; i < n; i += 32) {                                // column pass + store of this round's slice
+        for (int i = pg; i < n; i += NPG) {                               // column pass + store of this round's slice
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = kmax<F32>(m, T[(yy * W + x) * 32 + w]);
+            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = kmax<F32>(m, T[(yy * W + x) * WS + w]);
             *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = from_key<F32>(m);
-            P[i * 32 + w] = m;                                           // own position only: no hazard with other threads' T reads
+            P[i * WS + w] = m;                                           // own position only: no hazard with other threads' T reads
         }
         __syncthreads();
     }
@@ -378,17 +379,22 @@ int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
     }
     const int n = prec == PREC_F32 ? 4 : 8;
     VC_CHECK(C % n == 0 && cat.cs % n == 0 && cat.co % n == 0, VC_ERR_ARG, "sppf: channel alignment");
-    const int cw = prec == PREC_F32 ? 32 : 64;
-    const size_t lds_wide = (size_t)2 * cat.H * cat.W * 128;
+    // 64-byte slices when two such workgroups fit a CU's LDS (every workgroup of a 128-frame batch is then resident at once:
+    // the kernel is six LDS passes and seven barriers long, i.e. latency-bound), else 128-byte slices
+    const size_t plane = (size_t)2 * cat.H * cat.W * 4;                  // bytes per word of slice width
+    const int ws = plane * 16 <= 76 * 1024 ? 16 : 32;
+    const int cw = ws * 4 / (prec == PREC_F32 ? 4 : 2);
+    const size_t lds_wide = plane * ws;
     if (C % cw == 0 && cat.cs % 2 == 0 && cat.co % 2 == 0 && lds_wide <= 150 * 1024) {
         const int blocks = cat.B * (C / cw);
-        if (prec == PREC_F32) {
-            VC_HIP(hipFuncSetAttribute((const void*)sppf_pool_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
-            hipLaunchKernelGGL(sppf_pool_wide_kernel<true>, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
-        } else {
-            VC_HIP(hipFuncSetAttribute((const void*)sppf_pool_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
-            hipLaunchKernelGGL(sppf_pool_wide_kernel<false>, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
-        }
+        auto go = [&](auto kernel) {
+            if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide) != hipSuccess) return VC_ERR_HIP;
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
+            return VC_OK;
+        };
+        const int rc = prec == PREC_F32 ? (ws == 16 ? go(sppf_pool_wide_kernel<true, 16>) : go(sppf_pool_wide_kernel<true, 32>))
+                                        : (ws == 16 ? go(sppf_pool_wide_kernel<false, 16>) : go(sppf_pool_wide_kernel<false, 32>));
+        VC_CHECK(rc == VC_OK, VC_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the SPPF pool kernel");
         VC_HIP(hipGetLastError());
         return VC_OK;
     }
