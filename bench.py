@@ -47,7 +47,7 @@ WORKLOADS = {
                       clip=int(os.environ.get("VC_BENCH_CLIP", 512)), n_obj=12, inject=0, obj_shift=1.0,
                       desc="YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])"),
     "l1280-fp8": dict(model="yolov5l", size=1280, precision="fp8", B=int(os.environ.get("VC_BENCH_B", 16)), clip=64, n_obj=16, inject=16,
-                      obj_shift=-8.0,      # the random head of the deep variant would pass most of its 100 800 candidates per frame
+                      det_scale=1.0, obj_shift=-24.0,   # calibrated like the 640 workload: 20-80 boxes per frame survive the random head's NMS (tools/head_calib.py)
                       desc="YOLOv5l 1280x1280 single camera stream per GPU, fp8 MX-MFMA detector convs (BASELINE.json configs[4]), "
                            "16 ground-truth rectangles per frame injected after the conv stack"),
 }
@@ -108,7 +108,7 @@ class Stream:
         inject = wl["inject"] if inject is None else inject
         clip = clip or wl["clip"]
         clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
-        self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=4.0, obj_shift=wl["obj_shift"])
+        self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
         per_frame = max(64, 2 * max(inject, n_obj))
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,

@@ -267,6 +267,22 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(View cat, int C) {
 // non-negative ones the sign bit set.  bf16 pairs are keyed per half, so the 30 max() of a position are one v_pk_max_u16
 // (v_max_u32 for fp32) each instead of an unpack / two fmaxf / repack; keys are turned back into values on the way out.
 // (No NaNs reach this kernel: its input is the SiLU output of a finite convolution.)
+// fp8 (e4m3fn) planes: max-pooling only selects, so it runs on an order-preserving integer key of the byte (sign-magnitude ->
+// biased unsigned) and stores the winner's byte; 4 channels per thread.
+__device__ __forceinline__ unsigned int fp8_key4(unsigned int v) {           // per byte: b ^ (b & 0x80 ? 0xff : 0x80)
+    const unsigned int neg = (v >> 7) & 0x01010101u;
+    return v ^ (0x80808080u | (neg * 0x7fu));
+}
+__device__ __forceinline__ unsigned int fp8_unkey4(unsigned int k) {        // inverse: key >= 0x80 was a positive byte (k ^ 0x80), else negative (k ^ 0xff)
+    const unsigned int pos = (k >> 7) & 0x01010101u;
+    return k ^ (0xffffffffu ^ (pos * 0x7fu));
+}
+__device__ __forceinline__ unsigned int umax4(unsigned int a, unsigned int b) {
+    unsigned int r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const unsigned int x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff; r |= (x > y ? x : y) << (8 * i); }
+    return r;
+}
 template <bool F32>
 __device__ __forceinline__ uint32_t to_key(uint32_t v) {
     if (F32) return v ^ (((int32_t)v >> 31) | 0x80000000u);
@@ -286,9 +302,20 @@ __device__ __forceinline__ uint32_t kmax(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
-template <bool F32, int WS>        // WS 32-bit words of a pixel per workgroup (32: 128-byte slices; 16: 64-byte slices, two workgroups per CU)
+// element type of the plane: 0 = fp32, 1 = bf16 pairs, 2 = fp8 (e4m3fn) quads
+template <int ET> __device__ __forceinline__ uint32_t word_key(uint32_t v) { return ET == 2 ? fp8_key4(v) : to_key<ET == 0>(v); }
+template <int ET> __device__ __forceinline__ uint32_t word_unkey(uint32_t k) { return ET == 2 ? fp8_unkey4(k) : from_key<ET == 0>(k); }
+template <int ET> __device__ __forceinline__ uint32_t word_max(uint32_t a, uint32_t b) {
+    if (ET == 2) {
+        typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u8x4, a), __builtin_bit_cast(u8x4, b)));
+    }
+    return kmax<ET == 0>(a, b);
+}
+
+template <int ET, int WS>          // WS 32-bit words of a pixel per workgroup (32: 128-byte slices ... 4: 16-byte slices)
 __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
-    constexpr int ES = F32 ? 4 : 2;
+    constexpr int ES = ET == 0 ? 4 : (ET == 1 ? 2 : 1);
     constexpr int CW = WS * 4 / ES;                                      // channels per workgroup
     constexpr int NPG = 1024 / WS;                                       // positions per pass (16 waves hide the LDS latency)
     extern __shared__ __attribute__((aligned(16))) uint32_t smw[];       // two planes of [H*W][WS] words
@@ -300,44 +327,29 @@ __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
     const int w = threadIdx.x % WS, pg = threadIdx.x / WS;               // word of the slice, position group
     char* base = (char*)cat.ptr + (((size_t)b * n) * cat.cs + cat.co + c0) * ES + w * 4;
     const size_t pstride = (size_t)cat.cs * ES;
-    for (int i = pg; i < n; i += NPG) P[i * WS + w] = to_key<F32>(*(const uint32_t*)(base + i * pstride));
+    for (int i = pg; i < n; i += NPG) P[i * WS + w] = word_key<ET>(*(const uint32_t*)(base + i * pstride));
     __syncthreads();
     const uint32_t NEG = 0u;                                             // smallest key (below -inf)
     for (int round = 1; round <= 3; ++round) {
         for (int i = pg; i < n; i += NPG) {                               // row pass
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = kmax<F32>(m, P[(y * W + xx) * WS + w]);
+            for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); ++xx) m = word_max<ET>(m, P[(y * W + xx) * WS + w]);
             T[i * WS + w] = m;
         }
         __syncthreads();
         for (int i = pg; i < n; i += NPG) {                               // column pass + store of this round's slice
             const int y = i / W, x = i - y * W;
             uint32_t m = NEG;
-            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = kmax<F32>(m, T[(yy * W + x) * WS + w]);
-            *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = from_key<F32>(m);
+            for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); ++yy) m = word_max<ET>(m, T[(yy * W + x) * WS + w]);
+            *(uint32_t*)(base + i * pstride + (size_t)round * C * ES) = word_unkey<ET>(m);
             P[i * WS + w] = m;                                           // own position only: no hazard with other threads' T reads
         }
         __syncthreads();
     }
 }
 
-// fp8 (e4m3fn) planes: max-pooling only selects, so it runs on an order-preserving integer key of the byte (sign-magnitude ->
-// biased unsigned) and stores the winner's byte; 4 channels per thread.
-__device__ __forceinline__ unsigned int fp8_key4(unsigned int v) {           // per byte: b ^ (b & 0x80 ? 0xff : 0x80)
-    const unsigned int neg = (v >> 7) & 0x01010101u;
-    return v ^ (0x80808080u | (neg * 0x7fu));
-}
-__device__ __forceinline__ unsigned int fp8_unkey4(unsigned int k) {        // inverse: key >= 0x80 was a positive byte (k ^ 0x80), else negative (k ^ 0xff)
-    const unsigned int pos = (k >> 7) & 0x01010101u;
-    return k ^ (0xffffffffu ^ (pos * 0x7fu));
-}
-__device__ __forceinline__ unsigned int umax4(unsigned int a, unsigned int b) {
-    unsigned int r = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const unsigned int x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff; r |= (x > y ? x : y) << (8 * i); }
-    return r;
-}
+// fp8 fallback for planes that do not fit LDS: every output reads its 13 x 13 window (4 channels per thread)
 __global__ __launch_bounds__(256) void sppf_pool_fp8_kernel(View cat, int C) {
     const int cv = C / 4;
     const long total = (long)cat.B * cat.H * cat.W * cv;
@@ -370,8 +382,35 @@ __global__ __launch_bounds__(256) void sppf_pool_fp8_kernel(View cat, int C) {
 }
 
 int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
+    const int es = prec == PREC_F32 ? 4 : (prec == PREC_FP8 ? 1 : 2);
+    VC_CHECK(C % 4 == 0 && cat.cs % 4 == 0 && cat.co % 4 == 0, VC_ERR_ARG, "sppf: channel alignment");
+    // The wide LDS kernel with the widest slice that fits: 64-byte (or narrower) slices when two such workgroups fit a CU's LDS
+    // (every workgroup of a 128-frame batch is then resident at once -- the kernel is six LDS passes and seven barriers long, i.e.
+    // latency-bound), wider ones otherwise.
+    const size_t plane = (size_t)2 * cat.H * cat.W * 4;                  // bytes per word of slice width
+    int ws = 0;
+    for (int cand : {16, 8, 4})
+        if (!ws && plane * cand <= 76 * 1024 && C % (cand * 4 / es) == 0) ws = cand;
+    for (int cand : {32, 16, 8, 4})
+        if (!ws && plane * cand <= 150 * 1024 && C % (cand * 4 / es) == 0) ws = cand;
+    if (ws && (cat.cs * es) % 4 == 0 && (cat.co * es) % 4 == 0) {
+        const int cw = ws * 4 / es;
+        const size_t lds_wide = plane * ws;
+        const int blocks = cat.B * (C / cw);
+        auto go = [&](auto kernel) {
+            if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide) != hipSuccess) return (int)VC_ERR_HIP;
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
+            return (int)VC_OK;
+        };
+        int rc = VC_ERR_ARG;
+#define VC_SPPF_GO(ET) rc = ws == 32 ? go(sppf_pool_wide_kernel<ET, 32>) : ws == 16 ? go(sppf_pool_wide_kernel<ET, 16>) : ws == 8 ? go(sppf_pool_wide_kernel<ET, 8>) : go(sppf_pool_wide_kernel<ET, 4>)
+        if (prec == PREC_F32) { VC_SPPF_GO(0); } else if (prec == PREC_FP8) { VC_SPPF_GO(2); } else { VC_SPPF_GO(1); }
+#undef VC_SPPF_GO
+        VC_CHECK(rc == VC_OK, VC_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the SPPF pool kernel");
+        VC_HIP(hipGetLastError());
+        return VC_OK;
+    }
     if (prec == PREC_FP8) {
-        VC_CHECK(C % 4 == 0 && cat.cs % 4 == 0 && cat.co % 4 == 0, VC_ERR_ARG, "sppf fp8: channel alignment");
         const long total = (long)cat.B * cat.H * cat.W * (C / 4);
         hipLaunchKernelGGL(sppf_pool_fp8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, cat, C);
         VC_HIP(hipGetLastError());
@@ -379,25 +418,6 @@ int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
     }
     const int n = prec == PREC_F32 ? 4 : 8;
     VC_CHECK(C % n == 0 && cat.cs % n == 0 && cat.co % n == 0, VC_ERR_ARG, "sppf: channel alignment");
-    // 64-byte slices when two such workgroups fit a CU's LDS (every workgroup of a 128-frame batch is then resident at once:
-    // the kernel is six LDS passes and seven barriers long, i.e. latency-bound), else 128-byte slices
-    const size_t plane = (size_t)2 * cat.H * cat.W * 4;                  // bytes per word of slice width
-    const int ws = plane * 16 <= 76 * 1024 ? 16 : 32;
-    const int cw = ws * 4 / (prec == PREC_F32 ? 4 : 2);
-    const size_t lds_wide = plane * ws;
-    if (C % cw == 0 && cat.cs % 2 == 0 && cat.co % 2 == 0 && lds_wide <= 150 * 1024) {
-        const int blocks = cat.B * (C / cw);
-        auto go = [&](auto kernel) {
-            if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide) != hipSuccess) return VC_ERR_HIP;
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_wide, s, cat, C);
-            return VC_OK;
-        };
-        const int rc = prec == PREC_F32 ? (ws == 16 ? go(sppf_pool_wide_kernel<true, 16>) : go(sppf_pool_wide_kernel<true, 32>))
-                                        : (ws == 16 ? go(sppf_pool_wide_kernel<false, 16>) : go(sppf_pool_wide_kernel<false, 32>));
-        VC_CHECK(rc == VC_OK, VC_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the SPPF pool kernel");
-        VC_HIP(hipGetLastError());
-        return VC_OK;
-    }
     const size_t lds = (size_t)2 * cat.H * cat.W * n * sizeof(float);
     if (lds <= 150 * 1024) {
         const int blocks = cat.B * (C / n);

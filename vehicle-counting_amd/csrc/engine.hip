@@ -456,8 +456,11 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 } else if (stem_direct_on && stem_direct_applicable(cp)) {   // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
-                    if (e->stem_src && cp.in == e->ybuf["in"].ptr) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s));   // letterbox folded in
-                    else VC_TRY(launch_stem_direct(cp, s));
+                    // fp8 engine: the stem also writes the e4m3 copy the next layer reads (TO_FP8 of its own output, folded in)
+                    const View* q8 = nx && nx->kind == Op::TO_FP8 && nx->a.ptr == cp.out && nx->a.co == cp.out_co ? &nx->b : nullptr;
+                    if (e->stem_src && cp.in == e->ybuf["in"].ptr) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s, q8, 1.0f / e->act_scale));   // letterbox folded in
+                    else VC_TRY(launch_stem_direct(cp, s, q8, 1.0f / e->act_scale));
+                    if (q8) ++oi;                                            // the conversion op is done
                 } else if (reid_stem_on && nx && nx->kind == Op::MAXPOOL && nx->a.ptr == cp.out && reid_stem_applicable(cp, nx->b.cs, nx->b.co)) {
                     cp.cfg = 101;                                            // ReID stem: conv + ReLU + MaxPool in one kernel (reid_stem.hip)
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);

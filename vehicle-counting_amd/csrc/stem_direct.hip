@@ -26,7 +26,8 @@ union ChunkS { uint4 u; bf16x8s h; };
 template <int CT, bool U8>   // Cout = CT * 16
 __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w, const float* __restrict__ bias,
                                                           uint16_t* __restrict__ y, int B, int H, int Wp, int Ho, int Wo, int Kw8 /* weight row stride in chunks */,
-                                                          int out_cs, int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g) {
+                                                          int out_cs, int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g,
+                                                          uint8_t* __restrict__ y8, int q_cs, int q_co, float q_inv_scale) {
     __shared__ uint4 patch[STEM_PR * STEM_PP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -134,8 +135,21 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const uint4* __restric
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
                 const int ptm = pt + (odd ? 1 : 0);
                 const int oy = oy0 + wave * 2 + (ptm >> 1), ox = ox0 + (ptm & 1) * 16 + col;
-                if (oy < Ho && ox < Wo)
+                if (oy < Ho && ox < Wo) {
                     *(uint4*)(y + (((size_t)b * Ho + oy) * Wo + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
+                    if (y8) {       // fp8 engine: the e4m3 copy the next layer reads, from the bf16-rounded values (= bf16_to_fp8_kernel on y)
+                        const unsigned int wv[4] = {o4.x, o4.y, o4.z, o4.w};
+                        float f[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f[2 * j] = __builtin_amdgcn_fmed3f(__uint_as_float(wv[j] << 16) * q_inv_scale, -448.0f, 448.0f);
+                            f[2 * j + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(wv[j] & 0xffff0000u) * q_inv_scale, -448.0f, 448.0f);
+                        }
+                        unsigned int q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0u, false); q0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], q0, true);
+                        unsigned int q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0u, false); q1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], q1, true);
+                        *(uint2*)(y8 + (((size_t)b * Ho + oy) * Wo + ox) * q_cs + q_co + ct * 16 + (kq & ~1) * 4) = make_uint2(q0, q1);
+                    }
+                }
             }
         }
     }
@@ -148,7 +162,9 @@ bool stem_direct_applicable(const ConvP& p) {
            p.Cout <= 64 && p.Kp >= 160 && p.out_cs % 8 == 0 && p.out_co % 8 == 0;
 }
 
-static int launch_stem_impl(const ConvP& p, const uint8_t* src8, const LetterboxGeom& g, hipStream_t s) {
+static int launch_stem_impl(const ConvP& p, const uint8_t* src8, const LetterboxGeom& g, hipStream_t s, const View* q8 = nullptr, float q_inv_scale = 1.0f) {
+    uint8_t* y8 = q8 ? (uint8_t*)q8->ptr : nullptr;
+    const int q_cs = q8 ? q8->cs : 0, q_co = q8 ? q8->co : 0;
     const int tiles_x = (p.Wo + STEM_TW - 1) / STEM_TW, tiles_y = (p.Ho + STEM_TH - 1) / STEM_TH;
     const int ntiles = p.B * tiles_x * tiles_y;
     const int grid = std::min(ntiles, 256 * 3 - 64); // 3 workgroups per CU can be resident (VGPRs); 64 slots stay free for the tracker stream (conv_igemm.hip)
@@ -157,9 +173,9 @@ static int launch_stem_impl(const ConvP& p, const uint8_t* src8, const Letterbox
     const int kw8 = p.Kp / 8;
 #define VC_STEM_LAUNCH(CT)                                                                                                          \
     if (src8) launch_timed(p, stem_direct_kernel<CT, true>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8, \
-                           p.out_cs, p.out_co, tiles_x, tiles_y, src8, g);                                                             \
+                           p.out_cs, p.out_co, tiles_x, tiles_y, src8, g, y8, q_cs, q_co, q_inv_scale);                                  \
     else launch_timed(p, stem_direct_kernel<CT, false>, dim3(grid), dim3(256), 0, s, x, w, p.bias, y, p.B, p.H, p.W, p.Ho, p.Wo, kw8,    \
-                      p.out_cs, p.out_co, tiles_x, tiles_y, src8, g);
+                      p.out_cs, p.out_co, tiles_x, tiles_y, src8, g, y8, q_cs, q_co, q_inv_scale);
     switch (p.Cout / 16) {
         case 1: VC_STEM_LAUNCH(1) break;
         case 2: VC_STEM_LAUNCH(2) break;
@@ -172,7 +188,7 @@ static int launch_stem_impl(const ConvP& p, const uint8_t* src8, const Letterbox
     return VC_OK;
 }
 
-int launch_stem_direct(const ConvP& p, hipStream_t s) { return launch_stem_impl(p, nullptr, LetterboxGeom{}, s); }
+int launch_stem_direct(const ConvP& p, hipStream_t s, const View* q8, float q_inv_scale) { return launch_stem_impl(p, nullptr, LetterboxGeom{}, s, q8, q_inv_scale); }
 
 // no-resize geometry only (the frame is already at network scale), pairs never straddle the image edge (even left pad and
 // width), 2-byte aligned pair reads (even source width)
@@ -181,9 +197,9 @@ bool stem_u8_applicable(const ConvP& p, const LetterboxGeom& g) {
            g.net_h == p.H && g.net_w == 2 * p.W;
 }
 
-int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s) {
+int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s, const View* q8, float q_inv_scale) {
     if (!frames || !stem_u8_applicable(p, g)) return VC_ERR_ARG;
-    return launch_stem_impl(p, frames, g, s);
+    return launch_stem_impl(p, frames, g, s, q8, q_inv_scale);
 }
 
 }  // namespace vc

@@ -150,11 +150,12 @@ int launch_conv(const ConvP& p, hipStream_t s);
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument checks: for the autotuner
 int conv_num_cfgs();
 bool stem_direct_applicable(const ConvP& p);                    // stem_direct.hip: YOLO 6x6/s2 stem in bf16
-int launch_stem_direct(const ConvP& p, hipStream_t s);
+struct View;
+int launch_stem_direct(const ConvP& p, hipStream_t s, const View* q8 = nullptr, float q_inv_scale = 1.0f);   // q8: also write the e4m3 copy of the output
 struct LetterboxGeom;
 // the same with the letterbox folded into the patch fetch: reads the u8 frames directly (no-resize geometry, even source width)
 bool stem_u8_applicable(const ConvP& p, const LetterboxGeom& g);
-int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s);
+int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const LetterboxGeom& g, hipStream_t s, const View* q8 = nullptr, float q_inv_scale = 1.0f);
 // front_fused.hip: YOLO layers 0 + 1 (stem + 3x3 / s2) in one kernel, the stem's output never leaves the CU
 bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
