@@ -123,7 +123,7 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
     }
     const int n = finish_step(L, w, &h.hdr, h.list.data(), h.recs.data(), T, n_match, n_un, n_new, [&](const int* slots, int nd) { for (int i = 0; i < nd; ++i) h.free_stack.push_back(slots[i]); });
     (void)n;
-    h.n_rows = emit_rows(L, w, h.mean.data(), T, W, H, label,
+    h.n_rows = emit_rows(L, w, [&](int t) -> const double* { return &h.mean[(size_t)w.slot[t] * 8]; }, T, W, H, label,
                          [&](int pos, const long long* row) { memcpy(&h.rows[(size_t)pos * 6], row, 6 * sizeof(long long)); });
     return 0;
 }

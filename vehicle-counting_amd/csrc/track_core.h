@@ -663,11 +663,11 @@ VC_HD int finish_step(Lanes L, const StepWork& w, TrackerHdr* hdr, int* list, Tr
 // posterior, int() truncation, clamped to the frame), in list order.  Works on the step's arrays after finish_step (positions of the
 // step's START: survivors keep their order and the tracks born in this step are tentative, so this is the list order of the rows).
 // emit(position, row6) receives them; returns the count.
-template <class Emit>
-VC_HD int emit_rows(Lanes L, const StepWork& w, const double* mean_pool, int T, int W, int H, int label, Emit emit) {
+template <class MeanOf, class Emit>
+VC_HD int emit_rows(Lanes L, const StepWork& w, MeanOf mean_of, int T, int W, int H, int label, Emit emit) {
     return compact(L, T, [&](int t) { return w.state[t] == CONFIRMED && w.tsu[t] <= 1; },
                    [&](int pos, int t) {
-                       const double* m = mean_pool + (size_t)w.slot[t] * 8;
+                       const double* m = mean_of(t);                                  // posterior mean of list position t
                        const double bw = m[2] * m[3], bh = m[3];                     // track.py:82-96 to_tlwh
                        const double x = m[0] - bw / 2, y = m[1] - bh / 2;
                        long long row[6];

@@ -44,7 +44,8 @@ __device__ __forceinline__ void kalman_initiate_wave(double* m, double* P, const
     if (lane < 8) m[lane] = lane < 4 ? z[lane] : 0.0;
 }
 
-__device__ __forceinline__ void kalman_predict_wave(double* m, double* P, int lane) {
+// m2 / P2 (optional): a second copy of the predicted state (the step's LDS copy, read by the cost rows, the update and the rows)
+__device__ __forceinline__ void kalman_predict_wave(double* m, double* P, int lane, double* m2 = nullptr, double* P2 = nullptr) {
     const int r = lane >> 3, c = lane & 7;
     const double h = m[3];
     const double sp = VC_W_POS * h, sv = VC_W_VEL * h;
@@ -59,10 +60,19 @@ __device__ __forceinline__ void kalman_predict_wave(double* m, double* P, int la
     // every load above feeds a value stored below, so all lanes' loads have returned before the first store issues
     P[lane] = v;
     if (lane < 4) m[lane] = mk;
+    if (m2) {
+        P2[lane] = v;
+        if (lane < 8) m2[lane] = lane < 4 ? mk : m[lane];
+    }
 }
 
-__device__ __forceinline__ void kalman_update_wave(double* m, double* P, const double* z, int lane, volatile double* kbuf) {
+// ms / Ps (optional): where the prior is read from (the step's LDS copy of what m / P hold); the posterior goes to m / P and,
+// the mean, to ms as well
+__device__ __forceinline__ void kalman_update_wave(double* mg, double* Pg, const double* z, int lane, volatile double* kbuf, double* ms = nullptr,
+                                                   const double* Ps = nullptr) {
     const int r = lane >> 3, c = lane & 7;
+    const double* m = ms ? ms : mg;
+    const double* P = Ps ? Ps : Pg;
     double S[16], L[16];
     project4(m, P, S);
     chol4(S, L);
@@ -95,13 +105,14 @@ __device__ __forceinline__ void kalman_update_wave(double* m, double* P, const d
         for (int q = 0; q < 4; ++q) skt += S[a * 4 + q] * Kc[q];
         v += Kr[a] * skt;
     }
-    P[lane] = prc - v;
-    if (lane < 8) m[lane] = nm;
+    Pg[lane] = prc - v;
+    if (lane < 8) { mg[lane] = nm; if (ms) ms[lane] = nm; }
 }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define VC_SMALL_D 12       // detections per step up to which the appearance rows run one wave per track (appearance_row_wave)
 #define VC_TRACK_MAX_WAVES 8
+#define VC_STEP_STATE 64         // tracks whose Kalman state a step keeps in LDS (larger steps read the pool in global memory)
 #define VC_TRACK_DYN_LDS (96 * 1024)   // dynamic LDS the tracker kernels may ask for (step_work_bytes(512) = 62.5 KB)
 
 // LDS scratch of one tracker workgroup
@@ -117,6 +128,10 @@ struct TrackShared {
     // then starts and finishes without a dependent global-memory round trip for either
     TrackerHdr hdr;
     int list[TC_HARD_CAP];
+    // the step's copy of the Kalman state of up to VC_STEP_STATE tracks (list position t): written by the predict, read by the cost
+    // rows and the update, posterior mean read by the row emission -- no global-memory round trip between the phases of a step
+    double st_mean[VC_STEP_STATE][8];
+    double st_cov[VC_STEP_STATE][64];
 };
 
 // One workgroup (4 waves) per job = one confirmed track against a contiguous range of detections.
@@ -361,15 +376,14 @@ __global__ __launch_bounds__(256) void track_dots_kernel(const TrackBatchArgs a,
 // One wave per track: the gated appearance row from the precomputed table.  Lane = detection (coalesced reads of a table row),
 // loop over the track's ring entries; cost = 1 - max_s <g_s, f_d> / |f_d|.
 __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, const TrackDotPlan& dp, const CostJob& jb, int det_local0,
-                                                     double* out, int lane) {
+                                                     double* out, int lane, const double* m, const double* Pm) {
     const TrackPool& tp = a.pool;
     const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
-    const double* m = tp.mean + (size_t)jb.slot * 8;
     const float* tab = a.dot_arena + dp.table_off;
     double Lc[16];
     {
         double Sg[16];
-        project4(m, tp.cov + (size_t)jb.slot * 64, Sg);
+        project4(m, Pm, Sg);
         chol4(Sg, Lc);
     }
     // lanes = (sample group, detection): with D detections the wave splits into 64 / pow2(D) sample groups, each lane walks every
@@ -483,6 +497,9 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
             continue;
         }
         // ---- P0: Track.predict (track.py:112-124) + cost rows -------------------------------------------------------------
+        // Steps of up to VC_STEP_STATE tracks (lean instance): a wave predicts a track into the pool AND into the step's LDS copy and
+        // goes straight on to that track's cost rows -- no workgroup barrier and no global-memory round trip in between.
+        const bool use_st = TABLE && T <= VC_STEP_STATE;                 // block-uniform
         for (int t = wave; t < T; t += NW) {
             const int slot = list[t];
             if (lane == 0) {
@@ -492,18 +509,33 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head;
                 w.hits[t] = r.hits; w.id[t] = r.id;
             }
-            kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane);
+            kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane, use_st ? sh.st_mean[t] : nullptr, use_st ? sh.st_cov[t] : nullptr);
+            if (use_st && D > 0) {
+                wave_sync();                                             // the wave's own LDS writes (work arrays, state copy)
+                const int st = w.state[t], tsu = w.tsu[t];
+                if (st == CONFIRMED) {
+                    const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
+                    appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, sh.st_mean[t], sh.st_cov[t]);
+                }
+                if (!(st == CONFIRMED && tsu != 1)) {
+                    double b[4];
+                    mean_to_tlwh(sh.st_mean[t], b);
+                    for (int d = lane; d < D; d += 64)
+                        cost_iou[(size_t)t * D + d] = tsu > 1 ? VC_GATED : 1.0 - iou_tlwh(b, a.det_tlwh + (size_t)(tk.det_off + d) * 4);
+                }
+            }
         }
-        __syncthreads();
+        if (!use_st) __syncthreads();
         VC_TTS(1);
-        if (D > 0 && (TABLE || dp.use_table || D <= VC_SMALL_D)) {
+        if (use_st) {
+        } else         if (D > 0 && (TABLE || dp.use_table || D <= VC_SMALL_D)) {
             // one wave per track, no workgroup barriers: rows from the precomputed dot table (the normal case), or computed here
             // for a few detections when the table did not fit the arena
             for (int t = wave; t < T; t += NW) {
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    if (TABLE || dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane);
+                    if (TABLE || dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64);
                     else if constexpr (!TABLE) appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
                 }
                 if (!(st == CONFIRMED && tsu != 1)) {
@@ -554,7 +586,8 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
         for (int k = wave; k < n_match + n_new; k += NW) {
             if (k < n_match) {                                           // Track.update (track.py:126-145)
                 const int t = w.match_t[k], g = tk.det_off + w.match_d[k], slot = w.slot[t];
-                kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave]);
+                kalman_update_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, a.det_xyah + (size_t)g * 4, lane, sh.kbuf[wave],
+                                   use_st ? sh.st_mean[t] : nullptr, use_st ? sh.st_cov[t] : nullptr);
                 float* dst = tp.gallery + ((size_t)slot * tp.budget_cap + w.galh[t]) * VC_FEAT_DIM;
                 ((float4*)dst)[lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[lane];              // the normalised feature (track_norm_kernel)
                 ((float4*)dst)[64 + lane] = ((const float4*)(a.nfeat + (size_t)g * VC_FEAT_DIM))[64 + lane];
@@ -591,7 +624,8 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
             if (base + m > a.rows_cap) {
                 if (lane == 0) { report_error(a, hdr, TERR_ROWS, plan.tracker, task); a.task_row_n[task] = 0; a.task_row_off[task] = 0; }
             } else {
-                emit_rows(L, w, tp.mean, T, a.frame_w, a.frame_h, tk.label, [&](int pos, const long long* row) {
+                auto mean_of = [&](int t) -> const double* { return use_st ? sh.st_mean[t] : tp.mean + (size_t)w.slot[t] * 8; };
+                emit_rows(L, w, mean_of, T, a.frame_w, a.frame_h, tk.label, [&](int pos, const long long* row) {
                     long long* o = a.rows + (size_t)(base + pos) * 6;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) o[c] = row[c];
