@@ -134,6 +134,28 @@ def test_embed_crops(frames, precision):
     eng.close()
 
 
+@pytest.mark.parametrize("hw", [(640, 640), (360, 640), (416, 352)])
+def test_c3_fused_bit_identical(hw):
+    """c3_fused.hip (the first C3 block in one kernel: y1, y2, b1, m in LDS) against the four launches it replaces: the block's output
+    (layer 2) identical bit for bit, also where tiles hang over the right / bottom edge (H/4 not a multiple of 8, W/4 not of 16)."""
+    H, W = hw
+    nc = 8
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0)
+    fr = synth_frames(3, H, W, n_obj=6, seed=5)
+    eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=3, max_frame_hw=(H, W))
+    eng.detect([f[:, :, ::-1] for f in fr])
+    a = eng.debug_layer(2, batch=3)
+    os.environ["VC_C3_FUSED"] = "0"
+    try:
+        eng.detect([f[:, :, ::-1] for f in fr])
+        b = eng.debug_layer(2, batch=3)
+    finally:
+        del os.environ["VC_C3_FUSED"]
+    assert a.shape == b.shape and a.shape[-1] == 64 and np.abs(b).max() > 0.1
+    assert np.array_equal(a, b)
+    eng.close()
+
+
 def test_crop_resize_per_crop_kernel(frames):
     """crop_resize_wg_kernel (one workgroup per crop, tap tables in LDS, exact two-instruction /255) against the per-pixel kernel it
     replaces in the bf16 path: identical embeddings bit for bit (same crops: resized, clamped at the frame border, exactly 50 x 50)."""

@@ -443,6 +443,30 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 static const int front_fused_mode = getenv("VC_FRONT_FUSED") ? atoi(getenv("VC_FRONT_FUSED")) : 1;   // 0 off, 1 stream path, 2 always
                 const bool fuse_front = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv) &&
                                         (front_fused_mode == 2 || (e->stem_src && cp.in == e->ybuf["in"].ptr));
+                const bool c3_fused_on = !(getenv("VC_C3_FUSED") && atoi(getenv("VC_C3_FUSED")) == 0);       // read per call: the tests toggle it
+                const bool fuse_c3 = c3_fused_on && oi + 3 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV && ops[oi + 3].kind == Op::CONV &&
+                                     c3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv, ops[oi + 3].conv);
+                if (fuse_c3) {                                                // the first C3 block in one kernel (c3_fused.hip): y1, y2, b1, m stay in LDS
+                    double flc = fl;
+                    for (int j = 1; j <= 3; ++j) flc += 2.0 * ops[oi + j].conv.M * (double)ops[oi + j].conv.Cout * ops[oi + j].C;
+                    const ConvP& o3 = ops[oi + 3].conv;
+                    double wbytes = 0;
+                    for (int j = 0; j <= 3; ++j) wbytes += (double)ops[oi + j].conv.Cout * ops[oi + j].conv.K * es;
+                    const double byc = (double)cp.B * cp.H * cp.W * cp.Cin * es + wbytes + (double)o3.M * o3.Cout * es;
+                    cp.cfg = 103;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flc; e->prof_pairs[e->prof_used - 1].bytes = byc; }   // the pair armed above times all four layers
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, flc, byc, s);
+                        VC_TRY(launch_c3_fused(cp, ops[oi + 1].conv, ops[oi + 2].conv, ops[oi + 3].conv, s));
+                    }
+                    if (e->profiling && e->op_log.size() < (1u << 20)) {
+                        char line[256];
+                        snprintf(line, sizeof(line), "conv M=%d N=%d K=%d k=1x1 s=1 cfg=103 ms=%.4f tflops=%.1f\n", cp.M, 64, 64, e->last_ms, flc / (e->last_ms * 1e-3) / 1e12);
+                        e->op_log += line;
+                    }
+                    oi += 3;                                                  // m.cv1, m.cv2 and cv3 are done
+                    break;
+                }
                 if (fuse_front) {                                             // YOLO layers 0 + 1 in one kernel (front_fused.hip): layer 0 never reaches HBM
                     const Op& o1 = *nx;
                     const double fl1 = 2.0 * o1.conv.M * (double)o1.conv.Cout * o1.C;
