@@ -156,6 +156,45 @@ def test_c3_fused_bit_identical(hw):
     eng.close()
 
 
+_BNECK_SCRIPT = r"""
+import os, sys
+import numpy as np
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.synth import synth_frames
+from vehicle_counting_amd.weights import synth_yolo
+for H, W in ((640, 640), (360, 640), (416, 352)):
+    sd = synth_yolo("yolov5s", nc=8, seed=1702, det_scale=4.0, obj_shift=0.0)
+    fr = synth_frames(3, H, W, n_obj=6, seed=5)
+    eng = E.Engine(sd, None, precision="bf16", num_classes=8, max_batch=3, max_frame_hw=(H, W))
+    eng.detect([f[:, :, ::-1] for f in fr])
+    a = [eng.debug_layer(l, batch=3) for l in (4, 17)]
+    os.environ["VC_BNECK_FUSED"] = "0"
+    eng.detect([f[:, :, ::-1] for f in fr])
+    b = [eng.debug_layer(l, batch=3) for l in (4, 17)]
+    del os.environ["VC_BNECK_FUSED"]
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.abs(y).max() > 0.1
+        assert np.array_equal(x, y), (H, W, float((x == y).mean()))
+    eng.close()
+print("BNECK_OK")
+"""
+
+
+def test_bneck_fused_bit_identical():
+    """bneck_fused.hip (a 64-channel Bottleneck, 1x1 + 3x3 [+ shortcut], in one kernel with b1 in LDS) against the two launches it
+    replaces, at the outputs of the blocks that contain it: layer 4 (both bottlenecks of the second backbone C3, with the shortcut)
+    and layer 17 (the P3 head C3, without), tiles hanging over the edges included.  Bit for bit against the implicit-GEMM form of the
+    3x3 (same tap-major k order): the comparison runs in its own process with VC_AUTOTUNE=0, because the halo-staged 3x3 variants the
+    autotuner may pick sum the K tiles slice-major and differ from BOTH in the last bf16 bit of a few values."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC_AUTOTUNE="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("VC_TUNE_CACHE", None)
+    r = subprocess.run([sys.executable, "-c", _BNECK_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BNECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_crop_resize_per_crop_kernel(frames):
     """crop_resize_wg_kernel (one workgroup per crop, tap tables in LDS, exact two-instruction /255) against the per-pixel kernel it
     replaces in the bf16 path: identical embeddings bit for bit (same crops: resized, clamped at the frame border, exactly 50 x 50)."""

@@ -467,6 +467,26 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     oi += 3;                                                  // m.cv1, m.cv2 and cv3 are done
                     break;
                 }
+                const bool bneck_fused_on = !(getenv("VC_BNECK_FUSED") && atoi(getenv("VC_BNECK_FUSED")) == 0);    // read per call: the tests toggle it
+                if (bneck_fused_on && nx && nx->kind == Op::CONV && bneck_fused_applicable(cp, nx->conv)) {   // 64-channel Bottleneck in one kernel (bneck_fused.hip)
+                    const ConvP& o2 = nx->conv;
+                    const double flb = fl + 2.0 * o2.M * (double)o2.Cout * nx->C;
+                    const double byb = (double)cp.B * cp.H * cp.W * cp.Cin * es * (o2.res_mode != RES_NONE ? 1.0 : 1.0) + ((double)cp.Cout * cp.K + (double)o2.Cout * o2.K) * es +
+                                       (double)o2.M * o2.Cout * es;
+                    cp.cfg = 104;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flb; e->prof_pairs[e->prof_used - 1].bytes = byb; }
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, flb, byb, s);
+                        VC_TRY(launch_bneck_fused(cp, o2, s));
+                    }
+                    if (e->profiling && e->op_log.size() < (1u << 20)) {
+                        char line[256];
+                        snprintf(line, sizeof(line), "conv M=%d N=%d K=%d k=3x3 s=1 cfg=104 ms=%.4f tflops=%.1f\n", cp.M, 64, 640, e->last_ms, flb / (e->last_ms * 1e-3) / 1e12);
+                        e->op_log += line;
+                    }
+                    ++oi;                                                     // the 3x3 conv is done
+                    break;
+                }
                 if (fuse_front) {                                             // YOLO layers 0 + 1 in one kernel (front_fused.hip): layer 0 never reaches HBM
                     const Op& o1 = *nx;
                     const double fl1 = 2.0 * o1.conv.M * (double)o1.conv.Cout * o1.C;

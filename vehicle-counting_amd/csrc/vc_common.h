@@ -159,6 +159,8 @@ int launch_stem_direct_u8(const ConvP& p, const uint8_t* frames, const Letterbox
 // front_fused.hip: YOLO layers 0 + 1 (stem + 3x3 / s2) in one kernel, the stem's output never leaves the CU
 bool c3_fused_applicable(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, const ConvP& p3);     // c3_fused.hip: the first C3 block (64 -> 64, n = 1) in one kernel
 int launch_c3_fused(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, const ConvP& p3, hipStream_t s);
+bool bneck_fused_applicable(const ConvP& pm1, const ConvP& pm2);                                     // bneck_fused.hip: a 64-channel Bottleneck (1x1 + 3x3 [+ shortcut]) in one kernel
+int launch_bneck_fused(const ConvP& pm1, const ConvP& pm2, hipStream_t s);
 bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
