@@ -6,7 +6,7 @@
 // Same construction as c3_fused.hip: a workgroup owns an 8 x 16 tile of output pixels, computes b1 on the tile's 10 x 18 halo region
 // into LDS (pixels outside the image hold 0: the 3x3 pads b1 with zeros) and convolves it from there.  The weights of both layers
 // (8 + 72 KB in MFMA fragment order) stay in LDS for the whole launch, which leaves room for ONE workgroup per CU: eight waves, two
-// per SIMD.  LDS: y on the halo region (two 32-channel planes, 24 KB), b1 likewise (24 KB), weights 80 KB = 128 KB.
+// per SIMD.  LDS: b1 of two tiles on their halo regions (two 32-channel planes each, 2 x 24 KB), weights 80 KB = 128 KB.
 // MFMA operand order and k order (tap-major, then the two 32-channel halves of a tap) equal conv_igemm_kernel's; the epilogues are
 // conv_epilogue_bf16's expressions.
 #include <algorithm>
@@ -52,10 +52,13 @@ struct BnArgs {
     int B, H, W, tiles_x, tiles_y, res;
 };
 
+// Two groups of four waves work on DIFFERENT tiles at the same time: the producers (waves 4-7) compute b1 of tile k + 1 -- few MFMAs,
+// many SiLU transcendentals, operands straight from global memory (a 1x1 needs no staging) -- while the consumers (waves 0-3) run the
+// 3x3 of tile k from the b1 buffer the producers filled one step earlier: MFMA- and LDS-heavy.  Every SIMD holds one wave of each
+// group, so one group's MFMAs cover the other's quarter-rate v_exp / v_rcp; b1 is double-buffered, one workgroup barrier per tile.
 __global__ __launch_bounds__(BN_NW * 64) void bneck_fused_kernel(const BnArgs a) {
     const bool RES = a.res != 0;                            // launch-uniform: the block has a shortcut
-    __shared__ uint4 ys[2 * BN_NP * 4];                    // 24 KB: the block's input y, [32-channel plane][pixel slot][4 chunks]
-    __shared__ uint4 bs[2 * BN_NP * 4];                    // 24 KB: b1 likewise
+    __shared__ uint4 bs[2][2 * BN_NP * 4];                 // 2 x 24 KB: b1 of two tiles, [32-channel plane][pixel slot][4 chunks]
     __shared__ uint4 w1s[2 * 4 * 64];                      // 8 KB: cv1, [k step][channel tile][lane]
     __shared__ uint4 w2s[18 * 4 * 64];                     // 72 KB: cv2, [k step = 2 tap + half][channel tile][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -69,113 +72,122 @@ __global__ __launch_bounds__(BN_NW * 64) void bneck_fused_kernel(const BnArgs a)
         const int l = i & 63, ct = (i >> 6) & 3, s = i >> 8;
         w2s[i] = a.w2[(size_t)(ct * 16 + (l & 15)) * a.kw2 + 4 * s + (l >> 4)];
     }
-    // cv1: a wave's unit = (pixel tile, channel half); cv2: rows 2 (w & 3), 2 (w & 3) + 1 and channel half w >> 2
-    const int rp = wave & 3, ch0 = (wave >> 2) * 2;
-    float4 bv1[4], bv2[2];
+    const bool producer = wave >= 4;
+    const int gw = wave & 3;
+    float4 bv[4];                                           // producers: cv1's bias, consumers: cv2's
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv1[ct] = *(const float4*)(a.b1 + ct * 16 + kq * 4);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) bv2[ct] = *(const float4*)(a.b2 + (ch0 + ct) * 16 + kq * 4);
-
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const float4*)((producer ? a.b1 : a.b2) + ct * 16 + kq * 4);
     const int ntiles = a.B * a.tiles_y * a.tiles_x;
-    constexpr int NPRE = (BN_NH * 8 + NT - 1) / NT;        // 3 chunks of the y halo tile per thread
-    uint4 pre[NPRE];
-    auto fetch = [&](int t) {
+    const int nk = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // tiles of this workgroup
+    const bool odd = (kq & 1) != 0;
+    __syncthreads();                                        // weights are in LDS
+
+    // producers: the y fragments (MFMA B operands) of a tile's three pixel tiles of this wave, loaded one tile ahead
+    uint4 yf[3][2], yn[3][2];
+    auto load_y = [&](int t, uint4 (&dst)[3][2]) {
         const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
-        const int y0 = ty * BN_TH - 1, x0 = tx * BN_TW - 1;
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = threadIdx.x + k * NT;
-            const int n = i >> 3, c = i & 7;
+        for (int j = 0; j < 3; ++j) {
+            const int n = (gw * 3 + j) * 16 + col;
             const int ry = (n * 3641) >> 16, rx = n - ry * BN_RW;             // n / 18 for n < 192
-            const int gy = y0 + ry, gx = x0 + rx;
-            pre[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (n < BN_NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                pre[k] = *(const uint4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + c * 8);
+            const int gy = ty * BN_TH - 1 + ry, gx = tx * BN_TW - 1 + rx;
+            dst[j][0] = make_uint4(0u, 0u, 0u, 0u); dst[j][1] = dst[j][0];
+            if (n < BN_NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const uint16_t* px = a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + kq * 8;
+                dst[j][0] = *(const uint4*)px; dst[j][1] = *(const uint4*)(px + 32);
+            }
         }
     };
-    char* ysb = (char*)ys;
-    char* bsb = (char*)bs;
-    const bool odd = (kq & 1) != 0;
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
-        const int oy0 = ty * BN_TH, ox0 = tx * BN_TW;
-        __syncthreads();                                    // the previous tile's 3x3 pass (reads bs, ys) is done
+    if (producer && nk > 0) load_y(blockIdx.x, yf);
+    for (int k = 0; k <= nk; ++k) {
+        if (producer) {
+            if (k < nk) {
+                // ---- cv1 (1x1) of tile k on its halo region -> bs[k & 1]; pixels outside the image hold 0 (the 3x3 pads b1 with zeros) ------
+                const int t = blockIdx.x + k * gridDim.x;
+                if (k + 1 < nk) load_y(t + gridDim.x, yn);
+                const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y;
+                char* bsb = (char*)bs[k & 1];
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = threadIdx.x + k * NT;
-            const int n = i >> 3, c = i & 7;
-            if (n < BN_NH) *(uint4*)(ysb + (c >> 2) * BN_PLANE + bn_addr(n, c & 3)) = pre[k];
-        }
-        __syncthreads();
-        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);                // in flight during both passes
-
-        // ---- cv1 (1x1) on the halo region: 12 pixel tiles x 2 channel halves = 24 units over 8 waves ---------------------------------
-        for (int u = wave; u < 2 * BN_NT; u += BN_NW) {
-            const int pt = u >> 1, cth = (u & 1) * 2;
-            const int n = pt * 16 + col;
-            ChunkB y0f, y1f;
-            y0f.u = *(const uint4*)(ysb + bn_addr(n, kq));
-            y1f.u = *(const uint4*)(ysb + BN_PLANE + bn_addr(n, kq));
-            const int ry = (n * 3641) >> 16, rx = n - ry * BN_RW;
-            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
-            const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                for (int j = 0; j < 3; ++j) {
+                    const int n = (gw * 3 + j) * 16 + col;
+                    const int ry = (n * 3641) >> 16, rx = n - ry * BN_RW;
+                    const int gy = ty * BN_TH - 1 + ry, gx = tx * BN_TW - 1 + rx;
+                    const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    ChunkB y0f, y1f;
+                    y0f.u = yf[j][0]; y1f.u = yf[j][1];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const int ct = cth + c2;
-                ChunkB w0, w1;
-                w0.u = w1s[(0 * 4 + ct) * 64 + lane]; w1.u = w1s[(1 * 4 + ct) * 64 + lane];
-                f32x4b acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.h, y0f.h, (f32x4b){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.h, y1f.h, acc, 0, 0, 0);
-                const float4 bb = ct == 0 ? bv1[0] : ct == 1 ? bv1[1] : ct == 2 ? bv1[2] : bv1[3];
-                const f32x2b lo = bn_silu2((f32x2b){acc[0], acc[1]} + (f32x2b){bb.x, bb.y});
-                const f32x2b hi = bn_silu2((f32x2b){acc[2], acc[3]} + (f32x2b){bb.z, bb.w});
-                const bf16x2b p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
-                uint2 v = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
-                if (!inimg) v = make_uint2(0u, 0u);
-                // channel tile ct = channels 16 ct .. 16 ct + 15: plane ct >> 1, chunks 2 (ct & 1) and 2 (ct & 1) + 1 of the pixel
-                if (n < BN_NH) *(uint2*)(bsb + (ct >> 1) * BN_PLANE + bn_addr(n, (ct & 1) * 2 + (kq >> 1)) + (kq & 1) * 8) = v;
-            }
-        }
-        __syncthreads();
-        // ---- cv2 (3x3) on the interior [+ shortcut] -> HBM ---------------------------------------------------------------------------------
-        {
-            f32x4b acc[2][2];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4b){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const int tyy = tp / 3, txx = tp % 3;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    ChunkB bf[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) bf[q].u = *(const uint4*)(bsb + hf * BN_PLANE + bn_addr((rp * 2 + q + tyy) * BN_RW + col + txx, kq));
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        ChunkB w;
-                        w.u = w2s[((tp * 2 + hf) * 4 + ch0 + ct) * 64 + lane];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, bf[q].h, acc[ct][q], 0, 0, 0);
+                    for (int ct = 0; ct < 4; ++ct) {
+                        ChunkB w0, w1;
+                        w0.u = w1s[(0 * 4 + ct) * 64 + lane]; w1.u = w1s[(1 * 4 + ct) * 64 + lane];
+                        f32x4b acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.h, y0f.h, (f32x4b){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.h, y1f.h, acc, 0, 0, 0);
+                        const f32x2b lo = bn_silu2((f32x2b){acc[0], acc[1]} + (f32x2b){bv[ct].x, bv[ct].y});
+                        const f32x2b hi = bn_silu2((f32x2b){acc[2], acc[3]} + (f32x2b){bv[ct].z, bv[ct].w});
+                        const bf16x2b p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
+                        uint2 v = make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
+                        if (!inimg) v = make_uint2(0u, 0u);
+                        // channel tile ct = channels 16 ct .. 16 ct + 15: plane ct >> 1, chunks 2 (ct & 1) and 2 (ct & 1) + 1 of the pixel
+                        if (n < BN_NH) *(uint2*)(bsb + (ct >> 1) * BN_PLANE + bn_addr(n, (ct & 1) * 2 + (kq >> 1)) + (kq & 1) * 8) = v;
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { yf[j][0] = yn[j][0]; yf[j][1] = yn[j][1]; }
+            }
+        } else if (k >= 1) {
+            // ---- cv2 (3x3) of tile k - 1 from bs[(k - 1) & 1] [+ shortcut] -> HBM: wave gw owns rows 2 gw, 2 gw + 1, all 64 channels -------
+            const int t = blockIdx.x + (k - 1) * gridDim.x;
+            const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+            const int oy0 = ty * BN_TH, ox0 = tx * BN_TW;
+            const char* bsb = (const char*)bs[(k - 1) & 1];
+            uint2 rs[4][2];                                 // the shortcut: this lane's 4 channels of its pixel per (channel tile, row), read ahead
+            if (RES) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int oy = oy0 + gw * 2 + q, ox = ox0 + col;
+                    const bool ok = oy < a.H && ox < a.W;
+                    const uint16_t* px = a.x + (((size_t)b * a.H + min(oy, a.H - 1)) * a.W + min(ox, a.W - 1)) * a.in_cs + a.in_co + kq * 4;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) rs[ct][q] = ok ? *(const uint2*)(px + ct * 16) : make_uint2(0u, 0u);
+                }
+            }
+            f32x4b acc[4][2];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4b){0.f, 0.f, 0.f, 0.f};
+            // 18 k steps (tap-major, then the tap's two 32-channel halves), software-pipelined by hand: the six fragment reads of step
+            // s + 1 are issued BEFORE the eight MFMAs of step s (the scheduling barriers keep hipcc from sinking them back next to their
+            // uses, where every pair of MFMAs waited for an LDS read)
+            ChunkB bfr[2][2], wfr[2][4];
+            auto load_step = [&](int st, ChunkB (&bf)[2], ChunkB (&wf)[4]) {
+                const int tp = st >> 1, hf = st & 1, tyy = tp / 3, txx = tp - tyy * 3;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bf[q].u = *(const uint4*)(bsb + hf * BN_PLANE + bn_addr((gw * 2 + q + tyy) * BN_RW + col + txx, kq));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) wf[ct].u = w2s[(st * 4 + ct) * 64 + lane];
+            };
+            load_step(0, bfr[0], wfr[0]);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                if (st + 1 < 18) load_step(st + 1, bfr[(st + 1) & 1], wfr[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[st & 1][ct].h, bfr[st & 1][q].h, acc[ct][q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
+            for (int ct = 0; ct < 4; ++ct) {
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f32x2b xl = (f32x2b){acc[ct][q][0], acc[ct][q][1]} + (f32x2b){bv2[ct].x, bv2[ct].y};
-                    const f32x2b xh = (f32x2b){acc[ct][q][2], acc[ct][q][3]} + (f32x2b){bv2[ct].z, bv2[ct].w};
+                    const f32x2b xl = (f32x2b){acc[ct][q][0], acc[ct][q][1]} + (f32x2b){bv[ct].x, bv[ct].y};
+                    const f32x2b xh = (f32x2b){acc[ct][q][2], acc[ct][q][3]} + (f32x2b){bv[ct].z, bv[ct].w};
                     const f32x2b rl = bn_sigmoid2(xl), rh = bn_sigmoid2(xh);
                     f32x2b lo, hi;
-                    if (RES) {                              // the shortcut: this pixel of y, added AFTER the activation -- as ONE fused multiply-add
-                        const int nc = (rp * 2 + q + 1) * BN_RW + col + 1;       // (x * sigmoid(x) + y rounded once), which is what conv_epilogue_bf16 compiles to
-                        const int c = ch0 + ct;
-                        const uint2 r = *(const uint2*)(ysb + (c >> 1) * BN_PLANE + bn_addr(nc, (c & 1) * 2 + (kq >> 1)) + (kq & 1) * 8);
+                    if (RES) {          // added AFTER the activation, as ONE fused multiply-add (x * sigmoid(x) + y rounded once): what conv_epilogue_bf16 compiles to
+                        const uint2 r = rs[ct][q];
                         lo = __builtin_elementwise_fma(xl, rl, (f32x2b){__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)});
                         hi = __builtin_elementwise_fma(xh, rh, (f32x2b){__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)});
                     } else {
@@ -187,11 +199,12 @@ __global__ __launch_bounds__(BN_NW * 64) void bneck_fused_kernel(const BnArgs a)
                 const u32x2b sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
                 const u32x2b sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
-                const int oy = oy0 + rp * 2 + (odd ? 1 : 0), ox = ox0 + col;
+                const int oy = oy0 + gw * 2 + (odd ? 1 : 0), ox = ox0 + col;
                 if (oy < a.H && ox < a.W)
-                    *(uint4*)(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + (ch0 + ct) * 16 + (kq & ~1) * 4) = o4;
+                    *(uint4*)(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
         }
+        __syncthreads();                                    // bs[k & 1] is complete, bs[(k - 1) & 1] is free again
     }
 }
 
