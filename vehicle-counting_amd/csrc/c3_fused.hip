@@ -176,19 +176,25 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4c){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const int tyy = tp / 3, txx = tp % 3;
-                ChunkC bf[2];
+            // nine taps, software-pipelined by hand: the four fragment reads of tap s + 1 are issued before the four MFMAs of tap s
+            ChunkC bfr[2][2], wfr[2][2];
+            auto load_tap = [&](int tp, ChunkC (&bf)[2], ChunkC (&wf)[2]) {
+                const int tyy = tp / 3, txx = tp - tyy * 3;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) bf[q].u = *(const uint4*)(xab + c3_addr((wave * 2 + q + tyy) * C3_RW + col + txx, kq));
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    ChunkC w;
-                    w.u = wm2s[(tp * 2 + ct) * 64 + lane];
+                for (int ct = 0; ct < 2; ++ct) wf[ct].u = wm2s[(tp * 2 + ct) * 64 + lane];
+            };
+            load_tap(0, bfr[0], wfr[0]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, bf[q].h, acc[ct][q], 0, 0, 0);
-                }
+            for (int tp = 0; tp < 9; ++tp) {
+                if (tp + 1 < 9) load_tap(tp + 1, bfr[(tp + 1) & 1], wfr[(tp + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tp & 1][ct].h, bfr[tp & 1][q].h, acc[ct][q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
