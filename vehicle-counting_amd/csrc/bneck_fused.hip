@@ -107,20 +107,31 @@ __global__ __launch_bounds__(BN_NW * 64) void bneck_fused_kernel(const BnArgs a)
                 if (k + 1 < nk) load_y(t + gridDim.x, yn);
                 const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y;
                 char* bsb = (char*)bs[k & 1];
+                // all 24 MFMAs first (12 independent accumulators), then the epilogues: the matrix pipe drains while the VALU / transcendental
+                // units work through the earlier accumulators
+                f32x4b pacc[3][4];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const int n = (gw * 3 + j) * 16 + col;
-                    const int ry = (n * 3641) >> 16, rx = n - ry * BN_RW;
-                    const int gy = ty * BN_TH - 1 + ry, gx = tx * BN_TW - 1 + rx;
-                    const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                     ChunkB y0f, y1f;
                     y0f.u = yf[j][0]; y1f.u = yf[j][1];
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
                         ChunkB w0, w1;
                         w0.u = w1s[(0 * 4 + ct) * 64 + lane]; w1.u = w1s[(1 * 4 + ct) * 64 + lane];
-                        f32x4b acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.h, y0f.h, (f32x4b){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.h, y1f.h, acc, 0, 0, 0);
+                        pacc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.h, y0f.h, (f32x4b){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        pacc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.h, y1f.h, pacc[j][ct], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int n = (gw * 3 + j) * 16 + col;
+                    const int ry = (n * 3641) >> 16, rx = n - ry * BN_RW;
+                    const int gy = ty * BN_TH - 1 + ry, gx = tx * BN_TW - 1 + rx;
+                    const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const f32x4b acc = pacc[j][ct];
                         const f32x2b lo = bn_silu2((f32x2b){acc[0], acc[1]} + (f32x2b){bv[ct].x, bv[ct].y});
                         const f32x2b hi = bn_silu2((f32x2b){acc[2], acc[3]} + (f32x2b){bv[ct].z, bv[ct].w});
                         const bf16x2b p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
