@@ -91,6 +91,11 @@ int vc_engine_set_param(vc_engine* e, int net, const char* name, const float* w_
  * weights loaded by /root/reference/networks/yolo.py:58 may carry autoanchor values).  Default: the COCO set of yolov5{s,m,l}.yaml. */
 int vc_engine_set_anchors(vc_engine* e, const float* anchors18);
 int vc_engine_finalize(vc_engine* e); /* packs + uploads weights; detector/ReID calls are valid afterwards */
+/* Kernel-selection switches of a live engine (defaults come from the environment at vc_engine_create: VC_C3_FUSED, VC_BNECK_FUSED,
+ * VC_FRONT_FUSED, VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB).  Names: "c3_fused", "bneck_fused" (0 / 1), "front_fused" (0 off, 1 stream path,
+ * 2 always), "crop_per_pixel" (0 / 1), "dot_arena_mb" (largest appearance-table arena the tracker may allocate; 0 = compute the
+ * appearance rows inside the walk).  The parity tests use it to compare a fused kernel with the launches it replaces. */
+int vc_engine_set_option(vc_engine* e, const char* name, int value);
 
 /* ---- detect: ImageDetect.run ------------------------------------------------------------------ */
 /* rgb[i]: H[i] x W[i] x 3 uint8 RGB.  out_det: n * max_det * 6 floats [x1,y1,x2,y2,conf,cls] in source pixels
@@ -162,13 +167,16 @@ int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);
 
-/* Asynchronous form of vc_stream_run: the per-frame tracker loop of the batch runs on the engine's worker thread; the call
- * returns as soon as the batch's ReID is enqueued.  At most two batches may be outstanding.  vc_stream_collect returns the
- * rows of the OLDEST outstanding batch (same layout as vc_stream_run) and blocks until they are ready.  Calls that touch
- * tracker state (vc_tracker_*, vc_deepsort_update, vc_videotracker_run) first wait for outstanding batches. */
+/* Asynchronous form of vc_stream_run: the batch's tracker work is ONE kernel enqueued on the engine's tracker stream (no host
+ * thread); the call returns as soon as the batch's ReID and tracker kernel are enqueued.  At most two batches may be outstanding.
+ * vc_stream_collect returns the rows of the OLDEST outstanding batch (same layout as vc_stream_run) and blocks until they are
+ * ready.  Calls that touch tracker state (vc_tracker_*, vc_deepsort_update, vc_videotracker_run) first wait for outstanding batches.
+ * A submission that cannot be embedded (more than max_candidates boxes passed conf_thres, more boxes than max_crops, an empty crop)
+ * is reported ONCE by the call that finds it and dropped; vc_stream_reset abandons everything in flight. */
 int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                         int cap_rows_per_frame);
 int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b);
+int vc_stream_reset(vc_engine* e);
 /* Detection injection for throughput studies: replaces the detector's NMS output of the batches SUBMITTED from now on
  * (vc_stream_submit / vc_stream_submit_host capture it) with caller boxes after the conv stack has run. NULL clears. */
 int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);

@@ -133,6 +133,47 @@ def test_hostile_pickle_does_not_execute(tmp_path):
     assert isinstance(obj["model"], torch.nn.Module)             # the eval call became the construction of a stub module
 
 
+class _NestedHostile:
+    """Outer pickle: REDUCE torch.storage._load_from_bytes(<inner torch.save blob whose pickle calls builtins.eval>).  The real
+    _load_from_bytes is torch.load(..., weights_only=False) with the default pickle module."""
+
+    def __init__(self, inner):
+        self.inner = inner
+
+    def __reduce__(self):
+        return (torch.storage._load_from_bytes, (self.inner,))
+
+
+def test_nested_load_from_bytes_payload_does_not_execute(tmp_path):
+    import io
+    import os
+    from vehicle_counting_amd.checkpoint import _allowed
+    assert not _allowed("torch.storage", "_load_from_bytes")
+    buf = io.BytesIO()
+    torch.save({"w": _Hostile()}, buf)
+    path = tmp_path / "nested.pt"
+    torch.save({"net_dict": _NestedHostile(buf.getvalue())}, path)
+    os.environ.pop("VC_PWNED", None)
+    try:
+        load_reid_checkpoint(path)
+    except Exception:
+        pass                                                    # a TypeError about the stub is fine; running the payload is not
+    assert "VC_PWNED" not in os.environ
+    # a tensor pickled with plain pickle (the legitimate user of _load_from_bytes) still loads
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    path2 = tmp_path / "plain.pt"
+    torch.save({"net_dict": {"a": _NestedHostile(_tensor_blob(t))}}, path2)
+    got = load_reid_checkpoint(path2)
+    np.testing.assert_array_equal(got["a"], t.numpy())
+
+
+def _tensor_blob(t):
+    import io
+    b = io.BytesIO()
+    torch.save(t, b)
+    return b.getvalue()
+
+
 def test_imagedetect_refuses_to_run_without_weights():
     import types
     from vehicle_counting_amd.detect import ImageDetect

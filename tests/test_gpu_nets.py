@@ -145,12 +145,9 @@ def test_c3_fused_bit_identical(hw):
     eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=3, max_frame_hw=(H, W))
     eng.detect([f[:, :, ::-1] for f in fr])
     a = eng.debug_layer(2, batch=3)
-    os.environ["VC_C3_FUSED"] = "0"
-    try:
-        eng.detect([f[:, :, ::-1] for f in fr])
-        b = eng.debug_layer(2, batch=3)
-    finally:
-        del os.environ["VC_C3_FUSED"]
+    eng.set_option("c3_fused", 0)
+    eng.detect([f[:, :, ::-1] for f in fr])
+    b = eng.debug_layer(2, batch=3)
     assert a.shape == b.shape and a.shape[-1] == 64 and np.abs(b).max() > 0.1
     assert np.array_equal(a, b)
     eng.close()
@@ -168,10 +165,9 @@ for H, W in ((640, 640), (360, 640), (416, 352)):
     eng = E.Engine(sd, None, precision="bf16", num_classes=8, max_batch=3, max_frame_hw=(H, W))
     eng.detect([f[:, :, ::-1] for f in fr])
     a = [eng.debug_layer(l, batch=3) for l in (4, 17)]
-    os.environ["VC_BNECK_FUSED"] = "0"
+    eng.set_option("bneck_fused", 0)
     eng.detect([f[:, :, ::-1] for f in fr])
     b = [eng.debug_layer(l, batch=3) for l in (4, 17)]
-    del os.environ["VC_BNECK_FUSED"]
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.abs(y).max() > 0.1
         assert np.array_equal(x, y), (H, W, float((x == y).mean()))
@@ -203,11 +199,8 @@ def test_crop_resize_per_crop_kernel(frames):
     boxes = np.array([[100.3, 80.7, 60.2, 90.9], [320.0, 200.0, 50.0, 50.0], [10.0, 12.0, 40.0, 60.0], [630.0, 350.0, 80.0, 70.0],
                       [300.5, 180.5, 101.0, 33.0], [200.0, 100.0, 7.0, 160.0], [400.0, 300.0, 200.0, 3.0]])
     a = eng.embed(frames[0], boxes)
-    os.environ["VC_CROP_PER_PIXEL"] = "1"
-    try:
-        b = eng.embed(frames[0], boxes)
-    finally:
-        del os.environ["VC_CROP_PER_PIXEL"]
+    eng.set_option("crop_per_pixel", 1)
+    b = eng.embed(frames[0], boxes)
     assert np.array_equal(a, b)
     eng.close()
 
@@ -228,6 +221,8 @@ def test_front_fused_layers_0_1_bit_identical(hw):
     eng.stream_submit(dev.data_ptr(), 3, H, W)                    # device BGR frames: letterbox + layers 0 and 1 in front_fused_kernel
     eng.sync()
     b1, b2 = eng.debug_layer(1, batch=3), eng.debug_layer(2, batch=3)
+    with pytest.raises(E.L.VcError, match="layer 0 was not written"):      # layer 0 stayed in LDS: a stale read is refused
+        eng.debug_layer(0, batch=3)
     assert a1.shape == b1.shape and np.abs(a1).max() > 0.5
     np.testing.assert_array_equal(a1, b1)
     np.testing.assert_array_equal(a2, b2)

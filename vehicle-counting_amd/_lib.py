@@ -60,6 +60,7 @@ SIGNATURES = {
     "vc_engine_set_param": [_vp, _i, C.c_char_p, _pf, _pf],
     "vc_engine_set_anchors": [_vp, _pf],
     "vc_engine_finalize": [_vp],
+    "vc_engine_set_option": [_vp, C.c_char_p, _i],
     "vc_engine_sync": [_vp],
     "vc_detect": [_vp, _P(_vp), _pi, _pi, _i, _pf, _pi],
     "vc_detect_debug_shape": [_vp, _pi, _pi, _pi],
@@ -83,6 +84,7 @@ SIGNATURES = {
     "vc_stream_submit_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],
+    "vc_stream_reset": [_vp],
     "vc_counter_create": [_pd, _i, _pd, _i, _i, _P(_vp)],
     "vc_counter_destroy": [_vp],
     "vc_counter_add": [_vp, _pl, _pl, _pl, _pl, _i],

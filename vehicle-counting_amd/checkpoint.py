@@ -10,6 +10,7 @@ which is all `state_dict()` needs -- no upstream code runs.  The result is the f
 """
 from __future__ import annotations
 
+import io
 import pickle
 
 import numpy as np
@@ -27,8 +28,7 @@ _EXACT_OK = {
     ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
     ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
     ("torch.nn.parameter", "Parameter"), ("torch", "Tensor"), ("torch", "Size"), ("torch", "device"),
-    ("torch.serialization", "_get_layout"), ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"),
-    ("torch.storage", "TypedStorage"),
+    ("torch.serialization", "_get_layout"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
     ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
     ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
 }
@@ -51,6 +51,13 @@ def _allowed(module, name):
     return False
 
 
+def _load_from_bytes_restricted(b):
+    """Stand-in for torch.storage._load_from_bytes (what a tensor pickled with plain `pickle.dumps` reduces to).  The original is
+    `torch.load(io.BytesIO(b), weights_only=False)` with the UNRESTRICTED pickle module: an allowlisted call that would run any
+    inner payload.  The nested blob goes back through the same stub unpickler instead."""
+    return torch.load(io.BytesIO(b), map_location="cpu", pickle_module=_StubPickle, weights_only=False)
+
+
 class _StubUnpickler(pickle.Unpickler):
     """Resolves only the allowlisted torch / numpy / stdlib globals above; anything else (models.yolo.Model,
     models.common.Conv, ... and anything hostile) becomes an attribute-bag nn.Module subclass named after the original."""
@@ -58,6 +65,8 @@ class _StubUnpickler(pickle.Unpickler):
     _made = {}
 
     def find_class(self, module, name):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _load_from_bytes_restricted
         if _allowed(module, name):
             return super().find_class(module, name)          # incl. the protocol-2 names (__builtin__.set, copy_reg, ...)
         key = (module, name)

@@ -616,9 +616,8 @@ __global__ __launch_bounds__(256) void crop_resize_wg_kernel(const uint8_t* __re
     }
 }
 
-int launch_crop_resize(const uint8_t* frames, int H, int W, const int* crops5, int k, void* dst, int cpad, int prec, hipStream_t s) {
+int launch_crop_resize(const uint8_t* frames, int H, int W, const int* crops5, int k, void* dst, int cpad, int prec, hipStream_t s, bool per_pixel) {
     if (k <= 0) return VC_OK;
-    const bool per_pixel = getenv("VC_CROP_PER_PIXEL") != nullptr;                 // tests: the per-pixel instance of the bf16 path (read per call)
     if (prec != PREC_F32 && cpad == 8 && !per_pixel) {
         hipLaunchKernelGGL(crop_resize_wg_kernel, dim3(k), dim3(256), 0, s, frames, H, W, crops5, (uint4*)dst);
         VC_HIP(hipGetLastError());

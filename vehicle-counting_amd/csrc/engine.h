@@ -93,6 +93,9 @@ struct vc_engine {
     hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
+    // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
+    // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv
+    struct Options { int c3_fused = 1, bneck_fused = 1, front_fused = 1, crop_per_pixel = 0; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 
@@ -115,6 +118,7 @@ struct vc_engine {
     const uint8_t* stem_src = nullptr;
     vc::LetterboxGeom stem_geom{};
     bool in_stale = false;
+    bool l0_stale = false;                       // the last pass ran front_fused_kernel: layer 0 stayed in LDS, ybuf["l0"] holds an older pass
     float* h_det = nullptr;                      // pinned [max_batch][max_det][6]
     int* h_det_count = nullptr;                  // pinned [max_batch]
     float* h_det2[2] = {nullptr, nullptr};       // pinned detector outputs of the (up to) two submissions in flight
@@ -126,12 +130,13 @@ struct vc_engine {
     uint8_t* d_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned ingest_seq = 0;
-    // stream path: three feature / crop buffers -- the batch being tracked (possibly by the worker thread), the batch
+    // stream path: three feature / crop buffers -- the batch being tracked (tracker stream), the batch
     // whose ReID is running, and the one after it
     float* d_feat2[3] = {nullptr, nullptr, nullptr};
     int* d_crops2[3] = {nullptr, nullptr, nullptr};
     int* h_crops2[3] = {nullptr, nullptr, nullptr};
     unsigned reid_seq = 0;
+    std::vector<int> crop_scratch;               // crop list of the batch being validated (stream.hip::issue_reid)
     struct FrameDets { std::vector<double> xyxy, conf; std::vector<int> label; };
     struct Pending {
         const void* frames; int b, h, w, slot;
@@ -170,7 +175,8 @@ struct vc_engine {
     double* d_track_scratch = nullptr; size_t track_scratch_bytes = 0;
     // appearance dots hoisted out of the sequential loop (TrackDotPlan, kernels.h)
     vc::TrackDotPlan* d_dot_plans = nullptr; size_t dot_plans_cap = 0;
-    float* d_dot_arena = nullptr; size_t dot_arena_floats = 0;
+    float* d_dot_arena = nullptr; size_t dot_arena_floats = 0;     // grown on demand by track_enqueue up to dot_arena_max_floats
+    size_t dot_arena_max_floats = 0;
     int* d_row_src = nullptr; int row_src_cap = 0;
     int* d_gal_row = nullptr; int* d_dot_ctl = nullptr;
     float* d_nfeat = nullptr; float* d_det_ss = nullptr; size_t nfeat_cap = 0;

@@ -440,10 +440,10 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 conv_timer_arm(e, cp, fl, by);
                 if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only the u8 stem can run it
                     VC_CHECK(stem_direct_on && stem_u8_applicable(cp, e->stem_geom), VC_ERR_STATE, "letterbox fold-in: the direct stem does not apply");
-                static const int front_fused_mode = getenv("VC_FRONT_FUSED") ? atoi(getenv("VC_FRONT_FUSED")) : 1;   // 0 off, 1 stream path, 2 always
+                const int front_fused_mode = e->opt.front_fused;   // 0 off, 1 stream path, 2 always
                 const bool fuse_front = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv) &&
                                         (front_fused_mode == 2 || (e->stem_src && cp.in == e->ybuf["in"].ptr));
-                const bool c3_fused_on = !(getenv("VC_C3_FUSED") && atoi(getenv("VC_C3_FUSED")) == 0);       // read per call: the tests toggle it
+                const bool c3_fused_on = e->opt.c3_fused != 0;
                 const bool fuse_c3 = c3_fused_on && oi + 3 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV && ops[oi + 3].kind == Op::CONV &&
                                      c3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv, ops[oi + 3].conv);
                 if (fuse_c3) {                                                // the first C3 block in one kernel (c3_fused.hip): y1, y2, b1, m stay in LDS
@@ -467,7 +467,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     oi += 3;                                                  // m.cv1, m.cv2 and cv3 are done
                     break;
                 }
-                const bool bneck_fused_on = !(getenv("VC_BNECK_FUSED") && atoi(getenv("VC_BNECK_FUSED")) == 0);    // read per call: the tests toggle it
+                const bool bneck_fused_on = e->opt.bneck_fused != 0;
                 if (bneck_fused_on && nx && nx->kind == Op::CONV && bneck_fused_applicable(cp, nx->conv)) {   // 64-channel Bottleneck in one kernel (bneck_fused.hip)
                     const ConvP& o2 = nx->conv;
                     const double flb = fl + 2.0 * o2.M * (double)o2.Cout * nx->C;
@@ -496,6 +496,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     ProfScope ps(e, VC_PROF_CONV, fl + fl1, by01, s);
                     const bool u8 = e->stem_src && cp.in == e->ybuf["in"].ptr;
                     VC_TRY(launch_front_fused(cp, o1.conv, u8 ? e->stem_src : nullptr, e->stem_geom, s));
+                    e->l0_stale = true;                                       // layer 0 lived in LDS only
                     ++oi;                                                     // the 3x3 conv is done
                 } else if (stem_direct_on && stem_direct_applicable(cp)) {   // YOLO stem, bf16: direct convolution (stem_direct.hip)
                     cp.cfg = 100;
@@ -560,6 +561,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     hipStream_t ds = e->dstream;
     std::vector<Op> ops;
     VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
+    e->l0_stale = false;
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
     // decode + NMS
     const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 8);
@@ -685,7 +687,7 @@ int run_reid_on(vc_engine* e, const uint8_t* d_frames, int H, int W, int k, cons
     VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
     if (k <= 0) return VC_OK;
     { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs);
-      VC_TRY(launch_crop_resize(d_frames, H, W, d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->aux_prec), e->aux_prec, rs)); }
+      VC_TRY(launch_crop_resize(d_frames, H, W, d_crops, k, e->rbuf["in"].ptr, reid_cpad(e->aux_prec), e->aux_prec, rs, e->opt.crop_per_pixel != 0)); }
     return reid_forward(e, k, rs, feat_out);
 }
 
@@ -738,6 +740,11 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     e->prec = cfg->precision;
     e->aux_prec = cfg->precision == VC_PREC_FP8 ? (int)PREC_BF16 : cfg->precision;      // stem, logits, pools of the ReID net, ReID convs
     e->act_scale = getenv("VC_FP8_ACT_SCALE") ? (float)atof(getenv("VC_FP8_ACT_SCALE")) : 1.0f;
+    {
+        auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1);
+        e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
+    }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
     do {
@@ -892,6 +899,20 @@ int vc_engine_finalize(vc_engine* e) {
     return VC_OK;
 }
 
+// Kernel-selection switches of a live engine (the parity tests compare a fused kernel with the launches it replaces on the same
+// engine).  Initial values come from the environment at vc_engine_create; the launch path itself never calls getenv.
+int vc_engine_set_option(vc_engine* e, const char* name, int value) {
+    VC_CHECK(e && name, VC_ERR_ARG, "null argument");
+    const std::string n = name;
+    if (n == "c3_fused") e->opt.c3_fused = value;
+    else if (n == "bneck_fused") e->opt.bneck_fused = value;
+    else if (n == "front_fused") e->opt.front_fused = value;
+    else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
+    else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
+    else { set_error("unknown option '%s'", name); return VC_ERR_NOTFOUND; }
+    return VC_OK;
+}
+
 int vc_engine_sync(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_HIP(hipStreamSynchronize(e->stream));
@@ -979,6 +1000,8 @@ int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int d
         View v = mkview(e->ybuf["in"], e->last_B, e->last_nh, e->last_nw, 3, 0);
         return read_view_f32(e, v, out, cap, dims);
     }
+    VC_CHECK(!(layer == 0 && e->l0_stale), VC_ERR_STATE,
+             "layer 0 was not written by the last pass (front_fused_kernel keeps it in LDS); vc_engine_set_option(e, \"front_fused\", 0) and run again");
     return read_view_f32(e, e->layer_view[layer], out, cap, dims);
 }
 

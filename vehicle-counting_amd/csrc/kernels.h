@@ -65,7 +65,7 @@ int launch_nms(int B, int max_cand, int max_det, float iou, const float* geom_de
 // frames: F x H x W x 3 u8 BGR.  crop[i] = (frame, x1, y1, x2, y2) end-exclusive int corners.
 // dst: k x 50 x 50 x cpad (prec), channels >= 3 zero.  ((v/255 bilinear) - mean) / std, BGR order kept (quirk Q3).
 int launch_crop_resize(const uint8_t* frames, int H, int W, const int* crops5, int k, void* dst, int cpad, int prec,
-                       hipStream_t s);
+                       hipStream_t s, bool per_pixel = false);     // per_pixel: the per-pixel instance of the bf16 path (parity tests)
 // x_nchw: k x 3 x 50 x 50 f32 already-normalised tensor -> same NHWC/cpad layout (vc_embed_tensor)
 int launch_nchw_to_nhwc_pad(const float* x, int k, int C, int H, int W, void* dst, int cpad, int prec, hipStream_t s);
 int launch_maxpool3s2(const View& src, const View& dst, int prec, hipStream_t s);

@@ -142,8 +142,9 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
             marshal(h_det + (size_t)f * md * 6, h_cnt[f], pd.fd[f]);
         }
     }
-    pd.fslot = (int)(e->reid_seq++ % 3);
-    int* hc = e->h_crops2[pd.fslot];
+    // every check comes before a feature / crop slot is taken: a refused batch leaves the three-buffer rotation untouched
+    std::vector<int>& crops = e->crop_scratch;
+    crops.clear();
     int k = 0;
     for (int f = 0; f < b; ++f) {
         pd.row0[f] = k;
@@ -154,16 +155,20 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
             const double* bx = &d.xyxy[i * 4];
             const double bw = bx[2] - bx[0], bh = bx[3] - bx[1];                 // deep_sort.py:78-87
             const double cx = bx[0] + bw / 2, cy = bx[1] + bh / 2;
-            int* c = hc + (size_t)k * 5;
+            int c[5];
             c[0] = f;
             c[1] = std::max((int)(cx - bw / 2), 0); c[3] = std::min((int)(cx + bw / 2), w - 1);    // deep_sort.py:89-95
             c[2] = std::max((int)(cy - bh / 2), 0); c[4] = std::min((int)(cy + bh / 2), h - 1);
             VC_CHECK(c[3] > c[1] && c[4] > c[2], VC_ERR_ARG,
                      "frame %d box %zu gives an empty crop (the reference's cv2.resize raises here)", f, i);
+            crops.insert(crops.end(), c, c + 5);
             ++k;
         }
     }
+    pd.fslot = (int)(e->reid_seq++ % 3);
+    int* hc = e->h_crops2[pd.fslot];
     if (k > 0) {
+        memcpy(hc, crops.data(), (size_t)k * 5 * sizeof(int));
         VC_HIP(hipMemcpyAsync(e->d_crops2[pd.fslot], hc, (size_t)k * 5 * sizeof(int), hipMemcpyHostToDevice, e->rstream));
         VC_TRY(run_reid_on(e, (const uint8_t*)pd.frames, h, w, k, e->d_crops2[pd.fslot], e->d_feat2[pd.fslot], e->rstream));
     }
@@ -172,19 +177,28 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
     return VC_OK;
 }
 
+// A submission whose detections cannot be embedded (candidate overflow, more boxes than max_crops, an empty crop) is DROPPED: the
+// error is reported once by the call that found it and the stream continues with the next submission (it used to stay
+// at the front of the queue and fail every following call).
+int issue_reid_or_drop(vc_engine* e, size_t idx) {
+    const int st = issue_reid(e, e->pending[idx]);
+    if (st != VC_OK) e->pending.erase(e->pending.begin() + idx);
+    return st;
+}
+
 // If the detector of the next submission has finished, start its ReID now (it then overlaps the tracking in progress).
 int try_issue_next(vc_engine* e) {
-    vc_engine::Pending* next = nullptr;
+    int next = -1;
     int embedded = 0;                                   // batches that own one of the three feature buffers
-    for (vc_engine::Pending& p : e->pending) {
-        if (p.stage == 0) { next = &p; break; }
+    for (size_t i = 0; i < e->pending.size(); ++i) {
+        if (e->pending[i].stage == 0) { next = (int)i; break; }
         ++embedded;
     }
-    if (!next) return VC_OK;
+    if (next < 0) return VC_OK;
     embedded += (int)e->jobs.size();
     if (embedded >= 3) return VC_OK;
-    if (hipEventQuery(e->ev_det[next->slot]) != hipSuccess) return VC_OK;
-    return issue_reid(e, *next);
+    if (hipEventQuery(e->ev_det[e->pending[next].slot]) != hipSuccess) return VC_OK;
+    return issue_reid_or_drop(e, (size_t)next);
 }
 
 }  // namespace
@@ -241,7 +255,7 @@ static int take_front(vc_engine* e, const void* frames_dev, int b, int h, int w,
     g_tm.start();
     if (e->pending.front().stage == 0) {
         VC_HIP(hipEventSynchronize(e->ev_det[e->pending.front().slot]));
-        VC_TRY(issue_reid(e, e->pending.front()));
+        VC_TRY(issue_reid_or_drop(e, 0));
     }
     out = std::move(e->pending.front());
     e->pending.erase(e->pending.begin());
@@ -303,6 +317,24 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
     VC_CHECK(e->jobs.empty(), VC_ERR_STATE, "asynchronous batches are outstanding: vc_stream_collect them first");
     VC_TRY(vc_stream_run_async(e, trackers, num_classes, frames_dev, b, h, w, cap_rows_per_frame));
     return vc_stream_collect(e, out_rows6, cap_rows_per_frame, out_m, out_ndet, b);
+}
+
+// Abandon everything in flight on the stream path: waits for the GPU, discards the rows of uncollected batches (their tracker steps
+// HAVE run: reset the trackers as well if the clip is to be replayed) and empties the submission queue.  The way out of any error
+// state of vc_stream_* without destroying the engine.
+int vc_stream_reset(vc_engine* e) {
+    VC_CHECK(e, VC_ERR_ARG, "null engine");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_HIP(hipStreamSynchronize(e->dstream)); VC_HIP(hipStreamSynchronize(e->rstream)); VC_HIP(hipStreamSynchronize(e->stream));
+    while (!e->jobs.empty()) {
+        const vc_engine::AsyncJob job = std::move(e->jobs.front());
+        e->jobs.pop_front();
+        std::vector<int64_t> rows((size_t)job.b * job.cap * 6);
+        std::vector<int> m(job.b);
+        (void)track_collect(e, job.stage, rows.data(), job.cap, m.data());      // bookkeeping (pending_dets, known_tracks); errors are dropped with the rows
+    }
+    e->pending.clear();
+    return VC_OK;
 }
 
 // Zone filter of VideoCounting.run (/root/reference/modules/track.py:102-104 -> utilities/counting/bb_polygon.py:14-114):

@@ -99,9 +99,11 @@ int tracker_init_pool(vc_engine* e) {
     VC_HIP(hipMemcpy(e->d_free_stack, st.data(), T * sizeof(int), hipMemcpyHostToDevice));
     const int ctl[2] = {(int)T, 0};
     VC_HIP(hipMemcpy(e->d_free, ctl, sizeof(ctl), hipMemcpyHostToDevice));
-    // hoisted appearance dots (track_kernels.hip): table arena, row bookkeeping
-    e->dot_arena_floats = getenv("VC_DOT_ARENA_MB") ? (size_t)atol(getenv("VC_DOT_ARENA_MB")) * 262144 : (size_t)256 << 20;   // 1 GB by default (288 GB of HBM)
-    VC_TRY(dev_alloc(e, (void**)&e->d_dot_arena, e->dot_arena_floats * sizeof(float)));
+    // hoisted appearance dots (track_kernels.hip): table arena (grown on demand by track_enqueue, up to VC_DOT_ARENA_MB /
+    // vc_engine_set_option "dot_arena_mb": 1 GB by default; 0 forces the in-walk appearance rows), row bookkeeping
+    e->dot_arena_max_floats = getenv("VC_DOT_ARENA_MB") ? (size_t)atol(getenv("VC_DOT_ARENA_MB")) * 262144 : (size_t)256 << 20;
+    e->dot_arena_floats = 0;
+    VC_TRY(dev_alloc(e, (void**)&e->d_dot_arena, 16));
     e->row_src_cap = (int)std::min<size_t>(T * S, (size_t)1 << 24);
     VC_TRY(dev_alloc(e, (void**)&e->d_row_src, (size_t)e->row_src_cap * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&e->d_gal_row, T * S * sizeof(int)));
@@ -220,7 +222,11 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     const size_t o_tlwh = p; p = align16(p + (size_t)n_dets * 32);
     const size_t o_xyah = p; p = align16(p + (size_t)n_dets * 32);
     const size_t o_frow = p; p = align16(p + (size_t)n_dets * 4);
-    rows_cap += n_wg * VC_ROW_CHUNK;                          // the kernel reserves rows in chunks: one unfinished chunk per workgroup
+    // The kernel reserves rows in chunks: a workgroup that needs m rows and has fewer left abandons the rest of its chunk and grabs
+    // max(m, VC_ROW_CHUNK) fresh ones, so the rows it abandons are always fewer than the rows of the step that follows -- consumption
+    // is bounded by twice the rows emitted plus one unfinished chunk per workgroup (`cap + chunk` was a spurious TERR_ROWS
+    // for steady steps of 65..127 rows).
+    rows_cap = 2 * rows_cap + n_wg * VC_ROW_CHUNK;
     s.rows_cap = rows_cap;
     const OutLayout ol = out_layout(n_tasks, rows_cap);
     VC_TRY(stage_reserve(e, s, p, ol.total));
@@ -264,6 +270,18 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         VC_TRY(dev_alloc(e, (void**)&e->d_track_scratch, bytes));
         e->track_scratch_bytes = bytes;
     }
+    // appearance-table arena: grown to what this batch needs (bounded by dot_arena_max_floats); a batch that does not fit runs the
+    // instance that computes its appearance rows inside the walk
+    const bool tables_fit = all_tables && table_floats <= (long long)e->dot_arena_max_floats && table_rows <= (long long)e->row_src_cap;
+    if (tables_fit && (size_t)table_floats > e->dot_arena_floats) {
+        VC_TRY(track_idle(e));
+        VC_HIP(hipStreamSynchronize(e->stream));
+        const size_t want = std::min(e->dot_arena_max_floats, std::max((size_t)table_floats * 3 / 2, (size_t)1 << 22));
+        float* fresh = nullptr;
+        VC_HIP(hipMalloc((void**)&fresh, want * sizeof(float)));
+        for (void*& q : e->allocs) if (q == (void*)e->d_dot_arena) { (void)hipFree(q); q = fresh; }
+        e->d_dot_arena = fresh; e->dot_arena_floats = want;
+    }
     for (auto& td : s.tracker_dets) e->trackers[td.first]->pending_dets += td.second;
     hipStream_t ts = e->stream;
     if (wait) VC_HIP(hipStreamWaitEvent(ts, wait, 0));
@@ -286,7 +304,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.task_ntracks = (int*)(s.hd_out + ol.ntracks); a.task_T = (int*)(s.hd_out + ol.tT);
     a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
     a.scratch = e->d_track_scratch; a.scratch_per_wg = track_scratch_per_wg(); a.cap = cap; a.frame_w = W; a.frame_h = H;
-    a.all_tables = all_tables && table_floats <= (long long)e->dot_arena_floats && table_rows <= (long long)e->row_src_cap ? 1 : 0;
+    a.all_tables = tables_fit ? 1 : 0;
     a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back
     static const bool dbg_on = getenv("VC_TRACK_DBG") != nullptr;        // diagnostics: phase times of every task, printed per batch
     long long* dbg = nullptr;

@@ -72,6 +72,15 @@ class Engine:
     def sync(self):
         L.check(L.lib().vc_engine_sync(self._h))
 
+    def set_option(self, name, value):
+        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "front_fused", "crop_per_pixel", "dot_arena_mb")."""
+        L.check(L.lib().vc_engine_set_option(self._h, name.encode(), int(value)))
+
+    def stream_reset(self):
+        """Abandon everything in flight on the stream path (after an error, or to replay a clip)."""
+        L.check(L.lib().vc_stream_reset(self._h))
+        self._async_shapes = []
+
     # ---------------------------------------------------------------- detect (AutoShape forward)
     def detect(self, imgs_rgb):
         """list of HxWx3 uint8 RGB -> list of (n,6) float32 [x1,y1,x2,y2,conf,cls] in source pixels."""
@@ -228,7 +237,8 @@ class Engine:
         return rows[keep], np.repeat(np.arange(b), m), nd.copy()
 
     def stream_run_async(self, tracker_ids, frames_dev_ptr, b, h, w, cap_rows=512):
-        """Start tracking the batch on the engine's worker thread and return; `stream_collect` picks the rows up (in order)."""
+        """Enqueue the batch's ReID and its tracker kernel (one launch on the engine's tracker stream, no host thread) and return;
+        `stream_collect` picks the rows up (in order)."""
         tr = np.ascontiguousarray(tracker_ids, dtype=np.int32)
         L.check(L.lib().vc_stream_run_async(self._h, L.ptr(tr, C.c_int), len(tr), C.c_void_p(frames_dev_ptr), b, h, w, cap_rows))
         self._async_shapes = getattr(self, "_async_shapes", [])

@@ -83,7 +83,7 @@ class CountingPipeline:
         return self._finish(counter, obj, cam_name)
 
     def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False):
-        """asynchronous=True: the tracker loop of batch n runs on the engine's worker thread while batch n+1 is submitted and
+        """asynchronous=True: the tracker kernel of batch n runs on the engine's tracker stream while batch n+1 is submitted and
         embedded (`stream_run_async` / `stream_collect`); rows are identical, they arrive one batch later."""
         import torch
         tracker, counter = self._stages(cam_name, source.video_info, zone_path)
