@@ -175,7 +175,8 @@ def _dense_scenario(n_obj, n_frames, seed):
     return frames
 
 
-def test_config2_track_leg_256_detections_full_galleries():
+@pytest.mark.parametrize("arena_mb", [1024, 0])
+def test_config2_track_leg_256_detections_full_galleries(arena_mb):
     """BASELINE.json configs[2] track side (SURVEY.md B11 worst case): ~256 detections per frame against ~256 live tracks whose
     galleries fill up to NN_BUDGET = 60 samples (2 GMAC of cosine distances per frame): ids / states / counters identical to the
     oracle tracker in every frame, posterior means within 1e-9."""
@@ -183,6 +184,7 @@ def test_config2_track_leg_256_detections_full_galleries():
     frames = _dense_scenario(n_obj, n_frames, 77)
     ref = od.TrackerState(0.2, 60, max_iou_distance=0.6, max_age=30, n_init=3)
     eng = E.Engine(None, synth_reid(1702), precision="f32", max_crops=64, max_frame_hw=(360, 640), max_tracks=1024, nn_budget_cap=60)
+    eng.set_option("dot_arena_mb", arena_mb)       # 0: track_batch_kernel<4,false>, appearance rows by MFMA inside the walk
     tid = eng.tracker_create(max_dist=0.2, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
     for t, dets in enumerate(frames):
         ref.predict()

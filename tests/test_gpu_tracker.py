@@ -15,9 +15,14 @@ from vehicle_counting_amd.synth import synth_frames, synth_tracks  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["tables", "inwalk"])
+def eng(request):
+    """tables: the lean instance track_batch_kernel<8,true> (hoisted appearance dot tables, the normal case).  inwalk: the arena is
+    capped at 0 MB, so every batch runs track_batch_kernel<4,false> with the appearance rows computed inside the walk (what the
+    product falls back to when a scene's tables do not fit the arena) -- VERDICT r02 item 1(a)."""
     e = E.Engine(None, synth_reid(1702), precision="f32", max_crops=64, max_frame_hw=(360, 640), max_tracks=256, nn_budget_cap=60)
+    if request.param == "inwalk":
+        e.set_option("dot_arena_mb", 0)
     yield e
     e.close()
 

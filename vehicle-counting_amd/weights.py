@@ -70,8 +70,10 @@ def yolo_conv_table(variant="yolov5s", nc=80):
     return t
 
 
-def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0, box_scale=0.5):
+def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0, box_scale=0.5, fused=True):
     """Seeded synthetic, BN-folded detector parameters: {name+'.weight': OIHW f32, name+'.bias': f32}.
+    fused=False returns the SAME parameters before the fold, under upstream's un-fused names (`...conv.weight` without bias,
+    `...bn.{weight,bias,running_mean,running_var}`) -- what an ultralytics/yolov5 checkpoint holds before `model.fuse()`.
 
     Conv weights are variance-preserving for SiLU; BN statistics are non-trivial so the fold is
     exercised.  The Detect biases follow upstream's `_initialize_biases` prior
@@ -103,7 +105,12 @@ def synth_yolo(variant="yolov5s", nc=80, seed=1702, det_scale=1.0, obj_shift=0.0
         beta = (rng.standard_normal(co) * 0.1).astype(np.float32)
         mean = (rng.standard_normal(co) * 0.1).astype(np.float32)
         var = rng.uniform(0.8, 1.2, co).astype(np.float32)
-        sd[name + ".weight"], sd[name + ".bias"] = fold_bn(w, None, gamma, beta, mean, var, YOLO_BN_EPS)
+        if fused:
+            sd[name + ".weight"], sd[name + ".bias"] = fold_bn(w, None, gamma, beta, mean, var, YOLO_BN_EPS)
+        else:
+            bn = name[: -len("conv")] + "bn"
+            sd[name + ".weight"] = w
+            sd[bn + ".weight"], sd[bn + ".bias"], sd[bn + ".running_mean"], sd[bn + ".running_var"] = gamma, beta, mean, var
     return sd
 
 
