@@ -1,6 +1,6 @@
 """bench.py -- end-to-end frames/s of the detect + NMS + ReID + track hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload s640-bf16|l1280-fp8]
+    python bench.py --gpus N --steps K --warmup W [--workload s640-bf16|m1024-bf16|l1280-fp8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch of B synthetic frames of ONE camera stream per GPU: letterbox -> YOLOv5
@@ -10,10 +10,14 @@ the per-camera count tensors at the end.  Rank 0 prints ONE JSON line.
 
 Workloads (config.workload names the one measured):
   s640-bf16   BASELINE.json configs[1] -- the headline: YOLOv5s, 640x640 frames, bf16 convs, B = 128, 512-frame clip, 12 objects
+  m1024-bf16  BASELINE.json configs[2] -- YOLOv5m, 1024x1024 frames, bf16 convs, B = 32, 256 ground-truth rectangles per frame
+              injected after the conv stack has run (<= 256 detections per frame through NMS + ReID + DeepSORT)
   l1280-fp8   BASELINE.json configs[4] -- YOLOv5l, 1280x1280 frames, fp8 (MX-scaled MFMA) detector convs, B = 16, ground-truth
               rectangles injected after the conv stack has run (the seeded random head of the deep variant saturates)
 With the default workload on one GPU the line also carries `extra_points`: the same pipeline at K = 32 and K = 256 detections per
-frame (detection injection) and `value_host_frames`, the PCIe-inclusive rate with the frames in pinned host memory.
+frame (detection injection; K = 256 with its per-stage split), the fp32 engine (the mode whose CSV equals the
+oracle's exactly), short runs of the m1024-bf16 and l1280-fp8 workloads with their own `roofline`, and `value_host_frames`, the
+PCIe-inclusive rate with the frames in pinned host memory.
 """
 import argparse
 import gc
@@ -38,7 +42,7 @@ from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
 
 NC = 80
 TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md; fp8 = MX-scaled K = 128 form)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0, "f32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md; fp8 = MX-scaled K = 128 form; f32 = v_mfma_f32_16x16x4_f32, the vector rate)
 PEAK_HBM_GBS = 8000.0                              # HBM3E (MI355X_MICROARCH.md)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
 
@@ -46,6 +50,10 @@ WORKLOADS = {
     "s640-bf16": dict(model="yolov5s", size=640, precision="bf16", B=int(os.environ.get("VC_BENCH_B", 128)),
                       clip=int(os.environ.get("VC_BENCH_CLIP", 512)), n_obj=12, inject=0, obj_shift=1.0,
                       desc="YOLOv5s 640x640 single camera stream per GPU, bf16 convs (BASELINE.json configs[1])"),
+    "m1024-bf16": dict(model="yolov5m", size=1024, precision="bf16", B=int(os.environ.get("VC_BENCH_B", 32)), clip=64, n_obj=256, inject=256,
+                       det_scale=16.0, obj_shift=2.0,   # the random head's own output: ~1 % of the 64 512 candidates pass conf_thres (oracle-calibrated), decoded + NMSed, then replaced
+                       desc="YOLOv5m 1024x1024 single camera stream per GPU, bf16 convs, 256 ground-truth rectangles per frame injected after the "
+                            "conv stack (BASELINE.json configs[2]: <= 256 detections per frame through NMS + DeepSORT ReID)"),
     "l1280-fp8": dict(model="yolov5l", size=1280, precision="fp8", B=int(os.environ.get("VC_BENCH_B", 16)), clip=64, n_obj=16, inject=16,
                       det_scale=1.0, obj_shift=-24.0,   # calibrated like the 640 workload: 20-80 boxes per frame survive the random head's NMS (tools/head_calib.py)
                       desc="YOLOv5l 1280x1280 single camera stream per GPU, fp8 MX-MFMA detector convs (BASELINE.json configs[4]), "
@@ -100,7 +108,8 @@ def injected_detections(n_frames, size, n_obj, seed):
 class Stream:
     """One camera stream on one engine: the three overlapped stages of the fused path."""
 
-    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None):
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None):
+        wl = dict(wl, precision=precision or wl["precision"])
         self.wl, self.dev = wl, dev
         self.B = B or wl["B"]
         self.H = self.W = wl["size"]
@@ -226,58 +235,19 @@ class Stream:
         return dt, post_ms, all_counts
 
 
-def quick_point(wl, rank, local, dev, world, **kw):
-    """Throughput of one extra operating point: a short run of the same pipeline with other stream parameters."""
-    steps, warm = kw.pop("steps", 8), kw.pop("warmup", 2)
-    host = kw.pop("host", False)
-    st = Stream(wl, rank, local, dev, **kw)
-    if host:
-        st.use_host_frames()
-    st.run_steps(0, warm, False)
-    dt, _, _ = st.timed(warm, steps, world)
-    out = {"value": steps * st.B / dt, "unit": "frames/s", "frames_per_step": st.B, "steps": steps,
-           "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "tracked_rows": st.nrows}
-    st.eng.close()
-    del st
-    torch.cuda.empty_cache()
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s640-bf16")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the K = 32 / 256 and host-frames operating points")
-    ap.add_argument("--cpu-frames", type=int, default=12)
-    args = ap.parse_args()
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))            # `python bench.py --gpus N`: become N ranks (one per GPU) over RCCL
-    rank, world, local = parallel.init_from_env("nccl" if args.gpus > 1 else None)
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU")
-    ndev = torch.cuda.device_count()
-    if ndev < max(local + 1, 1) or (world > 1 and ndev < world):
-        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} of {world}, but only {ndev} device(s) are visible (no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    wl = WORKLOADS[args.workload]
-    peak_tflops = PEAK_TFLOPS[wl["precision"]]
-
-    st = Stream(wl, rank, local, dev)
-    eng, B = st.eng, st.B
-    st.run_steps(0, args.warmup, False)
+def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffic_src=None):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones (barrier + synchronize on both sides, max over ranks), with the
+    conv launches of the timed steps bracketed by in-flight HIP event pairs on their own streams; afterwards two extra steps with
+    blocking events give the per-stage split.  Returns (seconds, post-pass ms, gathered counts, roofline, stage_ms_per_step)."""
+    eng = st.eng
+    st.run_steps(first, warmup, False)
     st.sync(world)
     eng.profile_reset(); eng.profile(2)            # in-flight event pairs around every conv launch of the timed steps (no host waits)
-    dt, post_ms, all_counts = st.timed(args.warmup, args.steps, world)
+    dt, post_ms, all_counts = st.timed(first + warmup, steps, world)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=st.dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-
     # roofline of the dominant kernel (the conv kernels): HIP events around every conv launch of the TIMED steps, recorded on
     # the stream the kernel is launched on and resolved after the region (the launches overlap with the other two streams, as in
     # the rocprofv3 trace of this command).  The per-stage split comes from two extra steps with blocking events.
@@ -285,32 +255,21 @@ def main():
     conv_union_ms, conv_span_ms = eng.profile_conv_busy()
     eng.profile(0)
     eng.profile(True); eng.profile_reset()
-    first = args.warmup + args.steps
+    nxt = first + warmup + steps
     for i in range(2):
-        st.run_steps(first + i, 1, False)
+        st.run_steps(nxt + i, 1, False)
     eng.sync()
     conv = eng.profile_read(L.PROF_CONV)
     cats = {n: eng.profile_read(c) for n, c in (("conv", L.PROF_CONV), ("detect_aux", L.PROF_DETECT_AUX),
                                                 ("reid_aux", L.PROF_REID_AUX), ("track", L.PROF_TRACK))}
     eng.profile(False)
     isolated = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-
-    # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
-    # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
-    traffic, traffic_src = None, None
-    for rnd in ("r02", "r01"):
-        tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
-        if args.workload == "s640-bf16" and os.path.exists(tp):
-            with open(tp) as f:
-                traffic, traffic_src = json.load(f)["conv_all"]["hbm_bytes_per_launch"], f"profiles/{rnd}_pmc_traffic.json"
-            break
-
     # Roofline of the dominant kernels (all conv launches of a step), SURVEY.md 8(d): bound = whichever of
     # flops / peak_mfma and bytes / peak_hbm is larger.  Time base = the wall clock of the timed region (ms_per_step): conv
     # launches of the detector and ReID streams overlap each other, so a sum of per-launch durations counts that time twice
     # (kept below as achieved_sum_of_overlapped_durations); flops-per-step / ms_per_step can be re-derived from the driver's own
     # clock and from profiles/ (launches per step x rocprofv3 average duration is <= ms_per_step).
-    step_s = dt / args.steps
+    step_s = dt / steps
     n_meas_steps = max(conv_timed["launches"] / max(conv["launches"] / 2.0, 1.0), 1e-9)      # timed steps covered by the event pool
     flops_step, bytes_step = conv_timed["flops"] / n_meas_steps, conv_timed["bytes"] / n_meas_steps
     mfma_tflops, hbm_gbs = flops_step / step_s / 1e12, bytes_step / step_s / 1e9
@@ -334,6 +293,72 @@ def main():
         "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of event pairs
         "traffic_note": ("HBM bytes per conv launch from %s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes of this command)" % traffic_src) if traffic_src else None,
     }
+    return dt, post_ms, all_counts, roofline, {k: v["ms"] / 2 for k, v in cats.items()}
+
+
+def quick_point(wl, rank, local, dev, world, **kw):
+    """Throughput of one extra operating point: a short run of the same pipeline with other stream parameters.  full=True adds the
+    point's own `roofline` and per-stage split (same procedure as the headline)."""
+    steps, warm = kw.pop("steps", 8), kw.pop("warmup", 2)
+    host, full = kw.pop("host", False), kw.pop("full", False)
+    st = Stream(wl, rank, local, dev, **kw)
+    if host:
+        st.use_host_frames()
+    extra = {}
+    if full:
+        dt, _, _, roof, stages = measure(st, warm, steps, world, PEAK_TFLOPS[st.wl["precision"]])
+        keep = ("bound", "achieved", "peak", "unit", "frac", "mfma_frac", "mfma_tflops", "mfma_peak_tflops", "hbm_frac", "hbm_gbs", "launches_per_step",
+                "algorithmic_gflop_per_step", "algorithmic_bytes_per_launch", "avg_launch_us", "achieved_isolated_tflops")
+        extra = {"roofline": {k: roof[k] for k in keep}, "stage_ms_per_step": stages, "ms_per_step": dt / steps * 1e3,
+                 "dtype": st.wl["precision"], "workload": st.wl["desc"]}
+    else:
+        st.run_steps(0, warm, False)
+        dt, _, _ = st.timed(warm, steps, world)
+    out = {"value": steps * st.B / dt, "unit": "frames/s", "frames_per_step": st.B, "steps": steps,
+           "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "tracked_rows": st.nrows}
+    out.update(extra)
+    st.eng.close()
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s640-bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra operating points (K = 32 / 256, fp32, m1024-bf16, l1280-fp8, host frames)")
+    ap.add_argument("--cpu-frames", type=int, default=12)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))            # `python bench.py --gpus N`: become N ranks (one per GPU) over RCCL
+    rank, world, local = parallel.init_from_env("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per GPU")
+    ndev = torch.cuda.device_count()
+    if ndev < max(local + 1, 1) or (world > 1 and ndev < world):
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} of {world}, but only {ndev} device(s) are visible (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    wl = WORKLOADS[args.workload]
+    peak_tflops = PEAK_TFLOPS[wl["precision"]]
+
+    st = Stream(wl, rank, local, dev)
+    eng, B = st.eng, st.B
+    # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
+    # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
+    traffic, traffic_src = None, None
+    for rnd in ("r03", "r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if args.workload == "s640-bf16" and os.path.exists(tp):
+            with open(tp) as f:
+                traffic, traffic_src = json.load(f)["conv_all"]["hbm_bytes_per_launch"], f"profiles/{rnd}_pmc_traffic.json"
+            break
+    dt, post_ms, all_counts, roofline, stage_ms = measure(st, args.warmup, args.steps, world, peak_tflops, traffic=traffic, traffic_src=traffic_src)
 
     out = None
     if rank == 0:
@@ -350,7 +375,7 @@ def main():
                        "counts_allgather_shape": list(all_counts.shape), "counts_allgather_via": st.gather_via, "tracked_rows": int(st.nrows),
                        "counting": "vc_counter_add per batch, vc_counter_rows + vc_counts after the last batch (C ABI), inside the timed region", "counting_postpass_ms_total": post_ms, "tracker": "device-resident (one kernel per batch, no host round trip per frame)"},
             "roofline": roofline,
-            "stage_ms_per_step": {k: v["ms"] / 2 for k, v in cats.items()},
+            "stage_ms_per_step": stage_ms,
         }
     ysd, rsd, frames = st.ysd, st.rsd, st.frames
     eng.close()
@@ -360,7 +385,12 @@ def main():
         # other operating points of SURVEY.md 8(d), short runs of the same pipeline (extra keys; `value` above is the headline)
         out["extra_points"] = {
             "K32_injected": quick_point(wl, rank, local, dev, world, n_obj=32, inject=32, clip=256),
-            "K256_injected": quick_point(wl, rank, local, dev, world, n_obj=256, inject=256, B=32, clip=128, steps=6),
+            "K256_injected": quick_point(wl, rank, local, dev, world, n_obj=256, inject=256, B=32, clip=128, steps=6, full=True),
+            # the engine mode whose CSV is identical to the oracle's (tests/test_gpu_bench_config.py): fp32 MFMA convs, same stream
+            "s640_fp32_exact_csv": quick_point(wl, rank, local, dev, world, precision="f32", B=64, clip=128, steps=6, full=True),
+            # BASELINE.json configs[2] and configs[4], short runs of `--workload m1024-bf16` / `--workload l1280-fp8`
+            "m1024_bf16": quick_point(WORKLOADS["m1024-bf16"], rank, local, dev, world, steps=4, warmup=2, full=True),
+            "l1280_fp8": quick_point(WORKLOADS["l1280-fp8"], rank, local, dev, world, steps=6, warmup=2, full=True),
         }
         hp = quick_point(wl, rank, local, dev, world, host=True, steps=12, warmup=3)
         out["value_host_frames"] = hp["value"]

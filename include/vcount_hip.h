@@ -176,7 +176,30 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
 int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                         int cap_rows_per_frame);
 int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int* out_ndet, int b);
+/* The same for a batch that interleaves S cameras (the reference builds a new VideoTracker per video, modules/__init__.py:29-36; one
+ * engine then serves S videos): frame f belongs to camera cam_of_frame[f] in [0, n_cam) and is stepped on trackers[cam * num_classes +
+ * label]; the frames of one camera must appear in stream order inside the batch and across batches.  Rows come back per frame exactly
+ * as from vc_stream_run_async (vc_stream_collect).  Per-camera latency is b / n_cam frames, and the tracker kernel walks
+ * n_cam x num_classes trackers in parallel, b / n_cam steps each. */
+int vc_stream_run_async_multi(vc_engine* e, const int* trackers /* n_cam x num_classes */, int n_cam, int num_classes, const int* cam_of_frame /* b */,
+                              const void* frames_dev, int b, int h, int w, int cap_rows_per_frame);
 int vc_stream_reset(vc_engine* e);
+
+/* ---- one stream on several GPUs: frame-sharded front end (ordering contract of modules/__init__.py:54-84) -------- */
+/* Front half of the fused path for the OLDEST submission (vc_stream_submit): detections marshalled like networks/yolo.py:72-97 +
+ * crops + ReID for every box (deep_sort.py:119-129).  out_rows7: n x [frame index in the batch, x1, y1, x2, y2, conf, label] float64 --
+ * the boxes VideoTracker.run works on; frames without boxes contribute nothing (Q1).  *out_feat_dev: DEVICE address of the matching
+ * n x 512 float32 embeddings, valid until the third following vc_stream_embed / vc_stream_run* call. */
+int vc_stream_embed(vc_engine* e, const void* frames_dev, int b, int h, int w, double* out_rows7, int cap_rows, int* out_n, const float** out_feat_dev);
+/* Variable-length all-gather of such rows + embeddings over RCCL / xGMI on the engine's stream (vc_comm_init first): rows of all ranks,
+ * rank-major, counts per rank, and the DEVICE address of the gathered embeddings (valid until the next call). */
+int vc_allgather_rows(vc_engine* e, const double* rows7, const float* feat_dev, int n, double* out_rows7, int cap_rows, int* out_counts /* world */,
+                      const float** out_feat_dev);
+/* VideoTracker.run (modules/track.py:30-70) for a run of frames whose detections and embeddings are supplied: rows7 sorted by frame key
+ * (column 0, ascending integers), row i's embedding at feat_dev[i] (device).  One tracker kernel launch for the whole run.  Per distinct
+ * key j, ascending: out_keys[j], out_m[j] rows [x1, y1, x2, y2, track_id, label] at out_rows6 + j * cap_rows_per_frame * 6. */
+int vc_videotracker_run_features(vc_engine* e, const int* trackers, int num_classes, const double* rows7, const float* feat_dev, int n, int h, int w,
+                                 int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int64_t* out_keys, int cap_frames, int* out_n_frames);
 /* Detection injection for throughput studies: replaces the detector's NMS output of the batches SUBMITTED from now on
  * (vc_stream_submit / vc_stream_submit_host capture it) with caller boxes after the conv stack has run. NULL clears. */
 int vc_stream_inject(vc_engine* e, const float* det6 /* b x n x 6 */, const int* count, int b, int n);

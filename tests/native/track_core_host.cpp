@@ -147,6 +147,13 @@ int tch_rows(void* hp, long long* rows6) {
     return h.n_rows;
 }
 
+// pyset_difference_order alone: list(set(conf) - set(k for k in conf if matched[k])) in CPython's iteration order
+int tch_pyset_order(const int* conf, int n1, const unsigned char* matched, int n2, int* out) {
+    const int slots = pyset_need_slots(n1);
+    std::vector<short> m0(slots), m1(slots);
+    return pyset_difference_order(Lanes{0, 1}, conf, n1, [&](int k) { return matched[k] != 0; }, n2, m0.data(), m1.data(), out);
+}
+
 // lap_solve alone: pairs sorted by row like scipy.optimize.linear_sum_assignment
 int tch_lap(const double* cost, int nr, int nc, int* rows, int* cols) {
     const int cap = ((nr > nc ? nr : nc) + 7) / 8 * 8;

@@ -221,8 +221,23 @@ def test_front_fused_layers_0_1_bit_identical(hw):
     eng.stream_submit(dev.data_ptr(), 3, H, W)                    # device BGR frames: letterbox + layers 0 and 1 in front_fused_kernel
     eng.sync()
     b1, b2 = eng.debug_layer(1, batch=3), eng.debug_layer(2, batch=3)
-    with pytest.raises(E.L.VcError, match="layer 0 was not written"):      # layer 0 stayed in LDS: a stale read is refused
-        eng.debug_layer(0, batch=3)
+    # vc_detect AFTER a stream pass: the host images just uploaded are what the detector sees (the u8 source the stream pass left
+    # behind for debug_layer(-1) used to be picked up by the stem again), and layer 0 is written by the two-launch path
+    dets_a = eng.detect([f[:, :, ::-1] for f in fr[::-1]])
+    dets_b = eng.detect([f[:, :, ::-1] for f in fr])
+    a0 = eng.debug_layer(0, batch=3)
+    np.testing.assert_array_equal(eng.debug_layer(1, batch=3), a1)
+    assert any(len(x) != len(y) or not np.array_equal(x, y) for x, y in zip(dets_a, dets_b)) or len(dets_a[0]) == 0
+    eng.stream_submit(dev.data_ptr(), 3, H, W)
+    eng.sync()
+    try:                                                          # layer 0 stayed in LDS: a stale read is refused ...
+        b0 = eng.debug_layer(0, batch=3)
+    except E.L.VcError as ex:
+        assert "layer 0 was not written" in str(ex)
+        b0 = None
+    if b0 is not None:                                            # ... unless the geometry took the two-launch path, which writes it
+        np.testing.assert_array_equal(a0, b0)
+    assert (b0 is None) == (hw != (480, 352)), hw
     assert a1.shape == b1.shape and np.abs(a1).max() > 0.5
     np.testing.assert_array_equal(a1, b1)
     np.testing.assert_array_equal(a2, b2)

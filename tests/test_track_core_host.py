@@ -15,10 +15,9 @@ import scenarios
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def tch(tmp_path_factory):
+def _build(tmp_path_factory, *defines):
     so = str(tmp_path_factory.mktemp("tch") / "libtch.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", *defines, "-o", so,
                     os.path.join(HERE, "native", "track_core_host.cpp")], check=True)
     lib = C.CDLL(so)
     lib.tch_create.restype = C.c_void_p
@@ -28,7 +27,19 @@ def tch(tmp_path_factory):
     lib.tch_state.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.tch_rows.argtypes = [C.c_void_p, C.c_void_p]
     lib.tch_lap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.tch_pyset_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     return lib
+
+
+@pytest.fixture(scope="module")
+def tch(tmp_path_factory):
+    return _build(tmp_path_factory)
+
+
+@pytest.fixture(scope="module")
+def tch_sorted(tmp_path_factory):
+    """Negative control: the same source with the set-order emulation switched off (ascending order, the behaviour before round 3)."""
+    return _build(tmp_path_factory, "-DVC_PYSET_ALWAYS_SORTED")
 
 
 def _state(lib, h, cap):
@@ -40,12 +51,67 @@ def _state(lib, h, cap):
     return {"ids": ids[:n], "state": st[:n], "hits": hits[:n], "age": age[:n], "tsu": tsu[:n], "mean": mean[:n], "covdiag": cd[:n], "gallery": gal[:n]}
 
 
+def _first_divergence(lib, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"tracker_{name}.npz"))
+    p, frames = scenarios.build(name)
+    cap = 256
+    h = lib.tch_create(p["max_dist"], p["max_iou_distance"], p["max_age"], p["n_init"], p["budget"], cap, 512)
+    try:
+        for t, dets in enumerate(frames):
+            tlwh = np.ascontiguousarray(np.array([d["tlwh"] for d in dets]).reshape(-1, 4))
+            feat = np.ascontiguousarray(np.array([d["feature"] for d in dets], dtype=np.float32).reshape(-1, 512))
+            assert lib.tch_step(h, tlwh.ctypes.data, feat.ctypes.data, len(dets), 1280, 720, 0) == 0
+            s = _state(lib, h, cap)
+            if not (np.array_equal(s["ids"], g[f"f{t}_ids"]) and np.array_equal(s["state"], g[f"f{t}_state"]) and
+                    np.allclose(s["mean"], g[f"f{t}_mean"], rtol=1e-9, atol=1e-9)):
+                return t
+    finally:
+        lib.tch_destroy(h)
+    return None
+
+
+def test_crowded_trace_needs_cpythons_set_order(tch, tch_sorted, golden_dir):
+    """The reference's `list(set(track_indices) - set(matched))` (linear_assignment.py:144) feeds the IoU stage in CPython's hash-table
+    order.  On the crowded golden trace (45 overlapping objects) that order is not ascending in some steps and decides which detection
+    a new track id goes to: the build with the emulation reproduces the reference's trace, the ascending-order build does not."""
+    for name in ("crowded", "crowded90"):
+        assert _first_divergence(tch, golden_dir, name) is None
+        assert _first_divergence(tch_sorted, golden_dir, name) is not None
+    for name in ("steady", "stress", "occlusion"):                    # ... while the light scenes never leave the ascending case
+        assert _first_divergence(tch_sorted, golden_dir, name) is None
+
+
+def test_pyset_difference_order_equals_python_sets(tch):
+    """csrc/track_core.h::pyset_difference_order against the interpreter's own `list(set(a) - set(b))` for ascending a (list
+    positions of confirmed tracks, < 512) and b a subset of a -- every table size, both branches of set_difference."""
+    import sys
+    assert sys.implementation.name == "cpython"
+    rng = np.random.default_rng(5)
+    n_unsorted = 0
+    for trial in range(6000):
+        T = int(rng.choice([5, 9, 20, 40, 64, 100, 200, 400, 512]))
+        n1 = int(rng.integers(0, T + 1))
+        conf = np.sort(rng.choice(T, n1, replace=False)).astype(np.int32)
+        n2 = int(rng.integers(0, n1 + 1)) if rng.uniform() < 0.6 else max(0, n1 - int(rng.integers(0, 5)))
+        matched_keys = rng.choice(conf, n2, replace=False) if n2 else np.zeros(0, np.int32)
+        flags = np.zeros(512, np.uint8)
+        flags[matched_keys] = 1
+        want = list(set(conf.tolist()) - set(int(k) for k in matched_keys))
+        out = np.zeros(max(n1, 1), np.int32)
+        conf = np.ascontiguousarray(conf)
+        n = tch.tch_pyset_order(conf.ctypes.data, n1, flags.ctypes.data, n2, out.ctypes.data)
+        assert n == len(want), trial
+        assert out[:n].tolist() == want, (trial, T, n1, n2)
+        n_unsorted += want != sorted(want)
+    assert n_unsorted > 300, n_unsorted
+
+
 @pytest.mark.parametrize("name", list(scenarios.SCENARIOS))
 def test_golden_tracker_traces(tch, golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"tracker_{name}.npz"))
     p, frames = scenarios.build(name)
-    cap = 64
-    h = tch.tch_create(p["max_dist"], p["max_iou_distance"], p["max_age"], p["n_init"], p["budget"], cap, 256)
+    cap = 256
+    h = tch.tch_create(p["max_dist"], p["max_iou_distance"], p["max_age"], p["n_init"], p["budget"], cap, 512)
     for t, dets in enumerate(frames):
         tlwh = np.ascontiguousarray(np.array([d["tlwh"] for d in dets]).reshape(-1, 4))
         feat = np.ascontiguousarray(np.array([d["feature"] for d in dets], dtype=np.float32).reshape(-1, 512))

@@ -84,7 +84,11 @@ SIGNATURES = {
     "vc_stream_submit_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],
+    "vc_stream_run_async_multi": [_vp, _pi, _i, _i, _pi, _vp, _i, _i, _i, _i],
     "vc_stream_reset": [_vp],
+    "vc_stream_embed": [_vp, _vp, _i, _i, _i, _pd, _i, _pi, _P(_vp)],
+    "vc_allgather_rows": [_vp, _pd, _vp, _i, _pd, _i, _pi, _P(_vp)],
+    "vc_videotracker_run_features": [_vp, _pi, _i, _pd, _vp, _i, _i, _i, _pl, _i, _pi, _pl, _i, _pi],
     "vc_counter_create": [_pd, _i, _pd, _i, _i, _P(_vp)],
     "vc_counter_destroy": [_vp],
     "vc_counter_add": [_vp, _pl, _pl, _pl, _pl, _i],

@@ -196,4 +196,67 @@ int vc_allgather_counts(vc_engine* e, const int32_t* local, int n, int32_t* out)
     return VC_OK;
 }
 
+// Variable-length all-gather of detection rows and their embeddings (the frame-sharded front end): every rank hands in
+// n rows [7] float64 (host) with the device address of the matching [n][512] float32 embeddings and receives the rows of ALL ranks,
+// rank-major (a rank's rows keep their order), their counts per rank, and the device address of the gathered embeddings in the same
+// order.  Two collectives on the engine's stream: the counts, then rows + embeddings padded to the largest count (ncclAllGather wants
+// equal contributions).  The gathered embeddings stay valid until the next vc_allgather_rows.
+int vc_allgather_rows(vc_engine* e, const double* rows7, const float* feat_dev, int n, double* out_rows7, int cap_rows, int* out_counts,
+                      const float** out_feat_dev) {
+    VC_CHECK(e && out_rows7 && out_counts && out_feat_dev && n >= 0 && (n == 0 || (rows7 && feat_dev)), VC_ERR_ARG, "bad argument");
+    VC_CHECK(e->comm, VC_ERR_STATE, "vc_comm_init first");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    const int world = e->comm_world;
+    ncclComm_t comm = (ncclComm_t)e->comm;
+    hipStream_t s = e->stream;
+    auto reserve = [&](void** p, size_t* cap, size_t need) -> int {
+        if (need > *cap) { VC_TRY(dev_alloc(e, p, need * 3 / 2 + 256)); *cap = need * 3 / 2 + 256; }
+        return VC_OK;
+    };
+    VC_TRY(reserve(&e->d_comm_buf, &e->comm_buf_bytes, (size_t)(world + 1) * sizeof(int32_t)));
+    int32_t* d_n = (int32_t*)e->d_comm_buf;
+    VC_HIP(hipMemcpyAsync(d_n, &n, 4, hipMemcpyHostToDevice, s));
+    ncclResult_t r = ncclAllGather(d_n, d_n + 1, 1, ncclInt32, comm, s);
+    VC_CHECK(r == ncclSuccess, VC_ERR_HIP, "ncclAllGather(counts): %s", ncclGetErrorString(r));
+    VC_HIP(hipMemcpyAsync(out_counts, d_n + 1, (size_t)world * 4, hipMemcpyDeviceToHost, s));
+    VC_HIP(hipStreamSynchronize(s));
+    int maxn = 0, total = 0;
+    for (int k = 0; k < world; ++k) { maxn = std::max(maxn, out_counts[k]); total += out_counts[k]; }
+    VC_CHECK(total <= cap_rows, VC_ERR_CAPACITY, "vc_allgather_rows: %d rows, room for %d", total, cap_rows);
+    *out_feat_dev = nullptr;
+    if (total == 0) return VC_OK;
+    const size_t rb = (size_t)maxn * 7 * sizeof(double), fb = (size_t)maxn * VC_FEAT_DIM * sizeof(float);
+    VC_TRY(reserve(&e->d_gather_send, &e->gather_send_bytes, rb + fb));
+    VC_TRY(reserve(&e->d_gather_recv, &e->gather_recv_bytes, (rb + fb) * world));
+    VC_TRY(reserve(&e->d_gather_feat, &e->gather_feat_bytes, (size_t)total * VC_FEAT_DIM * sizeof(float)));
+    if ((size_t)world * rb > e->h_gather_bytes) { VC_TRY(host_alloc(e, (void**)&e->h_gather, (size_t)world * rb * 2)); e->h_gather_bytes = (size_t)world * rb * 2; }
+    char* send = (char*)e->d_gather_send;
+    char* recv = (char*)e->d_gather_recv;
+    if (n > 0) {
+        VC_HIP(hipMemcpyAsync(send, rows7, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, s));
+        VC_HIP(hipMemcpyAsync(send + rb, feat_dev, (size_t)n * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    ncclGroupStart();
+    r = ncclAllGather(send, recv, (size_t)maxn * 7, ncclDouble, comm, s);
+    const ncclResult_t r2 = ncclAllGather(send + rb, recv + (size_t)world * rb, (size_t)maxn * VC_FEAT_DIM, ncclFloat, comm, s);
+    ncclGroupEnd();
+    VC_CHECK(r == ncclSuccess && r2 == ncclSuccess, VC_ERR_HIP, "ncclAllGather(rows): %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+    VC_HIP(hipMemcpyAsync(e->h_gather, recv, (size_t)world * rb, hipMemcpyDeviceToHost, s));
+    size_t off = 0;
+    for (int k = 0; k < world; ++k) {                       // compact the embeddings on the device, rank-major
+        if (out_counts[k] > 0)
+            VC_HIP(hipMemcpyAsync((char*)e->d_gather_feat + off * VC_FEAT_DIM * sizeof(float), recv + (size_t)world * rb + (size_t)k * fb,
+                                  (size_t)out_counts[k] * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+        off += out_counts[k];
+    }
+    VC_HIP(hipStreamSynchronize(s));
+    off = 0;
+    for (int k = 0; k < world; ++k) {
+        memcpy(out_rows7 + off * 7, (const char*)e->h_gather + (size_t)k * rb, (size_t)out_counts[k] * 7 * sizeof(double));
+        off += out_counts[k];
+    }
+    *out_feat_dev = (const float*)e->d_gather_feat;
+    return VC_OK;
+}
+
 }  // extern "C"

@@ -186,6 +186,11 @@ struct vc_engine {
     // ---- count all-gather (counting.hip): RCCL communicator of the engine's process group ----------------------
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     void* d_comm_buf = nullptr; size_t comm_buf_bytes = 0;
+    // vc_allgather_rows (frame-sharded front end): padded send / receive blocks, the compacted embeddings, pinned rows
+    void* d_gather_send = nullptr; size_t gather_send_bytes = 0;
+    void* d_gather_recv = nullptr; size_t gather_recv_bytes = 0;
+    void* d_gather_feat = nullptr; size_t gather_feat_bytes = 0;
+    void* h_gather = nullptr; size_t h_gather_bytes = 0;
     void* d_overlay = nullptr; size_t overlay_bytes = 0;      // primitive lists of vc_overlay (overlay.hip)
 
     // ---- measurement ----------------------------------------------------------------------------------

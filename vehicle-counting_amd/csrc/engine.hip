@@ -660,12 +660,24 @@ static int reid_alloc(vc_engine* e) {
     return VC_OK;
 }
 
-// forward from the pre-filled "in" buffer (k x 50 x 50 x cpad) to e->d_feat
+// forward from the pre-filled "in" buffer (k x 50 x 50 x cpad) to feat_out.  A conv launch addresses at most 2^24 output pixels
+// (conv_check), and the first layer has 2500 per crop: more than VC_REID_CHUNK crops run as several passes over slices of "in"
+// (the other activation buffers are reused; the passes are ordered on the stream).
+#define VC_REID_CHUNK 6400
+static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float* feat_out);
 static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
+    // ... and its 50 x 50 x 64 output must stay below the 2 GiB a buffer descriptor addresses (fp32: 3200 crops)
+    const int chunk = std::min(VC_REID_CHUNK, (int)(((1ull << 31) - 1) / ((size_t)2500 * 64 * elem_size(e->aux_prec))) / 64 * 64);
+    for (int k0 = 0; k0 < k; k0 += chunk)
+        VC_TRY(reid_forward_chunk(e, k0, std::min(chunk, k - k0), rs, feat_out + (size_t)k0 * VC_FEAT_DIM));
+    return VC_OK;
+}
+static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float* feat_out) {
     std::vector<Op> ops;
     PlanBuilder pb{e, &e->reid, &ops, e->aux_prec};
     auto& m = e->rbuf;
     View x = mkview(m["in"], k, 50, 50, reid_cpad(e->aux_prec), 0);
+    x.ptr = (char*)x.ptr + (size_t)k0 * 50 * 50 * reid_cpad(e->aux_prec) * elem_size(e->aux_prec);
     x = pb.conv("conv", x, mkview(m["r0"], k, 50, 50, 64, 0), 3, 1, 1, ACT_RELU);             // model.py:51-55
     { Op op{}; op.kind = Op::MAXPOOL; op.a = x; op.b = mkview(m["x0"], k, 25, 25, 64, 0); ops.push_back(op); x = op.b; }   // :58
     for (const auto& b : kReidBlocks) {                                                        // BasicBlock.forward, model.py:30-38
@@ -943,6 +955,9 @@ int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* 
     VC_HIP(hipMemcpyAsync(e->d_geom, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice, e->dstream));
     VC_HIP(hipStreamSynchronize(e->dstream));        // hg / rgb[] are caller or stack memory
     const size_t px = (size_t)nh * nw * 4 * elem_size(e->aux_prec);
+    // this pass reads the letterboxed tensor written below: a u8 source left behind by an earlier stream pass (kept for
+    // vc_detect_debug_layer(-1)) must not be picked up by the stem kernels again
+    e->stem_src = nullptr; e->in_stale = false;
     for (int i = 0; i < n; ++i) {
         const LetterboxGeom g = letterbox_geom(h[i], w[i], nh, nw, false);
         ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream);

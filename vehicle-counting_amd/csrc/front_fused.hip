@@ -50,7 +50,9 @@ template <bool U8>
 __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
                                                              const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
-                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg) {
+                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl) {
+    // abl (VC_FF_ABLATE, diagnostics with WRONG results; 0 in production): 1 no transcendentals, 2 no stem MFMAs, 4 no stem LDS stores,
+    // 8 no output stores, 16 no stem phase, 32 no conv phase, 64 no patch writes
     __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
     __shared__ uint4 l0t[FF_NT0 * 16 * 4];                 // 72.7 KB: [pixel slot][4 chunks], swizzled
     __shared__ uint4 w1s[9 * 4 * 64];                      // 36.9 KB: layer-1 weights, [tap][channel tile][lane] = one fragment load per wave
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int i = threadIdx.x + k * NT;
-            if (i < FF_PR * FF_PC) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = patch_chunk(pre[k]); }
+            if (i < FF_PR * FF_PC && !(abl & 64)) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = patch_chunk(pre[k]); }
         }
         __syncthreads();
         if (dbg) ts1 = wall_clock64();
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         // even columns 0 .. 30; tile 33 + r = row r, odd columns 1 .. 31; tiles 66 .. 68 = the 33 pixels of column 32, one row per lane.
         // LDS slot of a pixel: plane (column parity) * 561 + row * 17 + column / 2, as before. ------------------------------------------
         const bool interior = gy0 >= 0 && gy0 + FF_RH <= H0 && gx0 >= 0 && gx0 + 2 * FF_TW + 1 <= W0;     // block-uniform: no zero padding of layer 0 in this tile
-        for (int tb = wave * 2; tb < FF_NT0R; tb += 2 * FF_NW) {    // two pixel tiles per pass and wave
+        for (int tb = wave * 2; tb < FF_NT0R && !(abl & 16); tb += 2 * FF_NW) {    // two pixel tiles per pass and wave
             int ly[2], lx[2], slot[2];
             bool live[2];
 #pragma unroll
@@ -170,6 +172,11 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 ChunkF xf[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) xf[q].u = patch[(2 * ly[q]) * FF_PP + lx[q] + koff[s]];
+                if (abl & 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { acc[0][q][0] += __uint_as_float(xf[q].u.x); acc[1][q][1] += __uint_as_float(xf[q].u.w); }
+                    continue;
+                }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -190,8 +197,9 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f32x2f lo = ff_silu2((f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv0[ct].x, bv0[ct].y});
-                    const f32x2f hi = ff_silu2((f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv0[ct].z, bv0[ct].w});
+                    f32x2f lo = (f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv0[ct].x, bv0[ct].y};
+                    f32x2f hi = (f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv0[ct].z, bv0[ct].w};
+                    if (!(abl & 1)) { lo = ff_silu2(lo); hi = ff_silu2(hi); }
                     const bf16x2f p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
                     P[q].x = inside[q] ? __builtin_bit_cast(uint32_t, p0) : 0u; P[q].y = inside[q] ? __builtin_bit_cast(uint32_t, p1) : 0u;
                 }
@@ -200,13 +208,13 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
                 const int q = odd ? 1 : 0;                   // even lanes keep tile 0's pixel, odd lanes tile 1's (same `col`)
                 // the pair (lane, lane ^ 16) shares `col`, hence the same pixel of each tile; liveness and slot are per lane's own tile
-                if (live[q]) *(uint4*)(l0b + ff_l0_addr(slot[q], ct * 2 + (kq >> 1))) = o4;
+                if (live[q] && !(abl & 4)) *(uint4*)(l0b + ff_l0_addr(slot[q], ct * 2 + (kq >> 1))) = o4;
             }
         }
         if (dbg) ts2 = wall_clock64();
         __syncthreads();
         // ---- layer 1 from the LDS tile: wave w owns output rows 2w, 2w + 1 (one pixel tile each), all 64 channels; weights from LDS ---
-        {
+        if (!(abl & 32)) {
             f32x4f acc[4][2];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
@@ -235,8 +243,9 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f32x2f lo = ff_silu2((f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv1[ct].x, bv1[ct].y});
-                    const f32x2f hi = ff_silu2((f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv1[ct].z, bv1[ct].w});
+                    f32x2f lo = (f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv1[ct].x, bv1[ct].y};
+                    f32x2f hi = (f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv1[ct].z, bv1[ct].w};
+                    if (!(abl & 1)) { lo = ff_silu2(lo); hi = ff_silu2(hi); }
                     const bf16x2f p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
                     P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
                 }
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 const u32x2f sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
                 const int oy = oy0 + wave * 2 + (odd ? 1 : 0), ox = ox0 + col;
-                if (oy < H1 && ox < W1)
+                if (oy < H1 && ox < W1 && !(abl & 8))
                     *(uint4*)(y + (((size_t)b * H1 + oy) * W1 + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
         }
@@ -280,12 +289,13 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     const uint4* x = (const uint4*)p0.in;
     uint16_t* y = (uint16_t*)p1.out;
     static const bool dbg_on = getenv("VC_FF_DBG") != nullptr;
+    const int abl = getenv("VC_FF_ABLATE") ? atoi(getenv("VC_FF_ABLATE")) : 0;       // diagnostics only (tools/ff_ablate.py)
     long long* dbg = nullptr;
     if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 64) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 64, s);
     if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
-                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg);
+                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
     else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
-                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg);
+                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
     VC_HIP(hipGetLastError());
     if (dbg) {
         hipStreamSynchronize(s);

@@ -209,13 +209,20 @@ extern "C" {
 // VideoTracker.run would hand to that class's DeepSort.update (modules/track.py:50-59; frames without boxes are skipped,
 // modules/__init__.py:68-69, Q1), prepared on the host (confidence filter + DeepSORT NMS do not depend on tracker state), then ONE
 // kernel on the tracker stream that steps every tracker through the whole batch (track_kernels.hip).  No host round trip per frame.
-static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const int* trackers, int num_classes, int stage, int cap_rows_per_frame,
-                                  std::vector<int>& ndet) {
+// Multi-camera batches: frame f of the batch belongs to camera cam_of_frame[f] (nullptr: one camera) and is stepped on that camera's
+// trackers, trackers[cam * num_classes + c]; the frames of one camera appear in the batch in stream order.  One engine (one weight
+// copy, one detector launch per layer) then serves S cameras with B / S frames of latency each, and the tracker kernel walks
+// S x num_classes trackers in parallel, B / S steps each (a new VideoTracker per video, /root/reference/modules/__init__.py:29-36).
+static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const int* all_trackers, int num_classes, const int* cam_of_frame, int n_cam,
+                                  int stage, int cap_rows_per_frame, std::vector<int>& ndet) {
     const int b = pd.b;
     ndet.assign(b, 0);
     std::vector<std::vector<FrameClassDets>> frames(b);
     std::vector<std::vector<int>> by_class(num_classes);
     for (int f = 0; f < b; ++f) {
+        const int cam = cam_of_frame ? cam_of_frame[f] : 0;
+        VC_CHECK(cam >= 0 && cam < n_cam, VC_ERR_ARG, "frame %d: camera index %d outside [0, %d)", f, cam, n_cam);
+        const int* trackers = all_trackers + (size_t)cam * num_classes;
         FrameDets& d = pd.fd[f];
         ndet[f] = (int)d.conf.size();
         if (d.conf.empty()) continue;                                                // Q1
@@ -278,7 +285,12 @@ extern "C" {
 // vc_stream_collect.  At most two batches may be outstanding.
 int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                         int cap_rows_per_frame) {
-    VC_CHECK(e && trackers && frames_dev && cap_rows_per_frame > 0, VC_ERR_ARG, "bad argument");
+    return vc_stream_run_async_multi(e, trackers, 1, num_classes, nullptr, frames_dev, b, h, w, cap_rows_per_frame);
+}
+
+int vc_stream_run_async_multi(vc_engine* e, const int* trackers, int n_cam, int num_classes, const int* cam_of_frame, const void* frames_dev, int b, int h,
+                              int w, int cap_rows_per_frame) {
+    VC_CHECK(e && trackers && frames_dev && cap_rows_per_frame > 0 && n_cam >= 1 && (n_cam == 1 || cam_of_frame), VC_ERR_ARG, "bad argument");
     VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_CHECK(e->jobs.size() < 2, VC_ERR_STATE, "two asynchronous batches are already outstanding: call vc_stream_collect");
@@ -286,7 +298,7 @@ int vc_stream_run_async(vc_engine* e, const int* trackers, int num_classes, cons
     VC_TRY(take_front(e, frames_dev, b, h, w, pd));
     vc_engine::AsyncJob job;
     job.stage = (int)(e->tstage_seq++ % 3); job.b = b; job.cap = cap_rows_per_frame;
-    VC_TRY(enqueue_batch_tracking(e, pd, trackers, num_classes, job.stage, cap_rows_per_frame, job.ndet));
+    VC_TRY(enqueue_batch_tracking(e, pd, trackers, num_classes, cam_of_frame, n_cam, job.stage, cap_rows_per_frame, job.ndet));
     e->jobs.push_back(std::move(job));
     g_tm.report();
     return try_issue_next(e);
@@ -317,6 +329,82 @@ int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void
     VC_CHECK(e->jobs.empty(), VC_ERR_STATE, "asynchronous batches are outstanding: vc_stream_collect them first");
     VC_TRY(vc_stream_run_async(e, trackers, num_classes, frames_dev, b, h, w, cap_rows_per_frame));
     return vc_stream_collect(e, out_rows6, cap_rows_per_frame, out_m, out_ndet, b);
+}
+
+// ---- one stream on several GPUs: the stateless front end shards by frame chunk over the ranks -----------------------
+// Front half of the fused path for the OLDEST submission: wait for its detector, marshal the detections like networks/yolo.py:72-97,
+// cut the crops and run the ReID net for every box (deep_sort.py:119-129, Q5), and hand back what VideoTracker.run works on: rows
+// [frame index in the batch, x1, y1, x2, y2, conf, label] (float64; a frame without boxes contributes nothing, Q1) plus the device
+// address of the matching [n][512] float32 embeddings.  The embeddings stay valid until the third following vc_stream_embed /
+// vc_stream_run* call (three feature buffers rotate).
+int vc_stream_embed(vc_engine* e, const void* frames_dev, int b, int h, int w, double* out_rows7, int cap_rows, int* out_n, const float** out_feat_dev) {
+    VC_CHECK(e && frames_dev && out_rows7 && out_n && out_feat_dev, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_detector && e->cfg.with_reid, VC_ERR_STATE, "engine not finalized");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    vc_engine::Pending pd;
+    VC_TRY(take_front(e, frames_dev, b, h, w, pd));
+    VC_HIP(hipEventSynchronize(e->ev_reid[pd.fslot]));
+    int n = 0;
+    for (int f = 0; f < b; ++f) n += (int)pd.fd[f].conf.size();
+    VC_CHECK(n <= cap_rows, VC_ERR_CAPACITY, "vc_stream_embed: %d rows, room for %d", n, cap_rows);
+    double* o = out_rows7;
+    for (int f = 0; f < b; ++f) {
+        const FrameDets& d = pd.fd[f];
+        for (size_t i = 0; i < d.conf.size(); ++i, o += 7) {
+            o[0] = (double)f; memcpy(o + 1, &d.xyxy[i * 4], 4 * sizeof(double)); o[5] = d.conf[i]; o[6] = (double)d.label[i];
+        }
+    }
+    *out_n = n;
+    *out_feat_dev = e->d_feat2[pd.fslot];
+    return VC_OK;
+}
+
+// VideoTracker.run (modules/track.py:30-70) for a run of frames whose detections AND embeddings are supplied -- the tracker rank of the
+// frame-sharded front end.  rows7 [n][7] = [frame key, x1, y1, x2, y2, conf, label] sorted by frame key (any ascending integer, e.g. the
+// 1-based frame id); row i's embedding is feat_dev[i].  One launch of track_batch_kernel steps every (frame, class with boxes) in order.
+// Output per distinct frame key, ascending: out_keys[j], out_m[j] rows [x1, y1, x2, y2, track id, label] at out_rows6[j * cap_rows_per_frame].
+int vc_videotracker_run_features(vc_engine* e, const int* trackers, int num_classes, const double* rows7, const float* feat_dev, int n, int h, int w,
+                                 int64_t* out_rows6, int cap_rows_per_frame, int* out_m, int64_t* out_keys, int cap_frames, int* out_n_frames) {
+    VC_CHECK(e && trackers && out_rows6 && out_m && out_keys && out_n_frames && (n == 0 || (rows7 && feat_dev)) && n >= 0, VC_ERR_ARG, "bad argument");
+    VC_HIP(hipSetDevice(e->cfg.device));
+    VC_TRY(async_wait_all(e));
+    std::vector<std::vector<FrameClassDets>> frames;
+    std::vector<int64_t> keys;
+    std::vector<std::vector<int>> by_class(num_classes);
+    for (int i0 = 0; i0 < n;) {
+        const double key = rows7[(size_t)i0 * 7];
+        int i1 = i0;
+        while (i1 < n && rows7[(size_t)i1 * 7] == key) ++i1;
+        VC_CHECK(keys.empty() || (int64_t)key > keys.back(), VC_ERR_ARG, "rows must be sorted by frame key");
+        keys.push_back((int64_t)key);
+        frames.emplace_back();
+        for (int i = i0; i < i1; ++i) {
+            const int lb = (int)rows7[(size_t)i * 7 + 6];
+            if (lb >= 0 && lb < num_classes) by_class[lb].push_back(i);
+        }
+        for (int c = 0; c < num_classes; ++c) {                                        // modules/track.py:50-59
+            std::vector<int>& g = by_class[c];
+            if (g.empty()) continue;
+            VC_CHECK(trackers[c] >= 0 && trackers[c] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            std::vector<double> bx(g.size() * 4), cf(g.size());
+            for (size_t k = 0; k < g.size(); ++k) {
+                memcpy(&bx[k * 4], rows7 + (size_t)g[k] * 7 + 1, 4 * sizeof(double));
+                cf[k] = rows7[(size_t)g[k] * 7 + 5];
+            }
+            FrameClassDets fc{c, trackers[c], {}};
+            prepare_dets(bx.data(), cf.data(), g.data(), (int)g.size(), e->trackers[trackers[c]]->p, fc.dets);
+            frames.back().push_back(std::move(fc));
+            g.clear();
+        }
+        i0 = i1;
+    }
+    const int nf = (int)frames.size();
+    VC_CHECK(nf <= cap_frames, VC_ERR_CAPACITY, "%d frames, room for %d", nf, cap_frames);
+    *out_n_frames = nf;
+    for (int j = 0; j < nf; ++j) out_keys[j] = keys[j];
+    if (nf == 0) return VC_OK;
+    VC_TRY(track_enqueue(e, 3, frames, feat_dev, w, h, nf * cap_rows_per_frame, nullptr));
+    return track_collect(e, 3, out_rows6, cap_rows_per_frame, out_m);
 }
 
 // Abandon everything in flight on the stream path: waits for the GPU, discards the rows of uncollected batches (their tracker steps

@@ -354,6 +354,120 @@ VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc,
     return nr;
 }
 
+// ---- CPython's list(set(a) - set(b)) --------------------------------------------------------------------------------------------------
+// linear_assignment.py:144 builds the cascade's unmatched tracks as `list(set(track_indices) - set(k for k, _ in matches))`, and
+// tracker.py:118-120 keeps that list's order for the confirmed tracks that enter the IoU stage -- the order of the IoU cost matrix's rows,
+// hence of the rejected pairs min_cost_matching appends to the unmatched detections, hence of the ids new tracks receive.  A Python set of
+// small ints iterates in hash-table slot order: ascending as long as every key is smaller than the table, anything else once a key wraps
+// around (a tracker with 40 confirmed tracks whose tracks 13 and 45 miss a frame yields [45, 13]).  The reference's results therefore
+// depend on CPython's set implementation (Objects/setobject.c, unchanged in the respects below from 3.7 to 3.12: 8-slot minimum table,
+// hash(int) = int, 9 linear probes then i = 5 i + 1 + perturb with perturb >>= 5, growth to the first power of two above 4 x used when
+// fill x 5 >= mask x 3; set_difference copies the left set when it is more than four times larger than the right one and otherwise
+// adds the surviving keys to a new set in the left set's iteration order).  Restated here for keys in [0, 512); tables of int16,
+// -1 = empty.  tests/test_track_core_host.py checks it against real Python sets.
+struct PySetSim { short* tab; short* spare; int mask, fill; };
+VC_HD void pyset_clear(Lanes L, short* t, int n) {
+    for (int i = L.lane; i < n; i += L.n) t[i] = -1;
+    wave_sync();
+}
+VC_HD void pyset_insert_clean(short* tab, int mask, int key) {     // set_insert_clean: the table holds no equal key and no dummy
+    unsigned perturb = (unsigned)key;
+    int i = key & mask;
+    while (true) {
+        if (tab[i] < 0) { tab[i] = (short)key; return; }
+        if (i + 9 <= mask)
+            for (int j = 1; j <= 9; ++j)
+                if (tab[i + j] < 0) { tab[i + j] = (short)key; return; }
+        perturb >>= 5;
+        i = (int)(((unsigned)i * 5u + 1u + perturb) & (unsigned)mask);
+    }
+}
+VC_HD void pyset_resize(Lanes L, PySetSim& s, int minused) {         // set_table_resize: re-insert in slot order
+    int newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    short* old = s.tab;
+    const int oldn = s.mask + 1;
+    s.tab = s.spare; s.spare = old; s.mask = newsize - 1;
+    pyset_clear(L, s.tab, newsize);
+    for (int i = 0; i < oldn; ++i) {
+        const int k = old[i];
+        if (k >= 0) pyset_insert_clean(s.tab, s.mask, k);      // every lane performs the same accesses: program order is enough
+    }
+}
+VC_HD void pyset_add(Lanes L, PySetSim& s, int key) {               // set_add_entry for a key that is not in the set yet
+    pyset_insert_clean(s.tab, s.mask, key);                         // (same probe sequence: no dummies, no equal keys)
+    ++s.fill;
+    if (s.fill * 5 >= s.mask * 3) pyset_resize(L, s, s.fill * 4);
+}
+VC_HD int pyset_seq_mask(int n) { return n < 5 ? 7 : n < 19 ? 31 : n < 77 ? 127 : n < 307 ? 511 : 2047; }   // mask after n adds to an empty set
+// conf[0 .. n1): ascending keys (the confirmed tracks' list positions); matched(key): key is in the right-hand set, n2 of them.
+// out[0 .. n1 - n2): the surviving keys in CPython's iteration order.  mem0 / mem1: two tables of at least `slots` int16 each, where
+// slots >= pyset_need_slots(n1).  Returns the number of survivors.
+VC_HD int pyset_copy_mask(int n1) { int ns = 8; if (n1 * 5 >= 21) while (ns <= 2 * n1) ns <<= 1; return ns - 1; }   // set_merge into an empty set
+VC_HD int pyset_need_slots(int n1) { return imax(pyset_seq_mask(n1), pyset_copy_mask(n1)) + 1; }
+// is the result simply ascending?  n1 keys with maximum max1 on the left, n2 of them removed, the largest survivor is maxu
+VC_HD bool pyset_difference_sorted(int n1, int n2, int max1, int maxu) {
+#ifdef VC_PYSET_ALWAYS_SORTED            // tests only (negative control): the pre-round-3 behaviour, ascending order whatever the keys
+    return true;
+#endif
+    const int mask1 = pyset_seq_mask(n1);
+    const bool s1_sorted = max1 <= mask1;                   // ascending whenever no key wraps around in a table that decides the order
+    const bool copy_path = (n1 >> 2) > n2;                  // set_difference: copy the left set and discard / build a new set
+    const int copy_mask = pyset_copy_mask(n1);
+    return copy_path ? (copy_mask == mask1 ? s1_sorted : max1 <= copy_mask) : (s1_sorted && maxu <= pyset_seq_mask(n1 - n2));
+}
+template <class M>
+VC_HD int pyset_difference_order(Lanes L, const int* conf, int n1, M matched, int n2, short* mem0, short* mem1, int* out) {
+    const int r = n1 - n2;
+    if (r <= 0 || n1 <= 0) return 0;
+    const int max1 = conf[n1 - 1];
+    const int mask1 = pyset_seq_mask(n1);
+    const bool copy_path = (n1 >> 2) > n2;
+    const int copy_mask = pyset_copy_mask(n1);
+    const bool s1_sorted = max1 <= mask1;
+    int maxu = -1;
+    for (int q = n1 - 1; q >= 0; --q) if (!matched(conf[q])) { maxu = conf[q]; break; }
+    if (pyset_difference_sorted(n1, n2, max1, maxu))
+        return compact(L, n1, [&](int q) { return !matched(conf[q]); }, [&](int pos, int q) { out[pos] = conf[q]; });
+    // the left set, as set(list) builds it
+    PySetSim a{mem0, mem1, 7, 0};
+    if (!s1_sorted) {
+        pyset_clear(L, a.tab, 8);
+        for (int q = 0; q < n1; ++q) pyset_add(L, a, conf[q]);
+    }
+    // its iteration order (slot order; ascending when nothing wrapped), filtered, goes through the result set
+    auto for_each_a = [&](auto&& f) {
+        if (s1_sorted) { for (int q = 0; q < n1; ++q) f(conf[q]); }
+        else { for (int i = 0; i <= a.mask; ++i) { const int k = a.tab[i]; if (k >= 0) f(k); } }
+    };
+    int n = 0;
+    if (copy_path) {
+        if (!s1_sorted && copy_mask == a.mask) {            // same table size: the copy is slot for slot
+            for_each_a([&](int k) { if (!matched(k)) { if (L.lane == 0) out[n] = k; ++n; } });
+            wave_sync();
+            return n;
+        }
+        short* rt = s1_sorted ? mem0 : a.spare;             // set_merge into an empty set: set_insert_clean in the source's slot order
+        pyset_clear(L, rt, copy_mask + 1);
+        for_each_a([&](int k) { pyset_insert_clean(rt, copy_mask, k); });
+        for (int i = 0; i <= copy_mask; ++i) { const int k = rt[i]; if (k >= 0 && !matched(k)) { if (L.lane == 0) out[n] = k; ++n; } }
+        wave_sync();
+        return n;
+    }
+    // new set: survivors are added in the left set's iteration order.  The left table must stay intact while the result grows, so the
+    // result ping-pongs between the second table's halves... it is at most as large as the left one: use its own pair of buffers
+    // carved from the spare table when the left set was simulated, else the two tables themselves.
+    int keys_n = 0;
+    for_each_a([&](int k) { if (!matched(k)) { if (L.lane == 0) out[keys_n] = k; ++keys_n; } });      // insertion order, staged in out[]
+    wave_sync();
+    PySetSim rs{mem0, mem1, 7, 0};
+    pyset_clear(L, rs.tab, 8);
+    for (int q = 0; q < keys_n; ++q) pyset_add(L, rs, out[q]);
+    for (int i = 0; i <= rs.mask; ++i) { const int k = rs.tab[i]; if (k >= 0) { if (L.lane == 0) out[n] = k; ++n; } }
+    wave_sync();
+    return n;
+}
+
 // linear_assignment.py:52-77 on the sub-matrix cost[rows[i] * ld + cols[j]].  Accepted pairs are appended to match_t / match_d
 // (n_match advances); unmatched rows / columns go to un_rows / un_cols in the reference's list order (unassigned ones first,
 // in index order, then the rejected pairs in row order).
@@ -507,7 +621,27 @@ __device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, c
     const unsigned long long um = __ballot(lane < T && !conf), rcm = __ballot(conf && !matched && tsu == 1), unm = __ballot(conf && !matched && tsu != 1);
     const int n_unconf = __popcll(um), nr = n_unconf + __popcll(rcm);
     const bool is_u = (um >> lane) & 1ull, is_r = (rcm >> lane) & 1ull;
-    int rows = lane_push(is_u ? __popcll(um & lt) : is_r ? n_unconf + __popcll(rcm & lt) : 63, lane);
+    int rows;
+    // The confirmed tracks missed for one frame enter in the order of the reference's `list(set(track_indices) - set(matched))`
+    // (linear_assignment.py:144, tracker.py:118-120): ascending unless a key wraps around in CPython's hash table (pyset_difference_order)
+    const unsigned long long cm = __ballot(conf), uam = rcm | unm;
+    const int n1 = __popcll(cm);
+    if (uam == 0 || pyset_difference_sorted(n1, n_match, 63 - __builtin_clzll(cm), 63 - __builtin_clzll(uam))) {
+        rows = lane_push(is_u ? __popcll(um & lt) : is_r ? n_unconf + __popcll(rcm & lt) : 63, lane);
+    } else {
+        if (conf) w.confirmed[__popcll(cm & lt)] = lane;
+        if (lane < T) w.matched[lane] = matched ? 1 : 0;
+        wave_sync();
+        const int n_ua = pyset_difference_order(Lanes{lane, 64}, w.confirmed, n1, [&](int t) { return w.matched[t] != 0; }, n_match, (short*)w.small_c,
+                                                (short*)w.small_t, w.ri);
+        wave_sync();
+        const int key = lane < n_ua ? w.ri[lane] : 0;
+        const bool rec = lane < n_ua && __shfl(tsu, key) == 1;
+        const unsigned long long recm = __ballot(rec);
+        const int rows_u = lane_push(is_u ? __popcll(um & lt) : 63, lane);
+        const int rows_r = lane_push(rec ? n_unconf + __popcll(recm & lt) : (n_unconf > 0 ? 0 : 63), key);
+        rows = lane < n_unconf ? rows_u : rows_r;
+    }
     if (lane >= nr) rows = 0;
     if ((unm >> lane) & 1ull) w.un_tracks[__popcll(unm & lt)] = lane;
     n_un = __popcll(unm);
@@ -602,10 +736,16 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
     if (prof && L.lane == 0) prof[2] = tc_clock();
     // IoU stage (tracker.py:118-127): unconfirmed tracks + confirmed tracks that were missed for exactly one frame
     for (int q = L.lane; q < n_unconf; q += L.n) w.rows[q] = w.unconfirmed[q];
-    const int n_recent = compact(L, n_conf, [&](int q) { const int t = w.confirmed[q]; return !w.matched[t] && w.tsu[t] == 1; },
-                                 [&](int pos, int q) { w.rows[n_unconf + pos] = w.confirmed[q]; });
-    n_un = compact(L, n_conf, [&](int q) { const int t = w.confirmed[q]; return !w.matched[t] && w.tsu[t] != 1; },
-                   [&](int pos, int q) { w.un_tracks[pos] = w.confirmed[q]; });
+    // the cascade's unmatched tracks in the order of the reference's `list(set(track_indices) - set(matched))` (linear_assignment.py:144):
+    // that order is the row order of the IoU problem for the tracks missed for exactly one frame (tracker.py:118-120)
+    const int need = pyset_need_slots(n_conf);
+    short* const m0 = (w.small_c && need <= w.small_n * 4) ? (short*)w.small_c : (short*)cbuf;
+    short* const m1 = (w.small_t && need <= w.small_n * 4) ? (short*)w.small_t : (short*)tbuf;
+    wave_sync();
+    const int n_ua = pyset_difference_order(L, w.confirmed, n_conf, [&](int t) { return w.matched[t] != 0; }, n_match, m0, m1, w.ri);
+    wave_sync();
+    const int n_recent = compact(L, n_ua, [&](int q) { return w.tsu[w.ri[q]] == 1; }, [&](int pos, int q) { w.rows[n_unconf + pos] = w.ri[q]; });
+    n_un = compact(L, n_ua, [&](int q) { return w.tsu[w.ri[q]] != 1; }, [&](int pos, int q) { w.un_tracks[pos] = w.ri[q]; });
     wave_sync();
     int n_ur = 0, n_uc = 0;
     min_cost_matching(L, w, w.rows, n_unconf + n_recent, left, n_left, cost_iou, D, h.max_iou_distance, cbuf, tbuf, n_match, w.un_rows, n_ur, other,

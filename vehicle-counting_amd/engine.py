@@ -244,6 +244,18 @@ class Engine:
         self._async_shapes = getattr(self, "_async_shapes", [])
         self._async_shapes.append((b, cap_rows))
 
+    def stream_run_async_multi(self, tracker_ids, cam_of_frame, frames_dev_ptr, b, h, w, cap_rows=512):
+        """Multi-camera batch: tracker_ids [n_cam][num_classes], cam_of_frame [b] (each camera's frames in stream order); rows are
+        collected with `stream_collect` per frame of the batch, as for one camera."""
+        tr = np.ascontiguousarray(tracker_ids, dtype=np.int32)
+        assert tr.ndim == 2, "tracker_ids must be [n_cam][num_classes]"
+        cams = np.ascontiguousarray(cam_of_frame, dtype=np.int32).reshape(-1)
+        assert len(cams) == b
+        L.check(L.lib().vc_stream_run_async_multi(self._h, L.ptr(tr, C.c_int), tr.shape[0], tr.shape[1], L.ptr(cams, C.c_int),
+                                                  C.c_void_p(frames_dev_ptr), b, h, w, cap_rows))
+        self._async_shapes = getattr(self, "_async_shapes", [])
+        self._async_shapes.append((b, cap_rows))
+
     def stream_collect(self):
         """Rows of the oldest asynchronous batch, packed like `stream_run_packed` (blocks until its tracker loop is done)."""
         b, cap_rows = self._async_shapes.pop(0)
@@ -262,6 +274,41 @@ class Engine:
         out = C.c_void_p()
         L.check(L.lib().vc_stream_submit_host(self._h, C.c_void_p(frames_host_ptr), b, h, w, C.byref(out)))
         return out.value
+
+    # ---------------------------------------------------------------- frame-sharded front end (one stream on several GPUs)
+    def stream_embed(self, frames_dev_ptr, b, h, w):
+        """Front half of the fused path for the oldest submission: (rows [n, 7] float64 = frame index in the batch, x1, y1, x2, y2,
+        conf, label -- the boxes VideoTracker.run works on -- and the DEVICE address of the matching [n, 512] float32 embeddings)."""
+        cap = b * self.cfg.max_det
+        rows = np.zeros((cap, 7), np.float64)
+        n, feat = C.c_int(), C.c_void_p()
+        L.check(L.lib().vc_stream_embed(self._h, C.c_void_p(frames_dev_ptr), b, h, w, L.ptr(rows, C.c_double), cap, C.byref(n), C.byref(feat)))
+        return rows[: n.value].copy(), feat.value or 0
+
+    def allgather_rows(self, rows7, feat_dev_ptr, world):
+        """RCCL all-gather (C ABI, vc_comm_init first) of every rank's rows + embeddings: (rows of all ranks, rank-major; device
+        address of the gathered embeddings in the same order; rows per rank)."""
+        rows = L.f64(rows7).reshape(-1, 7)
+        cap = world * self.cfg.max_batch * self.cfg.max_det
+        out = np.zeros((cap, 7), np.float64)
+        counts = np.zeros(world, np.int32)
+        feat = C.c_void_p()
+        L.check(L.lib().vc_allgather_rows(self._h, L.ptr(rows, C.c_double), C.c_void_p(feat_dev_ptr or None), len(rows), L.ptr(out, C.c_double), cap,
+                                          L.ptr(counts, C.c_int), C.byref(feat)))
+        return out[: int(counts.sum())].copy(), feat.value or 0, counts
+
+    def videotracker_run_features(self, tracker_ids, rows7, feat_dev_ptr, h, w, cap_rows=512):
+        """VideoTracker.run for a run of frames with supplied detections (rows7 sorted by frame key) and device-resident embeddings:
+        [(frame key, rows [m, 6] = x1, y1, x2, y2, track id, label)] per distinct key, ascending; one tracker kernel launch."""
+        rows = L.f64(rows7).reshape(-1, 7)
+        tr = np.ascontiguousarray(tracker_ids, dtype=np.int32)
+        nf_cap = max(len(np.unique(rows[:, 0])), 1)
+        out = np.empty((nf_cap, cap_rows, 6), np.int64)
+        m, keys, nf = np.zeros(nf_cap, np.int32), np.zeros(nf_cap, np.int64), C.c_int()
+        L.check(L.lib().vc_videotracker_run_features(self._h, L.ptr(tr, C.c_int), len(tr), L.ptr(rows, C.c_double), C.c_void_p(feat_dev_ptr or None),
+                                                     len(rows), h, w, L.ptr(out, C.c_int64), cap_rows, L.ptr(m, C.c_int), L.ptr(keys, C.c_int64),
+                                                     nf_cap, C.byref(nf)))
+        return [(int(keys[j]), out[j, : m[j]].copy()) for j in range(nf.value)]
 
     def stream_inject(self, det6=None, counts=None):
         if det6 is None:

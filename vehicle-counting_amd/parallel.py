@@ -49,14 +49,12 @@ def allgather_counts(local_counts, device=None):
     return torch.cat(out, 0).cpu().numpy()
 
 
-def allgather_counts_native(engine, local_counts):
-    """The same all-gather through the C ABI (vc_comm_init / vc_allgather_counts: ncclAllGather on the engine's stream, RCCL over
-    xGMI).  The 128-byte RCCL id travels over the torch.distributed group the ranks already share; a single process gathers with
-    itself.  Returns int32 (world * n_cam_local, n_dir, n_cls), rank-major."""
+def ensure_comm(engine):
+    """Bring up the engine's RCCL communicator over the ranks of the torch.distributed group (a single process forms a world of
+    one): the 128-byte id travels over the group the ranks already share.  Returns (rank, world)."""
     import ctypes as C
 
     from . import _lib as L
-    t = np.ascontiguousarray(local_counts, dtype=np.int32)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     if not getattr(engine, "_comm_ready", False):
@@ -82,6 +80,17 @@ def allgather_counts_native(engine, local_counts):
             os.dup2(saved, 1)
             os.close(saved)
         engine._comm_ready = True
+    return rank, world
+
+
+def allgather_counts_native(engine, local_counts):
+    """The count all-gather through the C ABI (vc_comm_init / vc_allgather_counts: ncclAllGather on the engine's stream, RCCL over
+    xGMI).  Returns int32 (world * n_cam_local, n_dir, n_cls), rank-major."""
+    import ctypes as C
+
+    from . import _lib as L
+    t = np.ascontiguousarray(local_counts, dtype=np.int32)
+    rank, world = ensure_comm(engine)
     out = np.zeros((world,) + t.shape, np.int32)
     L.check(L.lib().vc_allgather_counts(engine._h, L.ptr(t.reshape(-1), C.c_int), t.size, L.ptr(out.reshape(-1), C.c_int)))
     return out.reshape((world * t.shape[0],) + t.shape[1:])

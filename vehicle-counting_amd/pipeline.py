@@ -115,51 +115,96 @@ class CountingPipeline:
             record(starts[-1], *self.engine.stream_collect()[:2])
         return self._finish(counter, obj, cam_name)
 
+    def run_streams(self, sources, cam_names, zone_paths, batch=16):
+        """S videos at once on ONE engine (the reference runs them one after another, each with a new VideoTracker,
+        modules/__init__.py:28-36): the frames of the cameras are interleaved round-robin into batches of `batch` frames, the
+        detector and the ReID net see one batch, every camera's frames are stepped on that camera's own trackers
+        (`vc_stream_run_async_multi`).  Per-camera results are identical to S separate `run_stream` calls; per-camera latency is
+        batch / S frames.  All sources must share one frame size.  Returns [(rows, counts)] in camera order."""
+        import torch
+        S = len(sources)
+        shapes = {s.frames.shape[1:] for s in sources}
+        assert len(shapes) == 1, "run_streams: all cameras must deliver frames of one size"
+        h, w, _ = next(iter(shapes))
+        stages = [self._stages(n, s.video_info, z) for n, s, z in zip(cam_names, sources, zone_paths)]
+        tids = np.array([st[0].tracker_ids for st in stages], np.int32)                 # [S][num_classes]
+        order = []                                                                       # (camera, frame) round-robin, exhausted cameras drop out
+        for t in range(max(len(s) for s in sources)):
+            order.extend((c, t) for c in range(S) if t < len(sources[c]))
+        cams = np.array([c for c, _ in order], np.int32)
+        fidx = np.array([t for _, t in order], np.int64)
+        dev = torch.from_numpy(np.stack([sources[c].frames[t] for c, t in order])).to(f"cuda:{self.engine.cfg.device}")
+        objs = [{"frames": [], "tracks": [], "labels": [], "boxes": []} for _ in range(S)]
+        starts = list(range(0, len(order), batch))
+
+        def record(f0, rows, fb):
+            g = f0 + fb                                                                  # global position of each row's frame
+            for c in range(S):
+                sel = cams[g] == c
+                o = objs[c]
+                o["frames"].extend((fidx[g[sel]] + 1).tolist())
+                o["tracks"].extend(rows[sel, 4].tolist())
+                o["labels"].extend(rows[sel, 5].tolist())
+                o["boxes"].extend(list(rows[sel, :4].copy()))
+
+        def span(n):
+            f0 = starts[n]
+            return f0, min(batch, len(order) - f0)
+
+        f0, b = span(0)
+        self.engine.stream_submit(dev[f0:f0 + b].data_ptr(), b, h, w)
+        for n in range(len(starts)):
+            f0, b = span(n)
+            if n + 1 < len(starts):
+                g0, gb = span(n + 1)
+                self.engine.stream_submit(dev[g0:g0 + gb].data_ptr(), gb, h, w)
+            self.engine.stream_run_async_multi(tids, cams[f0:f0 + b], dev[f0:f0 + b].data_ptr(), b, h, w)
+            if n > 0:
+                record(starts[n - 1], *self.engine.stream_collect()[:2])
+        if starts:
+            record(starts[-1], *self.engine.stream_collect()[:2])
+        return [self._finish(st[1], o, n) for st, o, n in zip(stages, objs, cam_names)]
+
     def run_frame_sharded(self, source, cam_name, zone_path, chunk=8, device=None):
-        """One camera stream, the stateless front end sharded by frame chunk over the ranks of torch.distributed (chunk j on rank
-        j % world), one ordered gather of [frame, x1, y1, x2, y2, conf, label, feature(512)] rows per round, the tracker and the
-        counting on rank 0 (tracker state never shards below a camera).  Returns (rows, counts) on rank 0, (None, None) elsewhere.
-        The detections are marshalled exactly as in run(): ImageDetect.run -> xywh -> xyxy (modules/track.py:39-41)."""
+        """ONE camera stream on several GPUs, on the product's own batched path: the stateless front end shards by
+        frame chunk over the ranks (chunk j on rank j % world): every rank submits its chunk to the batched detector
+        (`vc_stream_submit`) and takes the marshalled boxes + device-resident embeddings of the whole chunk back
+        (`vc_stream_embed`: one detector pass and one ReID pass per chunk); one variable-length RCCL all-gather per round behind the
+        C ABI (`vc_allgather_rows`: rows over PCIe-free xGMI, embeddings device to device) brings every round's rows to all ranks in
+        frame order; rank 0 steps the sequential tracker on the gathered round with ONE tracker kernel launch
+        (`vc_videotracker_run_features`) and runs the counting -- tracker state never shards below a camera.  The ordering contract
+        is the reference's (modules/__init__.py:54-84): frames reach the tracker in ascending order, empty frames are skipped (Q1).
+        Returns (rows, counts) on rank 0, (None, None) elsewhere."""
+        import torch
         import torch.distributed as dist
 
         from . import parallel
-        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank, world = parallel.ensure_comm(self.engine)
         frames = source.frames
         t, h, w, _ = frames.shape
         mine = parallel.shard_frames(t, rank, world, chunk)
         n_rounds = (len(range(0, t, chunk)) + world - 1) // world
         tracker, counter = self._stages(cam_name, source.video_info, zone_path) if rank == 0 else (None, None)
         obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
+        devs = [torch.from_numpy(frames[a:b]).to(f"cuda:{self.engine.cfg.device}") for a, b in mine]     # only this rank's chunks
+        if mine:
+            self.engine.stream_submit(devs[0].data_ptr(), len(devs[0]), h, w)
         for r in range(n_rounds):
-            local = []
+            if r + 1 < len(mine):                                                # detector of the next chunk runs behind this round's ReID / gather
+                self.engine.stream_submit(devs[r + 1].data_ptr(), len(devs[r + 1]), h, w)
             if r < len(mine):
-                for f in range(*mine[r]):
-                    bgr = frames[f]
-                    preds = self.detector.run({"imgs": [bgr[:, :, ::-1]], "ori_imgs": [bgr], "frames": [f + 1]})
-                    boxes, labels, scores = preds["boxes"][0], preds["labels"][0], preds["scores"][0]
-                    if len(boxes) == 0:                                              # modules/__init__.py:68-69 (Q1)
-                        continue
-                    xyxy = np.asarray(boxes, np.float64).copy()
-                    xyxy[:, 2] += xyxy[:, 0]; xyxy[:, 3] += xyxy[:, 1]               # modules/track.py:39-41
-                    bw, bh = xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]        # deep_sort.py:78-87
-                    cxcywh = np.stack([xyxy[:, 0] + bw / 2, xyxy[:, 1] + bh / 2, bw, bh], 1)
-                    feat = self.engine.embed(bgr, cxcywh)
-                    local.append(np.concatenate([np.full((len(xyxy), 1), f + 1, np.float64), xyxy, np.asarray(scores, np.float64)[:, None],
-                                                 np.asarray(labels, np.float64)[:, None], feat.astype(np.float64)], 1))
-            rows = parallel.gather_rows(np.concatenate(local, 0) if local else np.zeros((0, 7 + 512)), device=device)
+                rows7, feat = self.engine.stream_embed(devs[r].data_ptr(), len(devs[r]), h, w)
+                rows7[:, 0] += mine[r][0] + 1                                     # 1-based global frame id (modules/datasets.py:61)
+            else:
+                rows7, feat = np.zeros((0, 7)), 0
+            all_rows, all_feat, _ = self.engine.allgather_rows(rows7, feat, world)   # rank-major = frame order within a round
             if rank != 0:
                 continue
-            for fid in np.unique(rows[:, 0]) if len(rows) else []:                   # ascending frame ids
-                fr = rows[rows[:, 0] == fid]
-                lab = fr[:, 6].astype(np.int64)
-                for c in range(len(self.class_names)):                               # modules/track.py:50-59
-                    sel = fr[lab == c]
-                    if len(sel) == 0:
-                        continue
-                    out = tracker.deepsort[c].update_with_features(sel[:, 1:5], sel[:, 5], sel[:, 7:].astype(np.float32), h, w)
-                    for row in out:
-                        obj["frames"].append(int(fid)); obj["tracks"].append(int(row[4])); obj["labels"].append(c); obj["boxes"].append(row[:4].copy())
+            for fid, rows in self.engine.videotracker_run_features(tracker.tracker_ids, all_rows, all_feat, h, w):
+                obj["frames"].extend([fid] * len(rows))
+                obj["tracks"].extend(rows[:, 4].tolist())
+                obj["labels"].extend(rows[:, 5].tolist())
+                obj["boxes"].extend(list(rows[:, :4].copy()))
         if rank != 0:
             return None, None
         return self._finish(counter, obj, cam_name)
