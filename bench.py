@@ -108,7 +108,7 @@ def injected_detections(n_frames, size, n_obj, seed):
 class Stream:
     """One camera stream on one engine: the three overlapped stages of the fused path."""
 
-    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None):
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1):
         wl = dict(wl, precision=precision or wl["precision"])
         self.wl, self.dev = wl, dev
         self.B = B or wl["B"]
@@ -119,22 +119,31 @@ class Stream:
         clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
         self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
-        per_frame = max(64, 2 * max(inject, n_obj))
+        per_frame = max(64 if n_cam == 1 else 192, 2 * max(inject, n_obj))     # other cameras' clips draw more boxes from the random head than the rank-0 clip
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
                             img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=self.B * per_frame,
-                            max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096)
+                            max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096,
+                            max_trackers=max(256, n_cam * NC))
         k = 32
         sizes = []
         while k <= self.B * per_frame:
             sizes.append(k); k *= 2
         self.eng.pretune(tuple(sizes))                               # conv autotune for every ReID size bucket
-        self.trackers = [self.eng.tracker_create(**TRACK) for _ in range(NC)]
-        self.frames = synth_frames(clip, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True)      # one camera stream per rank
+        # n_cam > 1: S cameras interleaved frame by frame in every batch (vc_stream_run_async_multi): one engine, B / S frames of latency
+        # per camera, S x 80 trackers walked in parallel by the tracker kernel
+        self.n_cam = n_cam
+        assert self.B % n_cam == 0 and clip % n_cam == 0
+        self.trackers = [[self.eng.tracker_create(**TRACK) for _ in range(NC)] for _ in range(n_cam)]
+        per_cam = [synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank + 97 * c, bounce=True) for c in range(n_cam)]
+        self.frames = per_cam[0] if n_cam == 1 else np.stack(per_cam, 1).reshape((clip,) + per_cam[0].shape[1:])     # frame j: camera j % S, time j // S
+        self.cams = np.tile(np.arange(n_cam, dtype=np.int32), self.B // n_cam)
         self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region
         self.clip = clip
         self.inject = injected_detections(clip, self.H, inject, 1702 + rank) if inject else None
-        self.counter = VideoCounting([str(c) for c in range(NC)], ZONE)     # the Python restatement: checks the native counter after the timed region
-        self.ncounter = NativeCounter(ZONE, NC)                              # the count tensor behind the C ABI (vc_counter_* / vc_counts)
+        assert not (inject and n_cam > 1)
+        self.counters = [VideoCounting([str(c) for c in range(NC)], ZONE) for _ in range(n_cam)]    # the Python restatement: checks the native counter after the timed region
+        self.ncounters = [NativeCounter(ZONE, NC) for _ in range(n_cam)]     # the count tensors behind the C ABI (vc_counter_* / vc_counts), one per camera
+        self.ncounter = self.ncounters[0]
         self.gather_via = None
         try:                                                                 # bring the RCCL communicator up before anything is timed
             parallel.allgather_counts_native(self.eng, np.zeros((1, len(self.ncounter.direction_keys), NC), np.int32))
@@ -142,7 +151,7 @@ class Stream:
             print(f"bench.py: vc_comm_init failed ({ex})", file=sys.stderr)
         self.ndet = [0, 0]
         self.nrows = 0
-        self.kept = []
+        self.kept = [[] for _ in range(n_cam)]
         self.host = None
         self._dev_ptr = {}
 
@@ -166,7 +175,10 @@ class Stream:
 
     def run_async(self, i):
         ptr = self._dev_ptr.pop(i) if self.host is not None else self.batch_ptr(i)
-        self.eng.stream_run_async(self.trackers, ptr, self.B, self.H, self.W)
+        if self.n_cam == 1:
+            self.eng.stream_run_async(self.trackers[0], ptr, self.B, self.H, self.W)
+        else:
+            self.eng.stream_run_async_multi(self.trackers, self.cams, ptr, self.B, self.H, self.W)
 
     def collect(self, i, record):
         rows, fidx, nd = self.eng.stream_collect()
@@ -175,9 +187,13 @@ class Stream:
             self.nrows += len(rows)
             # VideoCounting.run for one batch behind the C ABI (zone filter, per-track rows), on the host while the GPU works on the
             # next batches; the rows are kept so that the Python VideoCounting can check the result after the timed region
-            fr = i * self.B + 1 + fidx
-            self.ncounter.add(fr, rows[:, 4], rows[:, 5], rows[:, :4])
-            self.kept.append((fr, rows))
+            S = self.n_cam
+            g = i * self.B + fidx                                            # position in the interleaved stream: camera g % S, time g // S
+            for c in range(S):
+                sel = slice(None) if S == 1 else (g % S == c)
+                fr, r = g[sel] // S + 1, rows[sel]
+                self.ncounters[c].add(fr, r[:, 4], r[:, 5], r[:, :4])
+                self.kept[c].append((fr, r))
 
     def run_steps(self, first, n, record):
         """Three overlapped stages: detector of batch i+1 (own stream), ReID of batch i (own stream), tracker kernel of batch i
@@ -207,8 +223,8 @@ class Stream:
         t0 = time.perf_counter()
         self.run_steps(first, steps, True)
         t_post = time.perf_counter()
-        table = self.ncounter.table()                                      # save_tracking_to_csv's table: directions, first / last points, every row
-        local_counts = self.ncounter.counts()[None]                        # int32 [1 camera][n_dir][n_cls]
+        tables = [nc.table() for nc in self.ncounters]                      # save_tracking_to_csv's table: directions, first / last points, every row
+        local_counts = np.stack([nc.counts() for nc in self.ncounters])    # int32 [cameras of this rank][n_dir][n_cls]
         try:                                                               # the one collective: ncclAllGather on the engine's stream (C ABI)
             all_counts = parallel.allgather_counts_native(self.eng, local_counts)
             self.gather_via = "vc_allgather_counts (RCCL, C ABI)"
@@ -221,17 +237,19 @@ class Stream:
         gc.enable()
         post_ms = (time.perf_counter() - t_post) * 1e3
         # outside the timed region: the Python VideoCounting + csv_records + count_directions over the same rows must agree
-        for fr, rows in self.kept:
-            self.counter.run(fr.tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]), finalize=False)
-        self.kept = []
-        recs = csv_records(self.counter.run([], [], [], np.zeros((0, 4), np.int64)))
-        dirs = list(self.counter.directions.keys())
-        ref = parallel.counts_to_tensor(count_directions(recs, dirs, NC), dirs, NC)
-        same_rows = len(recs) == len(table["frame_id"]) and all(
-            r["track_id"] == int(table["track_id"][k]) and r["frame_id"] == int(table["frame_id"][k]) and r["direction"] == table["direction"][k]
-            and r["box"] == table["box"][k].tolist() for k, r in enumerate(recs))
-        if not np.array_equal(ref, local_counts[0]) or not same_rows:
-            raise SystemExit("bench.py: vc_counts / vc_counter_rows disagree with VideoCounting + csv_records + count_directions")
+        for c in range(self.n_cam):
+            counter, table = self.counters[c], tables[c]
+            for fr, rows in self.kept[c]:
+                counter.run(fr.tolist(), rows[:, 4].tolist(), rows[:, 5].tolist(), np.ascontiguousarray(rows[:, :4]), finalize=False)
+            self.kept[c] = []
+            recs = csv_records(counter.run([], [], [], np.zeros((0, 4), np.int64)))
+            dirs = list(counter.directions.keys())
+            ref = parallel.counts_to_tensor(count_directions(recs, dirs, NC), dirs, NC)
+            same_rows = len(recs) == len(table["frame_id"]) and all(
+                r["track_id"] == int(table["track_id"][k]) and r["frame_id"] == int(table["frame_id"][k]) and r["direction"] == table["direction"][k]
+                and r["box"] == table["box"][k].tolist() for k, r in enumerate(recs))
+            if not np.array_equal(ref, local_counts[c]) or not same_rows:
+                raise SystemExit("bench.py: vc_counts / vc_counter_rows disagree with VideoCounting + csv_records + count_directions")
         return dt, post_ms, all_counts
 
 
@@ -297,6 +315,16 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
 
 
 def quick_point(wl, rank, local, dev, world, **kw):
+    """quick_point_ with failures reported in the point itself: an extra operating point never takes the headline line down."""
+    try:
+        return quick_point_(wl, rank, local, dev, world, **kw)
+    except Exception as ex:                                                       # loud, in the JSON line
+        print(f"bench.py: extra point failed: {ex}", file=sys.stderr)
+        torch.cuda.empty_cache()
+        return {"error": str(ex)[:300]}
+
+
+def quick_point_(wl, rank, local, dev, world, **kw):
     """Throughput of one extra operating point: a short run of the same pipeline with other stream parameters.  full=True adds the
     point's own `roofline` and per-stage split (same procedure as the headline)."""
     steps, warm = kw.pop("steps", 8), kw.pop("warmup", 2)
@@ -391,6 +419,8 @@ def main():
             # BASELINE.json configs[2] and configs[4], short runs of `--workload m1024-bf16` / `--workload l1280-fp8`
             "m1024_bf16": quick_point(WORKLOADS["m1024-bf16"], rank, local, dev, world, steps=4, warmup=2, full=True),
             "l1280_fp8": quick_point(WORKLOADS["l1280-fp8"], rank, local, dev, world, steps=6, warmup=2, full=True),
+            # BASELINE.json configs[3]'s 8 cameras on ONE GPU: 8 x 16 frames interleaved in every 128-frame batch (vc_stream_run_async_multi)
+            "s640_8cam_one_gpu": quick_point(wl, rank, local, dev, world, n_cam=8, clip=512, steps=12, warmup=3, full=True),
         }
         hp = quick_point(wl, rank, local, dev, world, host=True, steps=12, warmup=3)
         out["value_host_frames"] = hp["value"]

@@ -12,7 +12,8 @@ names = {0: "full", 1: "no transcendentals", 2: "no stem MFMAs", 3: "no trans + 
          48: "patch staging only", 64: "no patch writes", 17: "conv phase, no trans", 33: "stem phase, no trans", 35: "stem phase, no trans, no MFMA", 39: "stem: no trans/MFMA/LDS store"}
 for _ in range(2):
     eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync(); eng.stream_reset()
-for abl in (0, 1, 2, 3, 4, 8, 16, 32, 48, 64, 17, 33, 35, 39, 0):
+names.update({128: "no global fetch", 192: "no fetch, no patch writes", 256: "no patch LDS reads (stem)", 257: "no patch reads, no trans", 384: "no fetch, no patch reads"})
+for abl in (0, 128, 192, 256, 257, 384, 1, 16, 32, 0):
     os.environ["VC_FF_ABLATE"] = str(abl)
     eng.profile(True); eng.profile_reset()
     eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync()

@@ -52,12 +52,13 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
                                                              int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl) {
     // abl (VC_FF_ABLATE, diagnostics with WRONG results; 0 in production): 1 no transcendentals, 2 no stem MFMAs, 4 no stem LDS stores,
-    // 8 no output stores, 16 no stem phase, 32 no conv phase, 64 no patch writes
+    // 8 no output stores, 16 no stem phase, 32 no conv phase, 64 no patch writes, 128 no global fetch, 256 no patch reads in the stem
     __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
     __shared__ uint4 l0t[FF_NT0 * 16 * 4];                 // 72.7 KB: [pixel slot][4 chunks], swizzled
     __shared__ uint4 w1s[9 * 4 * 64];                      // 36.9 KB: layer-1 weights, [tap][channel tile][lane] = one fragment load per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
+    const size_t src_bytes = U8 ? (size_t)B * g.src_h * g.src_w * 3 : 0;
     // weights in registers for the whole launch
     ChunkF wf0[5][2];
 #pragma unroll
@@ -95,15 +96,26 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
             const int pr = i / FF_PC, pc = i - pr * FF_PC;
             const int iy = 2 * gy0 - 2 + pr, ip = gx0 - 1 + pc;
             pre[k] = make_uint4(0u, 0u, 0u, 0u);                            // .w = 0: outside the network input (zero padding)
-            if (i < FF_PR * FF_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
+            if (i < FF_PR * FF_PC && iy >= 0 && iy < H && ip >= 0 && ip < Wp && !(abl & 128)) {
                 if constexpr (!U8) {
                     pre[k] = x[((size_t)b * H + iy) * Wp + ip];
                 } else {
                     const int uy = iy - g.top, ux = 2 * ip - g.left;
                     pre[k].w = 1u;                                          // inside the input, letterbox padding (114) unless the bytes say otherwise
                     if (uy >= 0 && uy < g.unpad_h && ux >= 0 && ux + 1 < g.unpad_w) {
-                        const uint16_t* q = (const uint16_t*)(src8 + (((size_t)b * g.src_h + uy) * g.src_w + ux) * 3);
-                        pre[k].x = q[0]; pre[k].y = q[1]; pre[k].z = q[2]; pre[k].w = 2u;
+                        // the pixel pair's six bytes with ONE 8-byte load (2-byte aligned: gfx950 runs global memory in unaligned-access mode
+                        // and hipcc emits global_load_dwordx2) instead of three 16-bit loads; only the very last pair of the buffer, whose
+                        // two extra bytes would lie past its end, takes the 16-bit form
+                        const size_t off = (((size_t)b * g.src_h + uy) * g.src_w + ux) * 3;
+                        typedef unsigned long long u64a2 __attribute__((aligned(2)));
+                        if (off + 8 <= src_bytes) {
+                            const unsigned long long v = *(const u64a2*)(src8 + off);
+                            pre[k].x = (uint32_t)v & 0xffffu; pre[k].y = (uint32_t)(v >> 16) & 0xffffu; pre[k].z = (uint32_t)(v >> 32) & 0xffffu;
+                        } else {
+                            const uint16_t* q = (const uint16_t*)(src8 + off);
+                            pre[k].x = q[0]; pre[k].y = q[1]; pre[k].z = q[2];
+                        }
+                        pre[k].w = 2u;
                     }
                 }
             }
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
             for (int s = 0; s < 5; ++s) {
                 ChunkF xf[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xf[q].u = patch[(2 * ly[q]) * FF_PP + lx[q] + koff[s]];
+                for (int q = 0; q < 2; ++q) xf[q].u = (abl & 256) ? make_uint4(ly[q], lx[q], s, q) : patch[(2 * ly[q]) * FF_PP + lx[q] + koff[s]];
                 if (abl & 2) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { acc[0][q][0] += __uint_as_float(xf[q].u.x); acc[1][q][1] += __uint_as_float(xf[q].u.w); }

@@ -140,6 +140,7 @@ struct TrackBatchArgs {
     int frame_w, frame_h;
     int all_tables;                  // host-side bound: every tracker's appearance table fits the arena (lean kernel instance)
     int dbg_costs;                   // 1: keep the cost rows in the global scratch (vc_tracker_debug_costs reads them back)
+    int no_reg;                      // diagnostics (VC_TRACK_NO_REG): steps of <= 64 x 64 take the LDS-list matching path as well
     long long* dbg;                  // diagnostics (VC_TRACK_DBG): per task 8 timestamps (100 MHz): start, predict, cost rows, match, apply, finish
 };
 size_t track_scratch_per_wg();

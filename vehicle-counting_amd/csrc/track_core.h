@@ -636,7 +636,8 @@ __device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, c
                                                 (short*)w.small_t, w.ri);
         wave_sync();
         const int key = lane < n_ua ? w.ri[lane] : 0;
-        const bool rec = lane < n_ua && __shfl(tsu, key) == 1;
+        const int tsu_of_key = __shfl(tsu, key);             // every lane takes part: a shuffle reads nothing from a lane that is masked off
+        const bool rec = lane < n_ua && tsu_of_key == 1;
         const unsigned long long recm = __ballot(rec);
         const int rows_u = lane_push(is_u ? __popcll(um & lt) : 63, lane);
         const int rows_r = lane_push(rec ? n_unconf + __popcll(recm & lt) : (n_unconf > 0 ? 0 : 63), key);
@@ -671,9 +672,10 @@ VC_HD long long tc_clock() {
 }
 
 VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, int D, const double* cost_app, const double* cost_iou,
-                      double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err, long long* prof = nullptr) {
+                      double* cbuf, double* tbuf, int& n_match, int& n_un, int*& newdets, int& n_new, int& err, long long* prof = nullptr,
+                      bool allow_reg = true) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (T <= 64 && D <= 64) { match_step_wave64(L.lane, w, h, T, D, cost_app, cost_iou, n_match, n_un, newdets, n_new, err, prof); return; }
+    if (allow_reg && T <= 64 && D <= 64) { match_step_wave64(L.lane, w, h, T, D, cost_app, cost_iou, n_match, n_un, newdets, n_new, err, prof); return; }
 #endif
     if (prof && L.lane == 0) prof[0] = tc_clock();
     const int n_conf = compact(L, T, [&](int t) { return w.state[t] == CONFIRMED; }, [&](int pos, int t) { w.confirmed[pos] = t; });

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
         if (wave == 0) {
             int n_match = 0, n_un = 0, n_new = 0, err = TERR_NONE;
             int* newdets = nullptr;
-            match_step(L, w, *hdr, T, D, cost_app, cost_iou, cbuf, tbuf, n_match, n_un, newdets, n_new, err, a.dbg ? a.dbg + (size_t)task * 16 + 8 : nullptr);
+            match_step(L, w, *hdr, T, D, cost_app, cost_iou, cbuf, tbuf, n_match, n_un, newdets, n_new, err, a.dbg ? a.dbg + (size_t)task * 16 + 8 : nullptr, a.no_reg == 0);
             if (err == TERR_NONE && n_new > 0 && !pool_take(a, n_new, w.newslot, lane)) err = TERR_POOL;
             if (lane == 0) { sh.ctl[0] = n_match; sh.ctl[1] = n_un; sh.ctl[2] = n_new; sh.ctl[3] = newdets == w.left ? 1 : 0; sh.ctl[4] = err; }
         }

@@ -305,6 +305,8 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
     a.scratch = e->d_track_scratch; a.scratch_per_wg = track_scratch_per_wg(); a.cap = cap; a.frame_w = W; a.frame_h = H;
     a.all_tables = tables_fit ? 1 : 0;
+    static const bool no_reg = getenv("VC_TRACK_NO_REG") != nullptr;
+    a.no_reg = no_reg ? 1 : 0;
     a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back
     static const bool dbg_on = getenv("VC_TRACK_DBG") != nullptr;        // diagnostics: phase times of every task, printed per batch
     long long* dbg = nullptr;

@@ -16,7 +16,7 @@ class Engine:
 
     def __init__(self, yolo_sd=None, reid_sd=None, *, device=0, precision="bf16", model_name="yolov5s", num_classes=80,
                  img_size=640, max_batch=16, max_frame_hw=(720, 1280), conf_thres=0.25, iou_thres=0.45, max_det=300,
-                 max_candidates=4096, max_crops=1024, max_tracks=4096, nn_budget_cap=100):
+                 max_candidates=4096, max_crops=1024, max_tracks=4096, nn_budget_cap=100, max_trackers=256):
         lib = L.lib()
         cfg = L.EngineConfig()
         L.check(lib.vc_engine_config_default(C.byref(cfg)))
@@ -27,6 +27,7 @@ class Engine:
         cfg.max_frame_h, cfg.max_frame_w = max_frame_hw
         cfg.conf_thres, cfg.iou_thres, cfg.max_det, cfg.max_candidates = conf_thres, iou_thres, max_det, max_candidates
         cfg.max_crops, cfg.max_tracks, cfg.nn_budget_cap = max_crops, max_tracks, nn_budget_cap
+        cfg.max_trackers = max_trackers
         cfg.with_detector = 1 if yolo_sd is not None else 0
         cfg.with_reid = 1 if reid_sd is not None else 0
         self.cfg = cfg
