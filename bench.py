@@ -119,7 +119,7 @@ class Stream:
         clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
         self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
-        per_frame = max(64 if n_cam == 1 else 192, 2 * max(inject, n_obj))     # other cameras' clips draw more boxes from the random head than the rank-0 clip
+        per_frame = max(64, 2 * max(inject, n_obj))
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
                             img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=self.B * per_frame,
                             max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096,
@@ -134,7 +134,10 @@ class Stream:
         self.n_cam = n_cam
         assert self.B % n_cam == 0 and clip % n_cam == 0
         self.trackers = [[self.eng.tracker_create(**TRACK) for _ in range(NC)] for _ in range(n_cam)]
-        per_cam = [synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank + 97 * c, bounce=True) for c in range(n_cam)]
+        # every camera shows the rank's clip (same content, independent trackers): the point stays comparable with the single-camera
+        # headline -- other seeds draw 4 x more boxes from the random head
+        one = synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True)
+        per_cam = [one] * n_cam
         self.frames = per_cam[0] if n_cam == 1 else np.stack(per_cam, 1).reshape((clip,) + per_cam[0].shape[1:])     # frame j: camera j % S, time j // S
         self.cams = np.tile(np.arange(n_cam, dtype=np.int32), self.B // n_cam)
         self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region

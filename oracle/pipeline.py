@@ -14,14 +14,16 @@ from . import yolov5 as oy
 
 
 def run_video(frames_bgr, yolo_sd, reid_sd, tracking_config, zone_path, variant="yolov5s", nc=80, conf=0.25, iou=0.45,
-              max_det=300, timings=None, size=640):
-    embed = orr.make_embedder(reid_sd)
+              max_det=300, timings=None, size=640, bf16=False):
+    """bf16=True: detector and ReID net restated in the product's benchmarked precision (oracle/yolov5.py::forward, oracle/reid.py::
+    reid_forward_bf16); everything downstream (NMS, DeepSORT, counting) is unchanged."""
+    embed = orr.make_embedder(reid_sd, bf16=bf16)
     tracker = od.VideoTrackerOracle(nc, tracking_config, embed)
     polygon, dirs = oc.load_zone(zone_path)
     obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
     n_det = []
     for i, f in enumerate(frames_bgr):
-        det = oy.autoshape_detect(yolo_sd, [f[:, :, ::-1]], variant, nc, size, conf, iou, None, max_det)[0]
+        det = oy.autoshape_detect(yolo_sd, [f[:, :, ::-1]], variant, nc, size, conf, iou, None, max_det, bf16=bf16)[0]
         m = oy.marshal_like_reference(det)
         n_det.append(len(m["bboxes"]))
         if len(m["bboxes"]) == 0:

@@ -30,6 +30,38 @@ def _bn(x, sd, p):
                         training=False, eps=BN_EPS)
 
 
+def _fold(w, b, sd, p):
+    """Conv + eval-mode BatchNorm as one conv (float32), for the bf16 restatement below."""
+    scale = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + BN_EPS)
+    b0 = torch.zeros(w.shape[0]) if b is None else b
+    return w * scale[:, None, None, None], (b0 - sd[p + ".running_mean"]) * scale + sd[p + ".bias"]
+
+
+def reid_forward_bf16(sd, x):
+    """The same network in the product's VC_PREC_BF16 arithmetic: BatchNorm folded into the convs in float32, folded weights, the
+    input and every activation rounded to bfloat16 once, fp32 accumulate + bias (+ shortcut) + ReLU before the rounding, pooling and
+    the L2 norm in float32.  Not what the reference computes -- what a bf16 implementation of it has to compute."""
+    r = lambda t: t.bfloat16().float()
+    x = r(torch.as_tensor(x, dtype=torch.float32))
+    with torch.no_grad():
+        w, b = _fold(sd["conv.0.weight"], sd["conv.0.bias"], sd, "conv.1")
+        y = r(F.relu(F.conv2d(x, r(w), b, stride=1, padding=1)))
+        y = F.max_pool2d(y, 3, 2, padding=1)
+        for name, cin, cout, down in BLOCKS:
+            s = 2 if down else 1
+            w, b = _fold(sd[name + ".conv1.weight"], None, sd, name + ".bn1")
+            z = r(F.relu(F.conv2d(y, r(w), b, stride=s, padding=1)))
+            if down or cin != cout:
+                w, b = _fold(sd[name + ".downsample.0.weight"], None, sd, name + ".downsample.1")
+                y = r(F.conv2d(y, r(w), b, stride=s))
+            w, b = _fold(sd[name + ".conv2.weight"], None, sd, name + ".bn2")
+            y = r(F.relu(F.conv2d(z, r(w), b, stride=1, padding=1) + y))
+        y = F.avg_pool2d(y, (4, 4), 1)
+        y = y.view(y.size(0), -1)
+        y = y / y.norm(p=2, dim=1, keepdim=True)
+    return y.numpy()
+
+
 def reid_forward(sd, x):
     """x: (k,3,50,50) f32 -> (k,512) unit-norm f32.  model.py:83-98."""
     x = torch.as_tensor(x, dtype=torch.float32)
@@ -64,9 +96,9 @@ def preprocess_crops(crops):
     return out
 
 
-def make_embedder(sd):
+def make_embedder(sd, bf16=False):
     sd = {k: torch.as_tensor(v) for k, v in sd.items()}
 
     def embed(crops):
-        return reid_forward(sd, preprocess_crops(crops))
+        return (reid_forward_bf16 if bf16 else reid_forward)(sd, preprocess_crops(crops))
     return embed

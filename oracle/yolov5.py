@@ -100,37 +100,52 @@ def conv_specs(variant="yolov5s", nc=80):
     return out
 
 
-def _cba(x, sd, name, s, p):
-    """Conv (BN already folded into weight/bias) + SiLU; models/common.py::Conv.forward_fuse."""
-    return F.silu(F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=s, padding=p))
+def _r16(t):
+    """Round to bfloat16 (nearest even) and back: what one bf16 store + load does to an fp32 value."""
+    return t.bfloat16().float()
 
 
-def _c3(x, sd, p, rep, shortcut):
-    y = _cba(x, sd, p + ".cv1.conv", 1, 0)
+def _cba(x, sd, name, s, p, res=None, bf16=False):
+    """Conv (BN already folded into weight/bias) + SiLU; models/common.py::Conv.forward_fuse.  `res`: a Bottleneck's shortcut, added
+    after the activation.  bf16=True restates the arithmetic of the product's VC_PREC_BF16 mode: bf16 operands (the caller hands in
+    rounded activations and weights), fp32 accumulate + bias + SiLU (+ shortcut), ONE rounding to bf16 on store."""
+    y = F.silu(F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=s, padding=p))
+    if res is not None:
+        y = y + res
+    return _r16(y) if bf16 else y
+
+
+def _c3(x, sd, p, rep, shortcut, bf16=False):
+    y = _cba(x, sd, p + ".cv1.conv", 1, 0, bf16=bf16)
     for j in range(rep):
-        z = _cba(_cba(y, sd, f"{p}.m.{j}.cv1.conv", 1, 0), sd, f"{p}.m.{j}.cv2.conv", 1, 1)
-        y = y + z if shortcut else z
-    return _cba(torch.cat((y, _cba(x, sd, p + ".cv2.conv", 1, 0)), 1), sd, p + ".cv3.conv", 1, 0)
+        y = _cba(_cba(y, sd, f"{p}.m.{j}.cv1.conv", 1, 0, bf16=bf16), sd, f"{p}.m.{j}.cv2.conv", 1, 1, res=y if shortcut else None, bf16=bf16)
+    return _cba(torch.cat((y, _cba(x, sd, p + ".cv2.conv", 1, 0, bf16=bf16)), 1), sd, p + ".cv3.conv", 1, 0, bf16=bf16)
 
 
-def forward(sd, x, variant="yolov5s", nc=80, return_layers=False):
-    """x: (B,3,H,W) f32 in [0,1] -> (B, n_candidates, 5+nc) decoded predictions (Detect inference output)."""
+def forward(sd, x, variant="yolov5s", nc=80, return_layers=False, bf16=False):
+    """x: (B,3,H,W) f32 in [0,1] -> (B, n_candidates, 5+nc) decoded predictions (Detect inference output).
+    bf16=True: a restatement of the SAME network in the product's benchmarked precision (every weight, the input and every
+    activation -- Detect logits included -- rounded to bfloat16 once, fp32 accumulation): not what the reference computes, but what
+    a bf16 implementation of it has to compute, so that the HIP bf16 path can be held to a tight tolerance (accumulation order only)."""
     sd = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in sd.items()}
     x = torch.as_tensor(x, dtype=torch.float32)
+    if bf16:
+        sd = {k: (_r16(v) if k.endswith(".weight") else v) for k, v in sd.items()}
+        x = _r16(x)
     ys = []
     no = nc + 5
     with torch.no_grad():
         for idx, kind, frm, a in build_graph(variant):
             p = f"model.{idx}"
             if kind == "conv":
-                x = _cba(x, sd, p + ".conv", a[3], a[4])
+                x = _cba(x, sd, p + ".conv", a[3], a[4], bf16=bf16)
             elif kind == "c3":
-                x = _c3(x, sd, p, a[2], a[3])
+                x = _c3(x, sd, p, a[2], a[3], bf16=bf16)
             elif kind == "sppf":
-                x = _cba(x, sd, p + ".cv1.conv", 1, 0)
+                x = _cba(x, sd, p + ".cv1.conv", 1, 0, bf16=bf16)
                 y1 = F.max_pool2d(x, 5, 1, 2)
                 y2 = F.max_pool2d(y1, 5, 1, 2)
-                x = _cba(torch.cat((x, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1), sd, p + ".cv2.conv", 1, 0)
+                x = _cba(torch.cat((x, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1), sd, p + ".cv2.conv", 1, 0, bf16=bf16)
             elif kind == "up":
                 x = F.interpolate(x, scale_factor=2.0, mode="nearest")
             elif kind == "cat":
@@ -140,6 +155,8 @@ def forward(sd, x, variant="yolov5s", nc=80, return_layers=False):
                 raw = []
                 for i, src in enumerate(frm):
                     t = F.conv2d(ys[src], sd[f"{p}.m.{i}.weight"], sd[f"{p}.m.{i}.bias"])
+                    if bf16:
+                        t = _r16(t)
                     raw.append(t)
                     bs, _, ny, nx = t.shape
                     t = t.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
@@ -240,10 +257,10 @@ def preprocess(imgs_rgb, size=640):
 
 
 def autoshape_detect(sd, imgs_rgb, variant="yolov5s", nc=80, size=640, conf=0.25, iou=0.45, classes=None,
-                     max_det=300):
+                     max_det=300, bf16=False):
     """AutoShape.forward end to end: list of HxWx3 uint8 RGB -> list of (m,6) float32 xyxy in source pixels."""
     x, shape0, shape1 = preprocess(imgs_rgb, size)
-    pred = forward(sd, x, variant, nc).numpy()
+    pred = forward(sd, x, variant, nc, bf16=bf16).numpy()
     dets = non_max_suppression(pred, conf, iou, classes, max_det)
     return [np.concatenate((scale_coords(shape1, d[:, :4], s0), d[:, 4:]), 1) if len(d) else d
             for d, s0 in zip(dets, shape0)]

@@ -180,9 +180,11 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     for (int k = 0; k < n_tasks; ++k) s.dev_index[order[k]] = k;
     std::vector<TrackWgPlan> plans;
     int need = 8, n_dets = 0;
-    // Do the appearance tables of ALL trackers fit the arena for certain?  Bound from what the host knows: a tracker holds at most
-    // known_tracks (last collected batch) + pending_dets (detections of batches still in flight) tracks at the start of this batch,
-    // each with a full gallery.  Then the lean kernel instance (no fallback code, 8 waves) runs.
+    // Do the appearance tables of ALL trackers fit the arena for certain?  Bound from what the host knows: the tracks of the last
+    // collected batch (known_tracks) hold at most a full gallery each, and every detection of a batch still in flight (pending_dets)
+    // adds at most ONE gallery row -- it either extends one track's ring or starts a track with a single sample (tracker.py:82-91,
+    // 133-139).  (Round 2 charged a full gallery per pending detection: at 256 detections per frame that bound was 1.3 GB per tracker,
+    // nothing "fitted", and the batch ran on the fallback instance.)  Then the lean kernel instance (no fallback code, 8 waves) runs.
     long long table_floats = 0, table_rows = 0;
     bool all_tables = true;
     for (int k = 0; k < n_tasks;) {
@@ -198,7 +200,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         plans.push_back(TrackWgPlan{tr, k, k1, det_begin, dets, 0, 0, 0});
         {
             const Tracker& tk = *e->trackers[tr];
-            const long long old_rows = (long long)(tk.known_tracks + tk.pending_dets) * std::min(e->pool.budget_cap, tk.p.nn_budget);
+            const long long old_rows = (long long)tk.known_tracks * std::min(e->pool.budget_cap, tk.p.nn_budget) + tk.pending_dets;
             const long long need_f = (old_rows + dets) * dets;
             if (need_f >= (1ll << 31)) all_tables = false;
             table_floats += need_f; table_rows += old_rows;
