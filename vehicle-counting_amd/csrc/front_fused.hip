@@ -36,6 +36,8 @@ union ChunkF { uint4 u; bf16x8f h; };
 #define FF_PR (2 * FF_RH + 4)     // input patch rows (70)
 #define FF_PC (2 * FF_TW + 1 + 2) // input patch pixel pairs per row (35)
 #define FF_PP 36                  // LDS row pitch of the patch in 16-byte chunks
+#define FF_RAWC 15                // U8: 16-byte chunks of one raw source row of the patch (35 pixel pairs x 6 B = 210 B + up to 15 B of alignment slack)
+#define FF_RAWP (FF_RAWC * 16)    // byte pitch of a raw row in LDS
 
 typedef float f32x2f __attribute__((ext_vector_type(2)));
 // SiLU of two values: the multiplies and the add as packed fp32 operations (same IEEE results as the scalar forms)
@@ -86,6 +88,36 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
     // (three 16-bit loads per pixel pair) and the conversion (pad 114, R/B swap, exact /255, RNE to bf16) happens when the patch is
     // written to LDS one tile later -- converting at fetch time would make every wave wait for its loads right there.
     uint4 pre[NPRE];
+    // U8: the patch's source rows are fetched as ALIGNED 16-byte chunks (70 rows x 15 chunks = 1 050 loads per tile, two or three per
+    // thread) instead of three 16-bit loads per pixel pair (7 350 per tile): the 2-byte-granular loads occupied the texture-address
+    // unit for ~1 lane per cycle and were the largest single item of the kernel (tools/ff_ablate.py: no fetch = -0.17 of 0.67 ms).
+    // The raw bytes wait in registers during the tile's compute like `pre` did, go to a raw staging area in LDS at the top of the next
+    // tile (aliased with the layer-0 tile, which is dead between a tile's conv phase and the next tile's stem phase) and are converted
+    // from there.  Out-of-buffer chunks (before the first / after the last frame) are buffer loads past num_records: zeros.
+    constexpr int NRAW = (FF_PR * FF_RAWC + NT - 1) / NT;   // 3
+    uint4 praw[NRAW];
+    const __amdgpu_buffer_rsrc_t s8rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, U8 ? (int)((size_t)B * g.src_h * g.src_w * 3) : 0, 0x00020000);
+    auto row_start = [&](int b, int gy0, int gx0, int pr, bool& valid) -> long long {       // byte offset of the source pixel under the patch row's first pixel
+        const int uy = 2 * gy0 - 2 + pr - g.top;
+        valid = uy >= 0 && uy < g.unpad_h;
+        return (((long long)b * g.src_h + uy) * g.src_w + (2 * (gx0 - 1) - g.left)) * 3;
+    };
+    auto fetch_raw = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int gy0 = 2 * ty * FF_TH - 1, gx0 = 2 * tx * FF_TW - 1;
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            const int c = threadIdx.x + k * NT;
+            const int pr = c / FF_RAWC, j = c - pr * FF_RAWC;
+            bool valid;
+            const long long rs = row_start(b, gy0, gx0, pr, valid);
+            const long long off = ((rs >> 4) << 4) + 16 * j;                       // floor to 16 bytes (arithmetic shift: also for rs < 0)
+            typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+            u32x4r v = {0u, 0u, 0u, 0u};
+            if (c < FF_PR * FF_RAWC && valid && !(abl & 128)) v = __builtin_amdgcn_raw_buffer_load_b128(s8rd, (int)off, 0, 0);
+            praw[k] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
     auto fetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int gy0 = 2 * ty * FF_TH - 1, gx0 = 2 * tx * FF_TW - 1;          // first layer-0 row / column of the region
@@ -129,7 +161,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
     typedef __bf16 bf16x2f __attribute__((ext_vector_type(2)));
     const bool odd = (kq & 1) != 0;
     char* l0b = (char*)l0t;
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    if ((int)blockIdx.x < ntiles) { if constexpr (U8) fetch_raw(blockIdx.x); else fetch(blockIdx.x); }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int oy0 = ty * FF_TH, ox0 = tx * FF_TW;
@@ -137,14 +169,44 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
         if (dbg) ts0 = wall_clock64();
         __syncthreads();                                    // the previous tile's LDS reads are done
+        if constexpr (U8) {
+            char* rawb = (char*)l0t;                        // raw source rows: [FF_PR][FF_RAWP] bytes in the (dead) layer-0 tile
 #pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = threadIdx.x + k * NT;
-            if (i < FF_PR * FF_PC && !(abl & 64)) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = patch_chunk(pre[k]); }
+            for (int k = 0; k < NRAW; ++k) {
+                const int c = threadIdx.x + k * NT;
+                if (c < FF_PR * FF_RAWC) *(uint4*)(rawb + c * 16) = praw[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = threadIdx.x + k * NT;
+                if (i < FF_PR * FF_PC && !(abl & 64)) {
+                    const int pr = i / FF_PC, pc = i - pr * FF_PC;
+                    const int iy = 2 * gy0 - 2 + pr, ip = gx0 - 1 + pc;
+                    uint4 r = make_uint4(0u, 0u, 0u, 0u);                        // .w = 0: outside the network input (zero padding)
+                    if (iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
+                        const int ux = 2 * ip - g.left;
+                        bool valid;
+                        const long long rs = row_start(b, gy0, gx0, pr, valid);
+                        r.w = 1u;                                                // inside the input: letterbox padding (114) unless the bytes say otherwise
+                        if (valid && ux >= 0 && ux + 1 < g.unpad_w) {
+                            const uint16_t* q = (const uint16_t*)(rawb + pr * FF_RAWP + (int)(rs - ((rs >> 4) << 4)) + 6 * pc);
+                            r.x = q[0]; r.y = q[1]; r.z = q[2]; r.w = 2u;
+                        }
+                    }
+                    patch[pr * FF_PP + pc] = patch_chunk(r);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = threadIdx.x + k * NT;
+                if (i < FF_PR * FF_PC && !(abl & 64)) { const int pr = i / FF_PC; patch[pr * FF_PP + (i - pr * FF_PC)] = patch_chunk(pre[k]); }
+            }
         }
         __syncthreads();
         if (dbg) ts1 = wall_clock64();
-        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        if (t + (int)gridDim.x < ntiles) { if constexpr (U8) fetch_raw(t + gridDim.x); else fetch(t + gridDim.x); }
         // ---- layer 0 on the region.  Pixel tiles are ROW-ALIGNED so that a tile's coordinates cost no division: tile r < 33 = row r,
         // even columns 0 .. 30; tile 33 + r = row r, odd columns 1 .. 31; tiles 66 .. 68 = the 33 pixels of column 32, one row per lane.
         // LDS slot of a pixel: plane (column parity) * 561 + row * 17 + column / 2, as before. ------------------------------------------
