@@ -21,3 +21,15 @@ for abl in (0, 128, 192, 256, 257, 384, 1, 16, 32, 0):
     eng.profile(False)
     eng.stream_reset()
     print(f"abl {abl:3d} {names.get(abl, ''):32s} {l[0].split('ms=')[1].split()[0] if l else '?'} ms", flush=True)
+
+os.environ.pop("VC_FF_ABLATE", None)
+cn = {0: "full", 1: "no transcendentals", 2: "no global fetch", 4: "no output stores", 8: "no 3x3 pass", 16: "no cv12 pass", 32: "no m.cv1 pass", 64: "no cv3 pass",
+      6: "no fetch, no stores", 120: "staging only (no passes)", 7: "no trans/fetch/stores"}
+for abl in (0, 1, 2, 4, 6, 8, 16, 32, 64, 120, 7, 0):
+    os.environ["VC_C3_ABLATE"] = str(abl)
+    eng.profile(True); eng.profile_reset()
+    eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync()
+    l = [x for x in eng.profile_ops().strip().split("\n") if "cfg=103" in x]
+    eng.profile(False)
+    eng.stream_reset()
+    print(f"c3 abl {abl:3d} {cn.get(abl, ''):32s} {l[0].split('ms=')[1].split()[0] if l else '?'} ms", flush=True)

@@ -45,9 +45,11 @@ __device__ __forceinline__ f32x2c c3_silu2(f32x2c x) {
     return x * (f32x2c){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 // bias + SiLU on the four accumulator values of a lane -> 4 bf16 (8 bytes)
+template <bool NOTRANS = false>
 __device__ __forceinline__ uint2 c3_act4(const f32x4c& a, const float4& b) {
-    const f32x2c lo = c3_silu2((f32x2c){a[0], a[1]} + (f32x2c){b.x, b.y});
-    const f32x2c hi = c3_silu2((f32x2c){a[2], a[3]} + (f32x2c){b.z, b.w});
+    f32x2c lo = (f32x2c){a[0], a[1]} + (f32x2c){b.x, b.y};
+    f32x2c hi = (f32x2c){a[2], a[3]} + (f32x2c){b.z, b.w};
+    if constexpr (!NOTRANS) { lo = c3_silu2(lo); hi = c3_silu2(hi); }
     const bf16x2c p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
     return make_uint2(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1));
 }
@@ -59,9 +61,12 @@ struct C3Args {
     const uint16_t* x; int in_cs, in_co;
     uint16_t* y; int out_cs, out_co;
     int B, H, W, tiles_x, tiles_y;
-};
+    int abl;                               // diagnostics (VC_C3_ABLATE, wrong results): 1 no transcendentals, 2 no global fetch, 4 no output stores,
+};                                         // 8 no 3x3 pass, 16 no cv12 pass, 32 no m.cv1 pass, 64 no cv3 pass
 
+template <bool DIAG>
 __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a) {
+    const int abl = DIAG ? a.abl : 0;
     __shared__ uint4 xa[2 * C3_NP * 4];                    // 24 KB: x planes [k step][pixel slot][4 chunks]; plane 0 becomes b1
     __shared__ uint4 yb[C3_NP * 4];                        // 12 KB: y1 on the halo region, m in place on the interior
     __shared__ uint4 yc[C3_TH * C3_TW * 4];                // 8 KB: y2 on the interior
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) { bm1[ct] = *(const float4*)(a.bm1 + ct * 16 + kq * 4); bm2[ct] = *(const float4*)(a.bm2 + ct * 16 + kq * 4); }
 
+    auto act4 = [&](const f32x4c& v, const float4& bb) -> uint2 { if (DIAG && (abl & 1)) return c3_act4<true>(v, bb); return c3_act4<false>(v, bb); };
     const int ntiles = a.B * a.tiles_y * a.tiles_x;
     constexpr int NPRE = (C3_NH * 8 + NT - 1) / NT;        // 6 chunks of the x halo tile per thread
     uint4 pre[NPRE];
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
             const int ry = (n * 3641) >> 16, rx = n - ry * C3_RW;             // n / 18 for n < 192
             const int gy = y0 + ry, gx = x0 + rx;
             pre[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (n < C3_NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            if (n < C3_NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && !(abl & 2))
                 pre[k] = *(const uint4*)(a.x + (((size_t)b * a.H + gy) * a.W + gx) * a.in_cs + a.in_co + c * 8);
         }
     };
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);                // in flight during the four passes
 
         // ---- cv1 | cv2 on the halo region: y1 -> yb (all of it), y2 -> yc (interior pixels only) ------------------------------------
-        for (int pt = wave; pt < C3_NT; pt += C3_NW) {
+        for (int pt = wave; pt < C3_NT && !(abl & 16); pt += C3_NW) {
             const int n = pt * 16 + col;
             ChunkC x0f, x1f;
             x0f.u = *(const uint4*)(xab + c3_addr(n, kq));
@@ -143,15 +149,15 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
             const int q = (ry - 1) * C3_TW + (rx - 1);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                const uint2 v1 = c3_act4(acc[ct], b12[ct]);
+                const uint2 v1 = act4(acc[ct], b12[ct]);
                 if (n < C3_NH) *(uint2*)(ybb + c3_addr(n, ct * 2 + (kq >> 1)) + (kq & 1) * 8) = v1;
-                const uint2 v2 = c3_act4(acc[2 + ct], b12[2 + ct]);
+                const uint2 v2 = act4(acc[2 + ct], b12[2 + ct]);
                 if (interior) *(uint2*)(ycb + c3_addr(q, ct * 2 + (kq >> 1)) + (kq & 1) * 8) = v2;
             }
         }
         __syncthreads();
         // ---- m.cv1 on the halo region: b1 -> plane 0 of region A; pixels outside the image hold 0 (the 3x3 pads b1 with zeros) --------
-        for (int pt = wave; pt < C3_NT; pt += C3_NW) {
+        for (int pt = wave; pt < C3_NT && !(abl & 32); pt += C3_NW) {
             const int n = pt * 16 + col;
             ChunkC yf;
             yf.u = *(const uint4*)(ybb + c3_addr(n, kq));
@@ -163,14 +169,14 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
                 ChunkC w;
                 w.u = wm1s[ct * 64 + lane];
                 const f32x4c acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, yf.h, (f32x4c){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                uint2 v = c3_act4(acc, bm1[ct]);
+                uint2 v = act4(acc, bm1[ct]);
                 if (!inimg) v = make_uint2(0u, 0u);
                 if (n < C3_NH) *(uint2*)(xab + c3_addr(n, ct * 2 + (kq >> 1)) + (kq & 1) * 8) = v;
             }
         }
         __syncthreads();
         // ---- m.cv2 (3x3) on the interior + shortcut: wave w owns rows 2w, 2w + 1; m overwrites y1 in place -----------------------------
-        {
+        if (!(abl & 8)) {
             f32x4c acc[2][2];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
         }
         __syncthreads();
         // ---- cv3 on [m | y2]: rows 2w, 2w + 1, all 64 channels -> HBM ---------------------------------------------------------------------
-        {
+        if (!(abl & 64)) {
             f32x4c acc[4][2];
             ChunkC mf[2], yf[2];
 #pragma unroll
@@ -234,13 +240,13 @@ __global__ __launch_bounds__(C3_NW * 64, 2) void c3_fused_kernel(const C3Args a)
             }
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const uint2 P0 = c3_act4(acc[ct][0], b3[ct]), P1 = c3_act4(acc[ct][1], b3[ct]);
+                const uint2 P0 = act4(acc[ct][0], b3[ct]), P1 = act4(acc[ct][1], b3[ct]);
                 // lane pairs (lane, lane ^ 16) swap halves across the two rows: 16 bytes = 8 channels of ONE pixel (conv_epilogue_bf16)
                 const u32x2c sx = __builtin_amdgcn_permlane16_swap(P0.x, P1.x, false, false);
                 const u32x2c sy = __builtin_amdgcn_permlane16_swap(P0.y, P1.y, false, false);
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
                 const int oy = oy0 + wave * 2 + (odd ? 1 : 0), ox = ox0 + col;
-                if (oy < a.H && ox < a.W)
+                if (oy < a.H && ox < a.W && !(abl & 4))
                     *(uint4*)(a.y + (((size_t)b * a.H + oy) * a.W + ox) * a.out_cs + a.out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
         }
@@ -279,12 +285,14 @@ int launch_c3_fused(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, const 
         int per_cu = 2, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c3_fused_kernel, C3_NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c3_fused_kernel<false>, C3_NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         return per_cu * cus;
     }();
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     const int grid = std::min(ntiles, std::max(256, slots_hw - slots_reserve / 2));   // persistent; two workgroups per CU: half the usual number of slots stays free
-    launch_timed(p12, c3_fused_kernel, dim3(grid), dim3(C3_NW * 64), 0, s, a);
+    a.abl = getenv("VC_C3_ABLATE") ? atoi(getenv("VC_C3_ABLATE")) : 0;                 // diagnostics only (tools/ff_ablate.py)
+    if (a.abl) launch_timed(p12, c3_fused_kernel<true>, dim3(grid), dim3(C3_NW * 64), 0, s, a);
+    else launch_timed(p12, c3_fused_kernel<false>, dim3(grid), dim3(C3_NW * 64), 0, s, a);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

@@ -48,11 +48,12 @@ __device__ __forceinline__ f32x2f ff_silu2(f32x2f x) {
 }
 __device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
 
-template <bool U8>
+template <bool U8, bool DIAG = false>
 __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
                                                              const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
-                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl) {
+                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl_arg) {
+    const int abl = DIAG ? abl_arg : 0;        // the production instance folds every ablation branch away (they fragment the MFMA loops)
     // abl (VC_FF_ABLATE, diagnostics with WRONG results; 0 in production): 1 no transcendentals, 2 no stem MFMAs, 4 no stem LDS stores,
     // 8 no output stores, 16 no stem phase, 32 no conv phase, 64 no patch writes, 128 no global fetch, 256 no patch reads in the stem
     __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
@@ -356,7 +357,9 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     const int abl = getenv("VC_FF_ABLATE") ? atoi(getenv("VC_FF_ABLATE")) : 0;       // diagnostics only (tools/ff_ablate.py)
     long long* dbg = nullptr;
     if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 64) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 64, s);
-    if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
+    if (src8 && abl) launch_timed(p0, front_fused_kernel<true, true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
+                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
+    else if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
                            p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
     else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
                       p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
