@@ -68,6 +68,19 @@ def test_lap_matches_scipy_including_ties():
         r2, q2 = linear_sum_assignment(c)
         np.testing.assert_array_equal(r, r2)
         np.testing.assert_array_equal(q, q2)
+    # 65 .. 128 columns: the two-columns-per-lane register solver (lsap_reg2; a dense class step of BASELINE.json configs[2] is about
+    # 67 x 87 after the transpose); above 128 the LDS-list solver
+    for t in range(60):
+        nr, nc = (int(v) for v in rng.integers(40, 129, 2)) if t < 50 else (int(v) for v in rng.integers(120, 200, 2))
+        c = rng.uniform(0, 1, (nr, nc))
+        if t % 3 == 1:
+            c = np.round(c, 1)                               # many exact ties
+        if t % 3 == 2:
+            c[rng.random((nr, nc)) < 0.6] = 0.20001          # mostly gated
+        r, q = E.lap(c)
+        r2, q2 = linear_sum_assignment(c)
+        np.testing.assert_array_equal(r, r2, err_msg=f"{nr}x{nc} case {t}")
+        np.testing.assert_array_equal(q, q2, err_msg=f"{nr}x{nc} case {t}")
 
 
 def test_dsort_nms_golden(golden_dir):

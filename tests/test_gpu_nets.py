@@ -242,3 +242,26 @@ def test_front_fused_layers_0_1_bit_identical(hw):
     np.testing.assert_array_equal(a1, b1)
     np.testing.assert_array_equal(a2, b2)
     eng.close()
+
+
+@pytest.mark.parametrize("hw,nc,shift", [((640, 640), 80, 1.0), ((360, 640), 8, 0.0), ((416, 352), 3, 2.0)])
+def test_sparse_detect_head_equals_dense(hw, nc, shift):
+    """The sparse Detect head of the bf16 engine (8-channel objectness conv over every pixel, the full 3 x (5 + nc)-channel head only on
+    the pixels where an anchor can pass conf_thres, decode of the gathered logits) against the dense head + decode on the same engine:
+    the same detections bit for bit -- every surviving anchor sees the same dot products in the same order -- through vc_detect and
+    through the stream path, frames with many and with no candidates."""
+    import torch
+    H, W = hw
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=shift)
+    fr = synth_frames(4, H, W, n_obj=8, seed=5)
+    fr[3] = 0                                                    # a black frame: (almost) nothing passes
+    eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=4, max_frame_hw=(H, W))
+    imgs = [f[:, :, ::-1] for f in fr]
+    eng.set_option("sparse_head", 0)
+    dense = eng.detect(imgs)
+    eng.set_option("sparse_head", 1)
+    sparse = eng.detect(imgs)
+    assert sum(len(d) for d in dense) > 20
+    for d, s in zip(dense, sparse):
+        np.testing.assert_array_equal(d, s)
+    eng.close()

@@ -338,7 +338,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
 template <int BP, int BC, int WP, int WC, int KC, int NS, int PR>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
-__global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p_arg) {
+    ConvP p = p_arg;
+    if (p_arg.m_dev) {                        // device-side problem size (uniform): fewer pixels, fewer tiles
+        const int mm = min(p_arg.M, *p_arg.m_dev);
+        p.M = mm;
+        p.ntiles = ((mm + BP - 1) / BP) * ((p_arg.Cout + BC - 1) / BC);
+    }
     constexpr bool F32 = PR == PREC_F32, FP8 = PR == PREC_FP8;
     constexpr int ES = F32 ? 4 : FP8 ? 1 : 2; // element size
     static_assert(!FP8 || KC == 8, "fp8: one 128-byte LDS row = one K = 128 MX-scaled MFMA step");

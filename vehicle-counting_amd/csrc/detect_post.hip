@@ -72,6 +72,104 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeLevel l0, const
     }
 }
 
+// ---- sparse Detect head (bf16 engines) ----------------------------------------------------------------------------------------------
+// Detect.m[i] is a 1x1 conv with 3 x (5 + nc) = 255 outputs per pixel, and non_max_suppression drops every anchor whose objectness is
+// not above conf_thres before it looks at anything else (utils/general.py: `xc = prediction[..., 4] > conf_thres`).  Dense, the three head
+// convs write 0.55 GB of logits per 128 frames at 640 x 640 that the decode reads the three objectness values of and throws away.  Sparse:
+// an 8-channel conv (the three objectness rows of Detect.m[i], engine.hip) over every pixel, this kernel picks the pixels where an
+// anchor can pass -- the SAME float test as decode_kernel -- and gathers their feature vectors; the full 255-channel conv then runs on
+// the gathered rows only (conv_igemm_kernel with a device-side row count) and decode_sparse_kernel decodes those.  Same dot products in
+// the same order for every surviving anchor: the detections are identical to the dense path's.
+__global__ __launch_bounds__(256) void head_compact_kernel(const uint16_t* __restrict__ obj, const uint16_t* __restrict__ x, int x_cs, int x_co, int C, int M,
+                                                           int pix_per_frame, float conf_thres, int cap, int* __restrict__ count, int* __restrict__ list,
+                                                           uint16_t* __restrict__ xc, int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int cpr = C / 8;                                   // 16-byte chunks per feature row (16 / 32 / 64 / ...)
+    for (int m0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; m0 < M; m0 += nwaves * 64) {
+        const int m = m0 + lane;
+        bool pass = false;
+        if (m < M) {
+            const uint2 o = *(const uint2*)(obj + (size_t)m * 8);
+            const float l0 = __uint_as_float(o.x << 16), l1 = __uint_as_float(o.x & 0xffff0000u), l2 = __uint_as_float(o.y << 16);
+            pass = sigmoidf_(l0) > conf_thres || sigmoidf_(l1) > conf_thres || sigmoidf_(l2) > conf_thres;
+        }
+        const unsigned long long mask = __ballot(pass);
+        if (mask == 0) continue;
+        const int n = __popcll(mask);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, n);
+        base = __shfl(base, 0);
+        const int slot = base + __popcll(mask & lt);
+        if (pass) {
+            if (slot < cap) list[slot] = m;
+            else overflow[m / pix_per_frame] = 1;           // more gathered pixels than the level's buffer holds: reported like a candidate overflow
+        }
+        // the flagged pixels' feature rows, 64 / cpr rows per round (cpr lanes x 16 bytes each)
+        const int rpr = cpr >= 64 ? 1 : 64 / cpr;
+        for (int k0 = 0; k0 < n; k0 += rpr) {
+            const int k = k0 + lane / cpr, c = lane % cpr;
+            if (lane / cpr < rpr && k < n && base + k < cap) {
+                unsigned long long rest = mask;              // lane index of the k-th set bit
+                for (int q = 0; q < k; ++q) rest &= rest - 1;
+                const int src = m0 + (__ffsll((long long)rest) - 1);
+                for (int cc = c; cc < cpr; cc += 64) {
+                    const uint4 v = *(const uint4*)(x + (size_t)src * x_cs + x_co + cc * 8);
+                    *(uint4*)(xc + (size_t)(base + k) * C + cc * 8) = v;
+                }
+            }
+        }
+    }
+}
+
+// decode_kernel's arithmetic on the gathered logits: one thread per (gathered pixel, anchor)
+__global__ __launch_bounds__(256) void decode_sparse_kernel(const DecodeLevel l0, const DecodeLevel l1, const DecodeLevel l2, const int* __restrict__ counts,
+                                                            const int* __restrict__ list0, const int* __restrict__ list1, const int* __restrict__ list2,
+                                                            int cap0, int cap1, int cap2, int nc, float conf_thres, int max_cand, DetectPostBuffers pb) {
+    const int no = nc + 5;
+    const int n0 = min(counts[0], cap0), n1 = min(counts[1], cap1), n2 = min(counts[2], cap2);
+    const long total = 3l * ((long)n0 + n1 + n2);
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        long e = g / 3;
+        const int a = (int)(g - e * 3);
+        const int level = e < n0 ? 0 : (e < (long)n0 + n1 ? 1 : 2);
+        const DecodeLevel& lv = level == 0 ? l0 : (level == 1 ? l1 : l2);
+        const int s = (int)(level == 0 ? e : (level == 1 ? e - n0 : e - n0 - n1));
+        const int m = (level == 0 ? list0 : (level == 1 ? list1 : list2))[s];
+        const int ppf = lv.ny * lv.nx;
+        const int b = m / ppf, rem = m - b * ppf, y = rem / lv.nx, x = rem - y * lv.nx;
+        const size_t qoff = (size_t)s * lv.cs + a * no;
+        auto ld = [&](int c) -> float { return __uint_as_float((uint32_t)((const uint16_t*)lv.logits)[qoff + c] << 16); };
+        const float obj = sigmoidf_(ld(4));
+        if (!(obj > conf_thres)) continue;
+        const float sx = sigmoidf_(ld(0)), sy = sigmoidf_(ld(1)), sw = sigmoidf_(ld(2)), sh = sigmoidf_(ld(3));
+        const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
+        const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
+        const float tw = sw * 2.0f, th = sh * 2.0f;
+        const float w = tw * tw * lv.anchor_w[a];
+        const float h = th * th * lv.anchor_h[a];
+        float best = -1.0f;
+        int bj = 0;
+        for (int c = 0; c < nc; ++c) {
+            const float v = sigmoidf_(ld(5 + c)) * obj;
+            if (v > best) { best = v; bj = c; }
+        }
+        if (!(best > conf_thres)) continue;
+        const int pos = atomicAdd(pb.cand_count + b, 1);
+        if (pos >= max_cand) { pb.overflow[b] = 1; continue; }
+        const size_t o = (size_t)b * max_cand + pos;
+        const float hw = w / 2.0f, hh = h / 2.0f;
+        pb.cand_box[o * 4 + 0] = cx - hw;
+        pb.cand_box[o * 4 + 1] = cy - hh;
+        pb.cand_box[o * 4 + 2] = cx + hw;
+        pb.cand_box[o * 4 + 3] = cy + hh;
+        pb.cand_conf[o] = best;
+        pb.cand_cls[o] = bj;
+        pb.cand_idx[o] = lv.base + (a * lv.ny + y) * lv.nx + x;      // the anchor's position in the reference's flattened prediction
+    }
+}
+
 // Order candidates like `scores.sort(stable=True, descending=True)` over the reference's candidate order:
 // rank = #{j : conf_j > conf_i or (conf_j == conf_i and idx_j < idx_i)}.
 __global__ __launch_bounds__(256) void rank_sort_kernel(int max_cand, DetectPostBuffers pb) {
@@ -213,6 +311,25 @@ int launch_decode(const DecodeLevel* lv, int nlv, int B, int nc, float conf, int
     VC_CHECK(lv[0].bf16 == lv[1].bf16 && lv[1].bf16 == lv[2].bf16, VC_ERR_ARG, "decode: mixed logits types");
     if (lv[0].bf16) hipLaunchKernelGGL(decode_kernel<true>, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
     else hipLaunchKernelGGL(decode_kernel<false>, dim3((int)grid), dim3(256), 0, s, lv[0], lv[1], lv[2], B, nc, conf, max_cand, pb, pred_debug, n_total);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+int launch_head_compact(const void* obj, const View& x, int M, int pix_per_frame, float conf, int cap, int* count, int* list, void* xc, int* overflow, hipStream_t s) {
+    VC_CHECK(x.C % 8 == 0 && x.cs % 8 == 0 && x.co % 8 == 0, VC_ERR_ARG, "head compaction: channel counts must be multiples of 8");
+    const int waves = (M + 63) / 64;
+    const int grid = std::min(std::max((waves + 3) / 4, 1), 256 * 8);
+    hipLaunchKernelGGL(head_compact_kernel, dim3(grid), dim3(256), 0, s, (const uint16_t*)obj, (const uint16_t*)x.ptr, x.cs, x.co, x.C, M, pix_per_frame, conf, cap,
+                       count, list, (uint16_t*)xc, overflow);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// lv[i].logits = the gathered logits of level i ([cap_i][cs]); counts: device int[3]
+int launch_decode_sparse(const DecodeLevel* lv, const int* counts, int* const* lists, const int* caps, int nc, float conf, int max_cand, DetectPostBuffers& pb,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(decode_sparse_kernel, dim3(256 * 4), dim3(256), 0, s, lv[0], lv[1], lv[2], counts, lists[0], lists[1], lists[2], caps[0], caps[1], caps[2], nc,
+                       conf, max_cand, pb);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

@@ -19,6 +19,7 @@ struct ConvParam {
     bool set = false;
     bool pair_stem = false;          // YOLO stem in bf16: two 4-channel pixels form one 16-byte chunk
     int fuse_a = -1, fuse_b = -1;    // >= 0: internal parameter = rows of params[fuse_a] then params[fuse_b] (same input, 1x1)
+    int obj_of = -1;                 // >= 0: internal parameter = the three objectness rows (a * (5 + nc) + 4) of Detect head params[obj_of], padded to 8
     bool hidden = false;             // internal (fused) parameters are not enumerated to the caller
     std::vector<float> w, b;         // host copies (OIHW, BN folded) until finalize()
     void* d_w = nullptr;             // packed [Cout_pad][Kp]
@@ -29,7 +30,9 @@ struct ConvParam {
 };
 
 struct Op {
-    enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL, TO_FP8 } kind;
+    enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL, TO_FP8, HEAD_COMPACT } kind;
+    int level = 0;                   // HEAD_COMPACT: detection level
+    double flops_override = -1, bytes_override = -1;   // CONV: algorithmic work to report instead of the launch's own (sparse head)
     ConvP conv{};
     View a{}, b{};
     int C = 0;
@@ -95,7 +98,7 @@ struct vc_engine {
     bool finalized = false;
     // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
     // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv
-    struct Options { int c3_fused = 1, bneck_fused = 1, front_fused = 1, crop_per_pixel = 0; } opt;
+    struct Options { int c3_fused = 1, bneck_fused = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 
@@ -107,6 +110,14 @@ struct vc_engine {
     uint8_t* d_frames = nullptr;                 // staging for host images / stream frames
     size_t d_frames_bytes = 0;
     float* d_logits[3] = {nullptr, nullptr, nullptr};
+    // sparse Detect head (bf16 engines, detect_post.hip): objectness planes, gathered pixel lists / feature rows / logits, counts
+    void* d_obj[3] = {nullptr, nullptr, nullptr};
+    int* d_hc_list[3] = {nullptr, nullptr, nullptr};
+    void* d_hc_x[3] = {nullptr, nullptr, nullptr};
+    void* d_hc_logits[3] = {nullptr, nullptr, nullptr};
+    int hc_cap[3] = {0, 0, 0};
+    int* d_hc_count = nullptr;                   // [4]
+    bool sparse_pass = false;                    // the pass being built / last run used the sparse head
     float anchors[3][6];                         // Detect anchors in pixels (default: the COCO set of yolov5{s,m,l}.yaml)
     vc::DetectPostBuffers post{};
     float* d_geom = nullptr;                     // [max_batch][5] gain, padw, padh, src_w, src_h

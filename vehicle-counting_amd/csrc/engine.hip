@@ -209,9 +209,11 @@ static void yolo_define(vc_engine* e) {
     n.add("model.18.conv", c[2], c[2], 3, 3); yolo_c3_params(n, 20, 2 * c[2], c[3], e->rep[0]);
     n.add("model.21.conv", c[3], c[3], 3, 3); yolo_c3_params(n, 23, 2 * c[3], c[4], e->rep[0]);
     const int no = 3 * (e->cfg.num_classes + 5);
-    n.add("model.24.m.0", no, c[2], 1, 1);
-    n.add("model.24.m.1", no, c[3], 1, 1);
-    n.add("model.24.m.2", no, c[4], 1, 1);
+    for (int i = 0; i < 3; ++i) {
+        const int h = n.add("model.24.m." + std::to_string(i), no, c[2 + i], 1, 1);
+        const int o = n.add("model.24.m." + std::to_string(i) + ".obj", 8, c[2 + i], 1, 1);      // sparse head: the three objectness rows, padded to 8
+        n.params[o].obj_of = h; n.params[o].hidden = true;
+    }
 }
 
 static int yolo_alloc(vc_engine* e) {
@@ -249,6 +251,18 @@ static int yolo_alloc(vc_engine* e) {
     const int lcs = round_up(no, 8);
     const int strides[3] = {8, 16, 32};
     for (int i = 0; i < 3; ++i) VC_TRY(dev_alloc(e, (void**)&e->d_logits[i], px(strides[i]) * lcs * sizeof(float)));
+    if (e->prec == PREC_BF16) {
+        // sparse head: per level an 8-channel objectness plane and room for B x min(pixels per frame, max_candidates) gathered pixels
+        for (int i = 0; i < 3; ++i) {
+            const size_t ppf = (size_t)(S / strides[i]) * (S / strides[i]);
+            e->hc_cap[i] = (int)(B * std::min(ppf, (size_t)e->cfg.max_candidates));
+            VC_TRY(dev_alloc(e, &e->d_obj[i], px(strides[i]) * 8 * 2));
+            VC_TRY(dev_alloc(e, (void**)&e->d_hc_list[i], (size_t)e->hc_cap[i] * sizeof(int)));
+            VC_TRY(dev_alloc(e, &e->d_hc_x[i], (size_t)e->hc_cap[i] * c[2 + i] * 2));
+            VC_TRY(dev_alloc(e, &e->d_hc_logits[i], (size_t)e->hc_cap[i] * lcs * 2));
+        }
+        VC_TRY(dev_alloc(e, (void**)&e->d_hc_count, 64));
+    }
     // post-processing
     const size_t mc = e->cfg.max_candidates, md = e->cfg.max_det;
     auto& pb = e->post;
@@ -346,7 +360,29 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     // that the 255-channel head takes the 16-byte-store epilogue; FLOPs are still counted for `no` channels (Op::cout_logical).
     const int no = 3 * (e->cfg.num_classes + 5), lcs = round_up(no, 8);
     const View heads[3] = {p3, p4, p5};
-    for (int i = 0; i < 3; ++i) {
+    e->sparse_pass = e->prec == PREC_BF16 && e->opt.sparse_head && !e->want_pred_debug && e->d_hc_count;
+    for (int i = 0; i < 3 && e->sparse_pass; ++i) {
+        // sparse Detect head (detect_post.hip): objectness conv over every pixel -> gather the pixels that can pass conf_thres -> the
+        // full head on the gathered rows (row count on the device).  The algorithmic work reported is the dense head's.
+        const std::string hp = "model.24.m." + std::to_string(i);
+        const View& x = heads[i];
+        const double es = 2.0, Mh = (double)x.B * x.H * x.W;
+        View ov{}; ov.ptr = e->d_obj[i]; ov.cs = 8; ov.co = 0;
+        pb.conv(hp + ".obj", x, ov, 1, 1, 0, ACT_NONE);
+        if (pb.status != VC_OK) break;
+        ops.back().flops_override = 2.0 * Mh * 3 * x.C; ops.back().bytes_override = 0;
+        { Op op{}; op.kind = Op::HEAD_COMPACT; op.level = i; op.a = x; ops.push_back(op); }
+        View gx{}; gx.ptr = e->d_hc_x[i]; gx.B = 1; gx.H = 1; gx.W = e->hc_cap[i]; gx.C = x.C; gx.cs = x.C; gx.co = 0;
+        View go{}; go.ptr = e->d_hc_logits[i]; go.cs = lcs; go.co = 0;
+        pb.conv(hp, gx, go, 1, 1, 0, ACT_NONE);
+        if (pb.status != VC_OK) break;
+        Op& hop = ops.back();
+        hop.cout_logical = hop.conv.Cout; hop.conv.Cout = lcs;
+        hop.conv.m_dev = e->d_hc_count + i;
+        hop.flops_override = 2.0 * Mh * (no - 3) * x.C;
+        hop.bytes_override = (Mh * x.C + (double)no * x.C) * es + Mh * lcs * es;      // the dense head's in + weights + out
+    }
+    for (int i = 0; i < 3 && !e->sparse_pass; ++i) {
         View o{}; o.ptr = e->d_logits[i]; o.cs = lcs; o.co = 0;
         const bool wide = e->prec == PREC_F32;
         pb.conv("model.24.m." + std::to_string(i), heads[i], o, 1, 1, 0, ACT_NONE, nullptr, RES_NONE, wide);
@@ -429,10 +465,11 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
         const Op& op = ops[oi];
         switch (op.kind) {
             case Op::CONV: {
-                const double fl = 2.0 * op.conv.M * (double)(op.cout_logical ? op.cout_logical : op.conv.Cout) * op.C;
                 const double es = elem_size(op.conv.prec);
-                const double by = ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
-                                  (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
+                const double fl = op.flops_override >= 0 ? op.flops_override : 2.0 * op.conv.M * (double)(op.cout_logical ? op.cout_logical : op.conv.Cout) * op.C;
+                const double by = op.bytes_override >= 0 ? op.bytes_override
+                                                         : ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
+                                                               (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
                 ConvP cp = op.conv;
                 static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
@@ -512,7 +549,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     VC_TRY(launch_reid_stem_pool(cp, nx->b.ptr, s));
                     ++oi;                                                    // the pool op is done
                 } else {
-                    cp.cfg = tuned_cfg(e, cp, s);
+                    cp.cfg = cp.m_dev ? -1 : tuned_cfg(e, cp, s);          // a device-side row count: the implicit-GEMM heuristic (the only family that honours it)
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                     VC_TRY(launch_conv(cp, s));
                 }
@@ -529,6 +566,13 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
             case Op::UPSAMPLE: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, s)); break; }
             case Op::MAXPOOL: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_maxpool3s2(op.a, op.b, e->aux_prec, s)); break; }   // ReID only
             case Op::TO_FP8: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_bf16_to_fp8(op.a, op.b, 1.0f / e->act_scale, s)); break; }
+            case Op::HEAD_COMPACT: {
+                ProfScope ps(e, aux_cat, 0, 0, s);
+                const int i = op.level, M = op.a.B * op.a.H * op.a.W;
+                VC_TRY(launch_head_compact(e->d_obj[i], op.a, M, op.a.H * op.a.W, e->cfg.conf_thres, e->hc_cap[i], e->d_hc_count + i, e->d_hc_list[i], e->d_hc_x[i],
+                                           e->post.overflow, s));
+                break;
+            }
         }
     }
     return VC_OK;
@@ -562,6 +606,11 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     std::vector<Op> ops;
     VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
     e->l0_stale = false;
+    if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
+        VC_HIP(hipMemsetAsync(e->d_hc_count, 0, 64, ds));
+        VC_HIP(hipMemsetAsync(e->post.overflow, 0, sizeof(int) * B, ds));
+        VC_HIP(hipMemsetAsync(e->post.cand_count, 0, sizeof(int) * B, ds));
+    }
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
     // decode + NMS
     const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 8);
@@ -585,7 +634,14 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
         }
         dbg = e->d_pred_debug;
     }
-    { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds); VC_TRY(launch_decode(lv, 3, B, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, dbg, base, ds)); }
+    if (e->sparse_pass) {
+        for (int i = 0; i < 3; ++i) lv[i].logits = e->d_hc_logits[i];
+        ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds);
+        VC_TRY(launch_decode_sparse(lv, e->d_hc_count, e->d_hc_list, e->hc_cap, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, ds));
+    } else {
+        ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds);
+        VC_TRY(launch_decode(lv, 3, B, nc, e->cfg.conf_thres, e->cfg.max_candidates, e->post, dbg, base, ds));
+    }
     { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, ds); VC_TRY(launch_nms(B, e->cfg.max_candidates, e->cfg.max_det, e->cfg.iou_thres, e->d_geom, e->post, ds)); }
     return VC_OK;
 }
@@ -756,6 +812,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -889,6 +946,18 @@ int vc_engine_finalize(vc_engine* e) {
         p.b = a.b; p.b.insert(p.b.end(), b.b.begin(), b.b.end());
         p.set = true;
     }
+    for (auto& p : e->yolo.params) {                          // sparse head: the objectness rows of a Detect head as an 8-channel conv
+        if (p.obj_of < 0) continue;
+        const ConvParam& hd = e->yolo.params[p.obj_of];
+        VC_CHECK(hd.set, VC_ERR_STATE, "parameter '%s' was never set", hd.name.c_str());
+        const int no = hd.O / 3;
+        p.w.assign((size_t)8 * p.I, 0.f); p.b.assign(8, 0.f);
+        for (int a = 0; a < 3; ++a) {
+            memcpy(&p.w[(size_t)a * p.I], &hd.w[(size_t)(a * no + 4) * hd.I], (size_t)p.I * sizeof(float));
+            p.b[a] = hd.b[a * no + 4];
+        }
+        p.set = true;
+    }
     {
         std::vector<char> part(e->yolo.params.size(), 0);
         for (auto& p : e->yolo.params) if (p.fuse_a >= 0) { part[p.fuse_a] = 1; part[p.fuse_b] = 1; }
@@ -920,6 +989,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "bneck_fused") e->opt.bneck_fused = value;
     else if (n == "front_fused") e->opt.front_fused = value;
     else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
+    else if (n == "sparse_head") e->opt.sparse_head = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
     else { set_error("unknown option '%s'", name); return VC_ERR_NOTFOUND; }
     return VC_OK;

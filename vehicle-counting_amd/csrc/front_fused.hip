@@ -41,24 +41,13 @@ union ChunkF { uint4 u; bf16x8f h; };
 
 typedef float f32x2f __attribute__((ext_vector_type(2)));
 // SiLU of two values: the multiplies and the add as packed fp32 operations (same IEEE results as the scalar forms)
-#ifdef VC_FF_SCALAR_SILU        // experiment: plain (unpacked) fp32 VALU for the SiLU arithmetic (compile this file with -fno-slp-vectorize)
-__device__ __forceinline__ float ff_silu1(float x) {
-    float t, d, r;
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(-1.442695040888963387f));
-    t = __builtin_amdgcn_exp2f(t);
-    asm volatile("v_add_f32 %0, %1, 1.0" : "=v"(d) : "v"(t));
-    d = __builtin_amdgcn_rcpf(d);
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(d));
-    return r;
-}
-__device__ __forceinline__ f32x2f ff_silu2(f32x2f x) { return (f32x2f){ff_silu1(x.x), ff_silu1(x.y)}; }
-#else
+// (the SiLU's multiplies / add as plain fp32 VALU through inline assembly instead of the packed forms hipcc emits: 0.506 -> 0.494 ms,
+// inside the run-to-run spread: removed)
 __device__ __forceinline__ f32x2f ff_silu2(f32x2f x) {
     const f32x2f t = x * (f32x2f){-1.442695040888963387f, -1.442695040888963387f};
     const f32x2f d = (f32x2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + (f32x2f){1.0f, 1.0f};
     return x * (f32x2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
-#endif
 __device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
 
 template <bool U8, bool DIAG = false>

@@ -56,6 +56,11 @@ struct DetectPostBuffers {
 };
 int launch_decode(const DecodeLevel* lv, int nlv, int B, int nc, float conf, int max_cand, DetectPostBuffers& pb,
                   float* pred_debug /* nullable: B x n_total x (5+nc) */, int n_total, hipStream_t s);
+// sparse Detect head (detect_post.hip): pixels whose objectness can pass conf_thres -> list + gathered feature rows; decode of the gathered logits
+int launch_head_compact(const void* obj /* [M][8] bf16 */, const View& x, int M, int pix_per_frame, float conf, int cap, int* count, int* list, void* xc,
+                        int* overflow, hipStream_t s);
+int launch_decode_sparse(const DecodeLevel* lv, const int* counts, int* const* lists, const int* caps, int nc, float conf, int max_cand, DetectPostBuffers& pb,
+                         hipStream_t s);
 struct ScaleGeom { int net_h, net_w, src_h, src_w; };
 void scale_geom_host(const ScaleGeom& g, float out5[5]);   // gain, padw, padh, src_w, src_h as float32
 // geom_dev: device [B][5] from scale_geom_host
@@ -100,6 +105,7 @@ struct TrackWgPlan { int tracker, task_begin, task_end, det_begin, det_n, pad0, 
 // can hold during the batch is either a sample it held when the batch began or the normalised feature of one of the batch's own
 // detections, so <sample, detection feature> for ALL pairs is state-independent and is computed up front by a grid-wide kernel.
 // table[row * n_dets + d]: rows [0, n_old_rows) = the old samples (track order, ring position), rows n_old_rows + e = detection e.
+#define VC_TRACK_DYN_LDS_BYTES (96 * 1024)   // dynamic LDS the tracker kernels may ask for: step work arrays (62.5 KB at 512 tracks + detections) + the assignment matrix
 #define VC_ROW_CHUNK 128          // rows of the output arena a tracker workgroup reserves at a time
 struct TrackDotPlan { long long table_off; int n_old_rows, n_dets, row_src_off, tile_begin, tiles, det_tiles, use_table, pad; };
 struct TrackBatchArgs {
@@ -140,6 +146,7 @@ struct TrackBatchArgs {
     int frame_w, frame_h;
     int all_tables;                  // host-side bound: every tracker's appearance table fits the arena (lean kernel instance)
     int dbg_costs;                   // 1: keep the cost rows in the global scratch (vc_tracker_debug_costs reads them back)
+    int lmat_doubles;                // dynamic LDS behind the step work arrays for the assignment's matrix (0: small_c / global scratch only)
     int no_reg;                      // diagnostics (VC_TRACK_NO_REG): steps of <= 64 x 64 take the LDS-list matching path as well
     long long* dbg;                  // diagnostics (VC_TRACK_DBG): per task 8 timestamps (100 MHz): start, predict, cost rows, match, apply, finish
 };

@@ -202,15 +202,37 @@ __device__ __forceinline__ void best_step_dpp(BestK& b) {
     y.key = __builtin_amdgcn_mov_dpp(b.key, CTRL, 0xf, 0xf, true);
     if (better_k(y, b)) b = y;
 }
+// the steps across 16-lane rows: partner lane ^ 16 / lane ^ 32 through v_permlane16_swap / v_permlane32_swap (gfx950: VALU rate, no trip
+// through the LDS crossbar -- three ds_bpermute per step were most of a scan's latency for problems wider than 16 columns).
+// permlane16_swap(x, x) = ([x0 x0 x2 x2], [x1 x1 x3 x3]) by rows: an even row finds its partner in the second result, an odd row in the first.
+__device__ __forceinline__ int partner16(int x, bool odd_row) {
+    typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+    const u32x2s r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)(odd_row ? r.x : r.y);
+}
+__device__ __forceinline__ int partner32(int x, bool upper) {
+    typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+    const u32x2s r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)(upper ? r.x : r.y);
+}
 // best over lanes [0, width), width a power of two; valid in lane 0
 __device__ __forceinline__ void best_reduce(BestK& b, int width) {
     if (width > 1) best_step_dpp<0xB1>(b);
     if (width > 2) best_step_dpp<0x4E>(b);
     if (width > 4) best_step_dpp<0x141>(b);
     if (width > 8) best_step_dpp<0x140>(b);
-    for (int o = 16; o < width; o <<= 1) {
+    if (width > 16) {
+        const bool odd = (__lane_id() >> 4) & 1;
         BestK y;
-        y.v = __shfl_xor(b.v, o); y.key = __shfl_xor(b.key, o);
+        y.v = __hiloint2double(partner16(__double2hiint(b.v), odd), partner16(__double2loint(b.v), odd));
+        y.key = partner16(b.key, odd);
+        if (better_k(y, b)) b = y;
+    }
+    if (width > 32) {
+        const bool up = __lane_id() >= 32;
+        BestK y;
+        y.v = __hiloint2double(partner32(__double2hiint(b.v), up), partner32(__double2loint(b.v), up));
+        y.key = partner32(b.key, up);
         if (better_k(y, b)) b = y;
     }
 }
@@ -265,6 +287,86 @@ __device__ __forceinline__ int lsap_reg(int lane, int nr, int nc, CostFn cost, i
     }
     return 0;
 }
+// The same solver for up to 128 rows x 128 columns: lane l owns columns l and l + 64 and rows l and l + 64 (two copies of the
+// per-column / per-row state), the scan merges a lane's two columns before the cross-lane reduction, list positions take seven bits
+// (key = unassigned ? 128 + position : 127 - position).  Same scan order, tie-breaking and dual updates as lsap_core / lsap_reg.  A
+// step of BASELINE.json configs[2] (about 90 tracks x 70 detections per class) is 67 x 87 after the transpose: on the LDS-list
+// solver, with the matrix in global memory, that was 120-230 us of a 250-390 us step.
+template <class CostFn>
+__device__ __forceinline__ int lsap_reg2(int lane, int nr, int nc, CostFn cost, int (&col4row)[2], int (&row4col)[2]) {
+    const double INF = (double)INFINITY;
+    double u[2] = {0.0, 0.0}, v[2] = {0.0, 0.0};
+    int path[2] = {-1, -1};
+    col4row[0] = col4row[1] = -1; row4col[0] = row4col[1] = -1;
+    auto sel = [](const auto (&a)[2], int h) { return h ? a[1] : a[0]; };
+    for (int cur = 0; cur < nr; ++cur) {
+        double minVal = 0, spc[2] = {INF, INF};
+        int i = cur, num_remaining = nc, sink = -1;
+        int pos[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pos[h] = lane + 64 * h < nc ? nc - 1 - (lane + 64 * h) : -1;
+        bool SR[2] = {false, false}, SC[2] = {false, false};
+        while (sink == -1) {
+            const int ih = i >> 6, il = i & 63;
+            if (lane == il) { if (ih) SR[1] = true; else SR[0] = true; }
+            const double ui = lane_get(ih ? u[1] : u[0], il);
+            BestK b = {INF, INT_MIN};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (pos[h] >= 0) {
+                    const double r = minVal + cost(i, lane, h) - ui - v[h];
+                    if (r < spc[h]) { path[h] = i; spc[h] = r; }
+                    const BestK c = {spc[h], row4col[h] == -1 ? 128 + pos[h] : 127 - pos[h]};
+                    if (better_k(c, b)) b = c;
+                }
+            }
+            best_reduce(b, 64);
+            minVal = lane_get(b.v, 0);
+            const int key = lane_get(b.key, 0);
+            if (minVal == INF) return -1;
+            const int it = key >= 128 ? key - 128 : 127 - key;
+            const unsigned long long m0 = __ballot(pos[0] == it), m1 = __ballot(pos[1] == it);
+            const int jstar = m0 ? __ffsll(m0) - 1 : 64 + __ffsll(m1) - 1;
+            const int jh = jstar >> 6, jl = jstar & 63;
+            const int rj = lane_get(jh ? row4col[1] : row4col[0], jl);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) if (pos[h] == num_remaining - 1) pos[h] = it;        // swap-remove: the list's last entry takes the freed position ...
+            if (lane == jl) { if (jh) { pos[1] = -1; SC[1] = true; } else { pos[0] = -1; SC[0] = true; } }    // ... and the chosen column leaves the list
+            --num_remaining;
+            if (rj == -1) sink = jstar; else i = rj;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                        // dual update of row lane + 64 g
+            const int c = col4row[g];
+            const double s0 = __shfl(spc[0], c >= 0 ? c & 63 : 0), s1 = __shfl(spc[1], c >= 0 ? c & 63 : 0);
+            const double spc_of_my_col = (c >> 6) & 1 ? s1 : s0;
+            const int row = lane + 64 * g;
+            if (row == cur) u[g] += minVal;
+            else if (SR[g] && row < nr) u[g] += minVal - spc_of_my_col;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (SC[h]) v[h] -= minVal - spc[h];
+        int j = sink;                                        // augment along the alternating path
+        while (true) {
+            const int r = lane_get((j >> 6) ? path[1] : path[0], j & 63);
+            const int prev = lane_get((r >> 6) ? col4row[1] : col4row[0], r & 63);
+            if (lane == (j & 63)) { if (j >> 6) row4col[1] = r; else row4col[0] = r; }
+            if (lane == (r & 63)) { if (r >> 6) col4row[1] = j; else col4row[0] = j; }
+            j = prev;
+            if (r == cur) break;
+        }
+    }
+    (void)sel;
+    return 0;
+}
+// cost row-major [nr][nc] in memory, nr <= nc <= 128; col4row_out[0..nr)
+__device__ __forceinline__ int lsap_core_wave128(int lane, int nr, int nc, const double* cost, int* col4row_out) {
+    int c4r[2], r4c[2];
+    if (lsap_reg2(lane, nr, nc, [&](int i, int l, int h) { const int j = l + 64 * h; return cost[(size_t)i * nc + (j < nc ? j : 0)]; }, c4r, r4c) != 0) return -1;
+    if (lane < nr) col4row_out[lane] = c4r[0];
+    if (lane + 64 < nr) col4row_out[lane + 64] = c4r[1];
+    return 0;
+}
 // cost row-major [nr][nc] in memory (LDS for the small problems this is used for); col4row_out[0..nr)
 __device__ __forceinline__ int lsap_core_wave64(int lane, int nr, int nc, const double* cost, int* col4row_out) {
     int c4r, r4c;
@@ -285,6 +387,8 @@ struct StepWork {
     LapWork lap;
     double *small_c, *small_t;      // gathered sub-matrix / its transpose when it has at most small_n entries (LDS on the device:
     int small_n;                    // the assignment's scans then never leave the CU); 0 = always use the caller's buffers
+    double* lmat;                   // one larger LDS matrix (lmat_n entries) for the problems that outgrow small_c / small_t: it holds
+    int lmat_n;                     // the matrix the solver scans -- the gathered one, or its transpose when rows > columns
 };
 
 // bytes of one StepWork with capacity cap (all arrays 8-byte aligned: cap is a multiple of 8)
@@ -293,7 +397,7 @@ VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (6 + 12 + 4) +
 VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     char* p = (char*)base;
     w.cap = cap;
-    w.small_c = nullptr; w.small_t = nullptr; w.small_n = 0;
+    w.small_c = nullptr; w.small_t = nullptr; w.small_n = 0; w.lmat = nullptr; w.lmat_n = 0;
     auto D = [&](double*& q) { q = (double*)p; p += (size_t)cap * 8; };
     auto I = [&](int*& q) { q = (int*)p; p += (size_t)cap * 4; };
     auto B = [&](unsigned char*& q) { q = (unsigned char*)p; p += (size_t)cap; };
@@ -304,6 +408,24 @@ VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     I(w.confirmed); I(w.unconfirmed); I(w.left); I(w.rows); I(w.un_rows); I(w.un_cols); I(w.un_tracks); I(w.match_t); I(w.match_d);
     I(w.ri); I(w.ci); I(w.newslot);
     B(w.lap.SR); B(w.lap.SC); B(w.row_used); B(w.col_used); B(w.matched);
+}
+
+// The transposed solve (nr > nc): t holds the matrix as [nc][nr]; pairs come back sorted by ORIGINAL row like SciPy's.
+VC_HD int lap_solve_tr(Lanes L, const StepWork& w, const double* t, int nr, int nc, int& err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nr <= 64) { if (lsap_core_wave64(L.lane, nc, nr, t, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
+    else if (nr <= 128) { if (lsap_core_wave128(L.lane, nc, nr, t, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
+    else
+#endif
+    if (lsap_core(L, nc, nr, t, w.lap) != 0) { err = TERR_LAP; return 0; }
+    int* r2c = w.lap.path;                                   // free again after the solve: original row -> original column
+    for (int i = L.lane; i < nr; i += L.n) r2c[i] = -1;
+    wave_sync();
+    for (int v = L.lane; v < nc; v += L.n) r2c[w.lap.col4row[v]] = v;
+    wave_sync();
+    const int np = compact(L, nr, [&](int i) { return r2c[i] >= 0; }, [&](int pos, int i) { w.ri[pos] = i; w.ci[pos] = r2c[i]; });
+    wave_sync();
+    return np;
 }
 
 // scipy.optimize.linear_sum_assignment on c [nr][nc]: pairs (ri[k], ci[k]) sorted by row; returns their number (min(nr, nc)).
@@ -330,22 +452,11 @@ VC_HD int lap_solve(Lanes L, const StepWork& w, const double* c, int nr, int nc,
             tbuf[(size_t)j * nr + i] = c[e];
         }
         wave_sync();
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (nr <= 64) { if (lsap_core_wave64(L.lane, nc, nr, tbuf, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
-        else
-#endif
-        if (lsap_core(L, nc, nr, tbuf, w.lap) != 0) { err = TERR_LAP; return 0; }
-        int* r2c = w.lap.path;                               // free again after the solve: original row -> original column
-        for (int i = L.lane; i < nr; i += L.n) r2c[i] = -1;
-        wave_sync();
-        for (int v = L.lane; v < nc; v += L.n) r2c[w.lap.col4row[v]] = v;
-        wave_sync();
-        const int np = compact(L, nr, [&](int i) { return r2c[i] >= 0; }, [&](int pos, int i) { w.ri[pos] = i; w.ci[pos] = r2c[i]; });
-        wave_sync();
-        return np;
+        return lap_solve_tr(L, w, tbuf, nr, nc, err);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nc <= 64) { if (lsap_core_wave64(L.lane, nr, nc, c, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
+    else if (nc <= 128) { if (lsap_core_wave128(L.lane, nr, nc, c, w.lap.col4row) != 0) { err = TERR_LAP; return 0; } wave_sync(); }
     else
 #endif
     if (lsap_core(L, nr, nc, c, w.lap) != 0) { err = TERR_LAP; return 0; }
@@ -481,21 +592,35 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
         wave_sync();
         return;
     }
-    if (nr * nc <= w.small_n) { cbuf = w.small_c; tbuf = w.small_t; }
-    for (int e = L.lane; e < nr * nc; e += L.n) {           // parallel gather + clamp
-        const int i = e / nc, j = e - i * nc;
-        const double v = cost[(size_t)rows[i] * ld + cols[j]];
-        cbuf[e] = v > max_cost ? max_cost + 1e-5 : v;
+    // The sub-matrix is gathered ONCE, clamped, straight into the orientation the solver scans (SciPy solves the transpose when there
+    // are more rows than columns) and into the fastest memory that holds it: the 2 KB static LDS buffer, the batch's LDS matrix
+    // (w.lmat, dense scenes), else the workgroup's global scratch.  Eight independent reads per lane and round: the cost rows of a
+    // dense step live in global memory, and one dependent round trip per element made this loop the larger part of the matching.
+    const bool tr = nr > nc && nc > 1;
+    const int n = nr * nc;
+    double* mat = n <= w.small_n ? w.small_c : (w.lmat && n <= w.lmat_n ? w.lmat : (tr ? tbuf : cbuf));
+    for (int e0 = L.lane; e0 < n; e0 += 8 * L.n) {          // parallel gather + clamp
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * L.n, ee = e < n ? e : 0, i = ee / nc, j = ee - i * nc;
+            v[k] = cost[(size_t)rows[i] * ld + cols[j]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * L.n;
+            if (e < n) { const int i = e / nc, j = e - i * nc; mat[tr ? (size_t)j * nr + i : (size_t)e] = v[k] > max_cost ? max_cost + 1e-5 : v[k]; }
+        }
     }
     for (int i = L.lane; i < nr; i += L.n) w.row_used[i] = 0;
     for (int j = L.lane; j < nc; j += L.n) w.col_used[j] = 0;
     wave_sync();
-    const int np = lap_solve(L, w, cbuf, nr, nc, tbuf, err);
+    const int np = tr ? lap_solve_tr(L, w, mat, nr, nc, err) : lap_solve(L, w, mat, nr, nc, tbuf, err);
     for (int k = L.lane; k < np; k += L.n) { w.row_used[w.ri[k]] = 1; w.col_used[w.ci[k]] = 1; }
     wave_sync();
     n_uc = compact(L, nc, [&](int j) { return !w.col_used[j]; }, [&](int pos, int j) { un_cols[pos] = cols[j]; });
     n_ur = compact(L, nr, [&](int i) { return !w.row_used[i]; }, [&](int pos, int i) { un_rows[pos] = rows[i]; });
-    auto rejected = [&](int k) { return cbuf[(size_t)w.ri[k] * nc + w.ci[k]] > max_cost; };
+    auto rejected = [&](int k) { return cost[(size_t)rows[w.ri[k]] * ld + cols[w.ci[k]]] > max_cost; };     // the clamp maps exactly these to max + 1e-5
     const int nrej = compact(L, np, rejected, [&](int pos, int k) { un_rows[n_ur + pos] = rows[w.ri[k]]; un_cols[n_uc + pos] = cols[w.ci[k]]; });
     const int nacc = compact(L, np, [&](int k) { return !rejected(k); },
                              [&](int pos, int k) { w.match_t[n_match + pos] = rows[w.ri[k]]; w.match_d[n_match + pos] = cols[w.ci[k]]; });

@@ -113,7 +113,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define VC_SMALL_D 12       // detections per step up to which the appearance rows run one wave per track (appearance_row_wave)
 #define VC_TRACK_MAX_WAVES 8
 #define VC_STEP_STATE 64         // tracks whose Kalman state a step keeps in LDS (larger steps read the pool in global memory)
-#define VC_TRACK_DYN_LDS (96 * 1024)   // dynamic LDS the tracker kernels may ask for (step_work_bytes(512) = 62.5 KB)
+#define VC_TRACK_DYN_LDS VC_TRACK_DYN_LDS_BYTES
 
 // LDS scratch of one tracker workgroup
 struct TrackShared {
@@ -476,6 +476,9 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
     double* tbuf = cbuf + TC_MAT;
     step_work_carve(w_glb, wg_scratch + 4 * TC_MAT * sizeof(double), TC_HARD_CAP);
     w_lds.small_c = w_glb.small_c = sh.small_c; w_lds.small_t = w_glb.small_t = sh.small_t; w_lds.small_n = w_glb.small_n = 256;
+    // dense batches: the matrix the assignment scans lives in LDS behind the step's work arrays (the host sizes it, tracker.hip)
+    w_lds.lmat = w_glb.lmat = a.lmat_doubles > 0 ? (double*)(track_dyn_lds + step_work_bytes(a.cap)) : nullptr;
+    w_lds.lmat_n = w_glb.lmat_n = a.lmat_doubles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Lanes L{lane, 64};
     const TrackPool& tp = a.pool;
@@ -670,7 +673,7 @@ size_t track_scratch_per_wg() { return ((size_t)4 * TC_MAT * sizeof(double) + st
 
 int launch_track_batch(const TrackBatchArgs& a, int n_wg, hipStream_t s) {
     if (n_wg <= 0) return VC_OK;
-    const size_t lds = step_work_bytes(a.cap);
+    const size_t lds = step_work_bytes(a.cap) + (size_t)a.lmat_doubles * sizeof(double);
     static const bool lds_ok = [] {                          // dynamic LDS beyond 64 KB (cap = 512) has to be allowed per kernel
         return hipFuncSetAttribute((const void*)track_batch_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VC_TRACK_DYN_LDS) == hipSuccess &&
                hipFuncSetAttribute((const void*)track_batch_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VC_TRACK_DYN_LDS) == hipSuccess;

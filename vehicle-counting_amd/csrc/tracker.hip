@@ -180,6 +180,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     for (int k = 0; k < n_tasks; ++k) s.dev_index[order[k]] = k;
     std::vector<TrackWgPlan> plans;
     int need = 8, n_dets = 0;
+    long long mat_need = 0;              // entries of the largest assignment problem a step of this batch is likely to pose (tracks x detections)
     // Do the appearance tables of ALL trackers fit the arena for certain?  Bound from what the host knows: the tracks of the last
     // collected batch (known_tracks) hold at most a full gallery each, and every detection of a batch still in flight (pending_dets)
     // adds at most ONE gallery row -- it either extends one track's ring or starts a track with a single sample (tracker.py:82-91,
@@ -207,13 +208,15 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         }
         // LDS capacity from the tracker's recent size (the kernel falls back to global-memory work arrays for a larger step)
         need = std::max(need, 2 * e->trackers[tr]->known_tracks + 2 * dmax + 16);
+        mat_need = std::max(mat_need, (long long)(e->trackers[tr]->known_tracks + 32) * dmax);
         s.tracker_dets.emplace_back(tr, dets);
         s.last_task_of.push_back(k1 - 1);
         k = k1;
     }
     s.n_dets = n_dets;
-    int cap = 32;
-    while (cap < need && cap < TC_HARD_CAP) cap *= 2;
+    // work-array capacity: 32, else the next multiple of 64 (a power of two, as before round 3, doubled the arrays' LDS for a 310-entry
+    // step and left no room for the assignment matrix next to them)
+    const int cap = need <= 32 ? 32 : std::min((int)TC_HARD_CAP, (need + 63) / 64 * 64);
     const int n_wg = (int)plans.size();
     s.n_wg = n_wg;
     s.step_cap = cap;
@@ -307,6 +310,14 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     a.status = s.d_cursor + 4;                               // device memory (atomics), copied next to the rows below
     a.scratch = e->d_track_scratch; a.scratch_per_wg = track_scratch_per_wg(); a.cap = cap; a.frame_w = W; a.frame_h = H;
     a.all_tables = tables_fit ? 1 : 0;
+    // Dense steps (BASELINE.json configs[2]: ~90 tracks x ~70 detections): the matrix the assignment scans goes into LDS behind the work
+    // arrays -- as much as the kernel's dynamic LDS allows; light batches ask for none (their problems fit the 2 KB static buffers, and
+    // a small LDS footprint lets conv workgroups share the tracker's CUs).
+    a.lmat_doubles = 0;
+    if (mat_need > 256) {
+        const long long room = ((long long)VC_TRACK_DYN_LDS_BYTES - (long long)step_work_bytes(cap)) / 8;
+        a.lmat_doubles = (int)std::max(0ll, std::min(room, (mat_need + 63) / 64 * 64));
+    }
     static const bool no_reg = getenv("VC_TRACK_NO_REG") != nullptr;
     a.no_reg = no_reg ? 1 : 0;
     a.dbg_costs = st == 3 ? 1 : 0;                               // blocking entry points: vc_tracker_debug_costs may read the rows back

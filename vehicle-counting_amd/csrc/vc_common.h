@@ -133,6 +133,9 @@ struct ConvP {
     // one launch, e.g. C3.cv1 + C3.cv2); split is a multiple of 4, 0 = single destination
     void* out2;
     int split, out2_cs, out2_co;
+    const int* m_dev;    // optional: the number of valid output pixels lives on the DEVICE (a compacted batch whose size the host does not
+                         // know, e.g. the sparse Detect head): the kernel processes min(M, *m_dev) pixels; M bounds the launch.  Only the
+                         // implicit-GEMM family (conv_igemm_kernel) honours it
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
     int ablate;          // diagnostics only (VC_CONV_ABLATE, timing experiments with wrong results): 1 = no staging DMA after the first tiles,
                          // 2 = no output stores, 3 = both, 6 = return at once (launch floor of the grid); per-phase times come from dbg
