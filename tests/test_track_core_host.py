@@ -152,6 +152,16 @@ def test_lap_equals_scipy_including_ties(tch):
         np.testing.assert_array_equal(q[:n], ci, err_msg=f"trial {trial} {nr}x{nc}")
 
 
+def test_constant_matrices_pair_the_diagonal():
+    """min_cost_matching's shortcut for an all-gated sub-matrix (track_core.h) relies on this property of SciPy's solver: on a constant
+    matrix it pairs row i with column i for every i < min(rows, columns)."""
+    for nr in range(1, 70, 3):
+        for nc in range(1, 70, 4):
+            r, c = linear_sum_assignment(np.full((nr, nc), 0.20001))
+            k = min(nr, nc)
+            assert np.array_equal(r, np.arange(k)) and np.array_equal(c, np.arange(k)), (nr, nc)
+
+
 def test_capacity_is_checked_before_anything_changes(tch):
     h = tch.tch_create(0.2, 0.6, 30, 3, 60, 8, 64)
     rng = np.random.default_rng(1)

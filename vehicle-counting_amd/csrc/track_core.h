@@ -599,6 +599,7 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
     const bool tr = nr > nc && nc > 1;
     const int n = nr * nc;
     double* mat = n <= w.small_n ? w.small_c : (w.lmat && n <= w.lmat_n ? w.lmat : (tr ? tbuf : cbuf));
+    unsigned long long adm = 0;                             // does ANY pair of the sub-matrix survive the threshold?
     for (int e0 = L.lane; e0 < n; e0 += 8 * L.n) {          // parallel gather + clamp
         double v[8];
 #pragma unroll
@@ -609,8 +610,25 @@ VC_HD void min_cost_matching(Lanes L, const StepWork& w, const int* rows, int nr
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = e0 + k * L.n;
-            if (e < n) { const int i = e / nc, j = e - i * nc; mat[tr ? (size_t)j * nr + i : (size_t)e] = v[k] > max_cost ? max_cost + 1e-5 : v[k]; }
+            if (e < n) {
+                const int i = e / nc, j = e - i * nc;
+                mat[tr ? (size_t)j * nr + i : (size_t)e] = v[k] > max_cost ? max_cost + 1e-5 : v[k];
+                if (!(v[k] > max_cost)) adm = 1;
+            }
         }
+    }
+    if (wave_or(L, adm) == 0) {
+        // Every entry is the clamp value: on a constant matrix SciPy's solver pairs row i with column i for i < min(nr, nc) (checked
+        // against scipy.optimize.linear_sum_assignment for every shape up to 40 x 40 and in tests/test_track_core_host.py), all of these
+        // pairs are rejected, and the reference's lists come out rotated: the unassigned tail first, then the rejected pairs in row
+        // order (linear_assignment.py:63-76).  A cascade level whose tracks have lost their objects -- most levels of a crowded scene
+        // -- costs one pass over its sub-matrix instead of an assignment.
+        const int k = imin(nr, nc);
+        for (int p = L.lane; p < nc; p += L.n) un_cols[p] = p < nc - k ? cols[k + p] : cols[p - (nc - k)];
+        for (int p = L.lane; p < nr; p += L.n) un_rows[p] = p < nr - k ? rows[k + p] : rows[p - (nr - k)];
+        n_ur = nr; n_uc = nc;
+        wave_sync();
+        return;
     }
     for (int i = L.lane; i < nr; i += L.n) w.row_used[i] = 0;
     for (int j = L.lane; j < nc; j += L.n) w.col_used[j] = 0;
