@@ -253,7 +253,7 @@ def test_sparse_detect_head_equals_dense(hw, nc, shift):
     import torch
     H, W = hw
     sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=shift)
-    fr = synth_frames(4, H, W, n_obj=8, seed=5)
+    fr = synth_frames(4, H, W, n_obj=12, seed=1702, bounce=True)  # bench.py's clip: ~15 boxes per frame at 640 x 640 with its head
     fr[3] = 0                                                    # a black frame: (almost) nothing passes
     eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=4, max_frame_hw=(H, W))
     imgs = [f[:, :, ::-1] for f in fr]
