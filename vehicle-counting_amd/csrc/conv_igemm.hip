@@ -90,24 +90,41 @@ __device__ __forceinline__ void mfma_results_settle(f32x4* acc) {
 // v_rcp_f32 directly (1 ulp each, far below the bf16 rounding that follows) -- a correctly rounded division costs 11 more
 // VALU instructions per value, and the epilogue is the larger part of the 1x1 layers.
 // Preconditions (checked by the caller): Cout, channel strides and offsets multiples of 8.
+typedef unsigned int u32x2r __attribute__((ext_vector_type(2)));
+// the residual values of a wave tile, as conv_epilogue_bf16 reads them (one 8-byte load per 16 x 16 block and lane)
+template <int PT, int CT>
+__device__ __forceinline__ void conv_residual_fetch(const ConvP& p, u32x2r (&R)[PT][CT], int mbase, int nbase, int frow) {
+    const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+        const int m = mbase + b * 16 + frow;
+        const int rrow = m * p.res_cs + p.res_co;
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int n = nbase + a * 16;
+            R[b][a] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (n < p.Cout && m < p.M) ? (rrow + n) * 2 : 0, 0, 0);
+        }
+    }
+}
+// Rpre / have_pre: the same values fetched ahead by the caller (conv3x3_halo_kernel reads them before its K loop: a one-tile workgroup
+// has nothing to overlap the residual's memory latency with at the end of its life). By reference and a flag, not a pointer that may be
+// null: a selected pointer sends the array to scratch memory.
 template <int PT, int CT, int ACT, int RES>
-__device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[CT][PT], const float4 (&bias)[CT], int mbase, int nbase, int frow) {
+__device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[CT][PT], const float4 (&bias)[CT], int mbase, int nbase, int frow,
+                                                   const u32x2r (&Rpre)[PT][CT], bool have_pre) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
     u32x2 R[PT][CT];
     if constexpr (RES != RES_NONE) {
-        const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, 0x7ffffff0, 0x00020000);
+        if (have_pre) {
 #pragma unroll
-        for (int b = 0; b < PT; ++b) {
-            const int m = mbase + b * 16 + frow;
-            const int rrow = m * p.res_cs + p.res_co;
+            for (int b = 0; b < PT; ++b)
 #pragma unroll
-            for (int a = 0; a < CT; ++a) {
-                const int n = nbase + a * 16;
-                R[b][a] = __builtin_amdgcn_raw_buffer_load_b64(rsrd, (n < p.Cout && m < p.M) ? (rrow + n) * 2 : 0, 0, 0);
-            }
+                for (int a = 0; a < CT; ++a) R[b][a] = Rpre[b][a];
+        } else {
+            conv_residual_fetch<PT, CT>(p, R, mbase, nbase, frow);
         }
     }
     const bool odd = ((threadIdx.x >> 4) & 1) != 0;
@@ -245,8 +262,18 @@ __device__ __forceinline__ void conv_epilogue_fp8(const ConvP& p, f32x4 (&acc)[C
 
 // Epilogue shared by the conv kernels: D[channel = (lane>>4)*4 + reg][pixel = lane&15] -> bias, activation, residual, bf16
 // pack, concat-slice / split-destination store.  mbase = first pixel of the wave's tile, nbase = this lane's first channel.
+template <int PT, int CT, int ACT, int RES>
+__device__ __forceinline__ void conv_epilogue_bf16(const ConvP& p, f32x4 (&acc)[CT][PT], const float4 (&bias)[CT], int mbase, int nbase, int frow) {
+    u32x2r none[PT][CT];                                   // never read
+    conv_epilogue_bf16<PT, CT, ACT, RES>(p, acc, bias, mbase, nbase, frow, none, false);
+}
+template <int PT, int CT>
+__device__ __forceinline__ bool conv_epilogue_fast_bf16(const ConvP& p) {        // the preconditions of conv_epilogue_bf16 (uniform)
+    return !p.out_f32 && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_co % 8 == 0 &&
+           (p.split == 0 || (p.split % 8 == 0 && p.out2_cs % 8 == 0 && p.out2_co % 8 == 0));
+}
 template <int PT, int CT, bool F32>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][PT], int mbase, int nbase, int frow) {
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][PT], int mbase, int nbase, int frow, const u32x2r (&Rpre)[PT][CT], bool have_pre) {
     float4 bias[CT];
 #pragma unroll
     for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -260,17 +287,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     // bf16 fast path: conv_epilogue_bf16 above
     if constexpr (!F32 && PT % 2 == 0) {
-        const bool fast = !p.out_f32 && p.Cout % 8 == 0 && p.out_cs % 8 == 0 && p.out_co % 8 == 0 &&
-                          (p.split == 0 || (p.split % 8 == 0 && p.out2_cs % 8 == 0 && p.out2_co % 8 == 0));
+        const bool fast = conv_epilogue_fast_bf16<PT, CT>(p);
         if (fast) {
             // activation / residual mode are launch constants: one straight-line instance per combination the networks use
             // (no per-value scalar branches), anything else takes the general loop below
             const int key = p.act * 4 + p.res_mode;
-            if (key == ACT_SILU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
-            if (key == ACT_SILU * 4 + RES_AFTER_ACT) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_AFTER_ACT>(p, acc, bias, mbase, nbase, frow); return; }
-            if (key == ACT_RELU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
-            if (key == ACT_RELU * 4 + RES_BEFORE_ACT) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_BEFORE_ACT>(p, acc, bias, mbase, nbase, frow); return; }
-            if (key == ACT_NONE * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_NONE, RES_NONE>(p, acc, bias, mbase, nbase, frow); return; }
+            if (key == ACT_SILU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_NONE>(p, acc, bias, mbase, nbase, frow, Rpre, false); return; }
+            if (key == ACT_SILU * 4 + RES_AFTER_ACT) { conv_epilogue_bf16<PT, CT, ACT_SILU, RES_AFTER_ACT>(p, acc, bias, mbase, nbase, frow, Rpre, have_pre); return; }
+            if (key == ACT_RELU * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_NONE>(p, acc, bias, mbase, nbase, frow, Rpre, false); return; }
+            if (key == ACT_RELU * 4 + RES_BEFORE_ACT) { conv_epilogue_bf16<PT, CT, ACT_RELU, RES_BEFORE_ACT>(p, acc, bias, mbase, nbase, frow, Rpre, have_pre); return; }
+            if (key == ACT_NONE * 4 + RES_NONE) { conv_epilogue_bf16<PT, CT, ACT_NONE, RES_NONE>(p, acc, bias, mbase, nbase, frow, Rpre, false); return; }
         }
     }
 #pragma unroll
@@ -337,6 +363,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][P
 // hardware answers with zeros (verified by the padded test cases); the per-row validity of all kh*kw taps is one 64-bit
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
+template <int PT, int CT, bool F32>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[CT][PT], int mbase, int nbase, int frow) {
+    u32x2r none[PT][CT];                                   // never read
+    conv_epilogue<PT, CT, F32>(p, acc, mbase, nbase, frow, none, false);
+}
 template <int BP, int BC, int WP, int WC, int KC, int NS, int PR>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
 __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p_arg) {
     ConvP p = p_arg;
@@ -734,6 +765,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
 #pragma unroll
         for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mfma_inputs_settle<CT * PT>(&acc[0][0]);
+    // the residual (ReID conv2 + shortcut, YOLO Bottleneck 3x3 + shortcut) is fetched NOW: this workgroup computes one tile and ends,
+    // so the epilogue's residual reads had a full memory latency to themselves (64 -> 64 at 25 x 25: 0.135 ms with, 0.100 ms without)
+    u32x2r rpre[PT][CT];
+    // (only where the 2 * PT * CT registers it holds through the K loop do not cost a wave of occupancy)
+    const bool have_res = PT * CT <= 8 && p.res_mode != RES_NONE && conv_epilogue_fast_bf16<PT, CT>(p) &&
+                          ((p.act == ACT_SILU && p.res_mode == RES_AFTER_ACT) || (p.act == ACT_RELU && p.res_mode == RES_BEFORE_ACT));
+    if (have_res) conv_residual_fetch<PT, CT>(p, rpre, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0];
     constexpr uint32_t XBYTES = XCH * 16, WSTAGE = WROWS * KC * 16;
@@ -806,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (3)] = wall_clock64(); } while (0);
 #undef VC_XSTAGE
 #undef VC_WSTAGE
-    conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
+    conv_epilogue<PT, CT, false>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow, rpre, have_res);
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (4)] = wall_clock64(); } while (0); }
 }
 
