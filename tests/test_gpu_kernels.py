@@ -74,11 +74,12 @@ def test_conv2d(case, precision):
 
 
 @pytest.mark.parametrize("slots", [0, 8])
-@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 44)))
+@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 50)))
 def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""
-    halo = cfg in (28, 29, 30, 31, 36, 37, 38, 39)          # 40-42 are implicit-GEMM tiles with 16 waves per workgroup
+    s2halo = 44 <= cfg <= 49
+    halo = cfg in (28, 29, 30, 31, 36, 37, 38, 39) or s2halo    # 40-43 are implicit-GEMM tiles with 16 waves per workgroup
     monkeypatch.setenv("VC_CONV_CFG", str(cfg))
     if slots:
         if halo:
@@ -92,6 +93,12 @@ def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
                  (1, 40, 160, 32, 64, 3, 1, 1, 1, 0)]
         if cfg >= 38:
             cases[-1] = (1, 40, 96, 32, 64, 3, 1, 1, 1, 0)       # 256-pixel tiles: five rows of 160 pixels exceed the largest patch buffer
+    if s2halo:
+        # halo-staged 3x3 / s2 / p1 (rectangular tiles, patch staged by parity class; Cin a multiple of 64): 20 x 16, 4 x 3 (a tile spans
+        # several images), the 80-column geometry of YOLO layer 3 (8 x 16 tiles), two channel groups with a ragged channel tail, and a
+        # 20-column map (25 x 5 tiles across images) with three groups
+        cases = [(2, 40, 32, 64, 72, 3, 2, 1, 1, 0), (5, 8, 6, 64, 40, 3, 2, 1, 2, 0), (1, 160, 160, 64, 128, 3, 2, 1, 1, 0),
+                 (3, 20, 24, 128, 136, 3, 2, 1, 0, 0), (2, 40, 40, 192, 64, 3, 2, 1, 1, 0)]
     for case in cases:
         B, H, W, Ci, Co, k, s, p, act, rm = case
         rng = np.random.default_rng(cfg * 131 + H)

@@ -848,6 +848,292 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo_kernel(const ConvP p) {
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (4)] = wall_clock64(); } while (0); }
 }
 
+// ---- halo-staged 3x3 / stride 2 / pad 1 (bf16) ---------------------------------------------------------------------------
+// The down-sampling layers (YOLO 3-P3 .. 7-P5 and the two head 3x3/s2) ran on the implicit GEMM at 480 - 880 TFLOP/s: nine separately
+// staged taps per output pixel, 9/4 L2 -> LDS trips per input line.  Same inside-out K loop as conv3x3_halo_kernel (patch staged once,
+// taps read it at shifted addresses, weights through the LDS-DMA ring), with what stride 2 changes:
+//   * the tile is a RECTANGLE of th x tw output pixels (th * tw <= 128, chosen by the launcher per layer), not a run of the flattened
+//     pixel index: a run of 128 outputs of an 80-wide map touches seven 160-pixel input rows, the 8 x 16 rectangle a 17 x 33 patch
+//     (1.10 x the 4 inputs per output nothing can avoid).  Rows are rows of the flattened (batch, y) space (H = 2 Ho, so input row =
+//     2 * output row - 1 + dy across images too): no ragged tiles at image bottoms.  The 128 pixel slots of the MFMA tiles are the
+//     rectangle row-major; slots past th * tw, past the map's right edge or the last row are masked lanes.
+//   * the patch is staged BY PARITY CLASS: tap (dy, dx) of output (r, c) reads patch pixel (2r + dy, 2c + dx), so the taps with
+//     (dy & 1, dx & 1) = (rp, cp) touch only patch rows of parity rp and columns of parity cp -- 4, 2, 2 and 1 taps for the classes
+//     even/even, even/odd, odd/even, odd/odd.  One class at a time is in LDS, (th + 1) x (tw + 1) pixels, and within it the 16 lanes
+//     of an MFMA fragment read CONSECUTIVE pixels (r + dy/2, c + dx/2): the stride-2 gather becomes the stride-1 kernel's access
+//     pattern.  A quarter of the patch at a time is also what lets a pixel be staged with 64 channels (its full 128-byte line, 20 KB
+//     per class) instead of a 32-channel slice of the whole patch (37 KB): the first version fetched half lines, and the second half
+//     came from HBM again 12 us later (FETCH_SIZE 822 MB for the 419 MB input of YOLO layer 3: HBM bound at 2 x the traffic).
+//   K order: 64-channel group, parity class, 32-channel half, tap -- 18 MFMA steps per group; the weight ring follows that order.
+// One patch buffer: the class loads are exposed to the workgroup and covered by the other workgroups of the CU (a second buffer for the
+// next class was built and measured: never faster, the LDS it takes costs a workgroup per CU).
+// Output rows are not consecutive in memory, so the epilogue takes the lane's pixel index per MFMA tile (mrow).
+template <int PT, int CT, int ACT>
+__device__ __forceinline__ void conv_epilogue_bf16_rows(const ConvP& p, f32x4 (&acc)[CT][PT], const int (&mrow)[PT], int nbase) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    float4 bias[CT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+#pragma unroll
+    for (int b = 0; b < PT; b += 2) {
+        const int m = odd ? mrow[b + 1] : mrow[b];                  // after the lane-pair exchange below (conv_epilogue_bf16)
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            const int n = nbase + a * 16;
+            u32x2 P[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[4] = {acc[a][b + t][0] + bias[a].x, acc[a][b + t][1] + bias[a].y, acc[a][b + t][2] + bias[a].z, acc[a][b + t][3] + bias[a].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = v[j];
+                    if constexpr (ACT == ACT_SILU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                    if constexpr (ACT == ACT_RELU) x = x > 0.f ? x : 0.f;
+                    v[j] = x;
+                }
+                P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+            const u32x2 sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
+            const u32x2 sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+            const u32x4 o4 = {sx.x, sy.x, sx.y, sy.y};
+            const int nn = odd ? n - 4 : n;
+            const bool ok = n < p.Cout && m < p.M;
+            __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, ok ? (m * p.out_cs + p.out_co + nn) * 2 : (int)0x80000000u, 0, 0);
+        }
+    }
+}
+
+struct S2Steps {          // the 18 steps of a 64-channel group: tap, 32-channel half, parity class, position within the class
+    int tap[18], sub[18], cls[18], pos[18], len[18];
+};
+constexpr S2Steps s2_steps() {
+    S2Steps t{};
+    const int taps[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
+    const int ntap[4] = {4, 2, 2, 1};
+    int n = 0;
+    for (int c = 0; c < 4; ++c)
+        for (int sub = 0; sub < 2; ++sub)
+            for (int k = 0; k < ntap[c]; ++k) {
+                t.tap[n] = taps[c][k]; t.sub[n] = sub; t.cls[n] = c; t.pos[n] = sub * ntap[c] + k; t.len[n] = 2 * ntap[c];
+                ++n;
+            }
+    return t;
+}
+
+template <int BP, int BC, int WP, int WC, int NS>
+__global__ __launch_bounds__(256, BP * BC <= 128 * 128 ? 3 : 2) void conv3x3s2_halo_kernel(const ConvP p) {
+    constexpr int KC = 4, ES = 2;
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (0)] = wall_clock64(); } while (0);      // diagnostics (VC_CONV_DBG): phase timestamps like conv_igemm_kernel
+    constexpr int XI = BP / 128 * 5;               // DMA instructions per class: 5 x 256 chunks = 160 pixels of 128 bytes per 128 outputs
+    constexpr int PASS = 64;
+    constexpr int WI = (BC + PASS - 1) / PASS;
+    constexpr int WROWS = WI * PASS;
+    constexpr int WTP = BP / WP, WTC = BC / WC, PT = WTP / 16, CT = WTC / 16;
+    constexpr int ZP = XI * 32 - 1;                // the zero pixel: last pixel of a patch buffer, never reached by a class
+    constexpr int XCH = XI * 256;
+    constexpr uint32_t OOB = 0x80000000u;
+    constexpr S2Steps ST = s2_steps();
+    static_assert(WP * WC == 4 && WTP % 32 == 0 && WTC % 16 == 0, "tile shape");
+    static_assert((NS - 2) * WI + XI <= 63 && NS <= 6, "counted vmcnt");
+    __shared__ __attribute__((aligned(16))) uint4 lds[XCH + NS * WROWS * KC];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int nblk = gridDim.x;
+    const int tiles_c = (p.Cout + BC - 1) / BC;
+    int tile;
+    {
+        const int b = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int TH = p.s2_th, TW = p.s2_tw;          // tile rows x columns (outputs), TH * TW <= BP, (TH + 1) * (TW + 1) <= ZP
+    const int CW = TW + 1;                         // row length of a class in the patch buffer
+    const int Wo = p.Wo, Ho = p.Ho, W = p.W;
+    const int G = p.B * Ho, GR = p.B * p.H;        // rows of the flattened (batch, y) spaces
+    const int ctiles = (Wo + TW - 1) / TW;
+    const int ptile = tile / tiles_c;
+    const int n0 = (tile - ptile * tiles_c) * BC;
+    const int g_top = (ptile / ctiles) * TH;
+    const int x0 = (ptile % ctiles) * TW;
+    const int gr0 = 2 * g_top - 1, c0 = 2 * x0 - 1;   // input row / column of the patch's corner
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int ncg = p.Cin / 64;
+
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.in), 0, (int)((size_t)p.B * p.H * p.W * p.in_cs * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.w), 0, (int)((size_t)((p.Cout + 127) / 128 * 128) * p.Kw * ES), 0x00020000);
+
+    // patch staging: buffer pixel lp = i * CW + j holds patch pixel (2i + rp, 2j + cp) of the class being staged, 8 chunks of 16 B;
+    // lane -> (lp, chunk slot), the class and the channel group only add uniform offsets
+    int xij[XI];                                   // i << 16 | j << 8 | chunk * 16 (i = 255: no such pixel)
+    {
+        const float inv_cw = 1.0f / (float)CW;
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            const int e = (k * 4 + wave) * 64 + lane;
+            const int lp = e >> 3, cpos = e & 7;
+            const int chunk = cpos ^ (((lp >> 1) & 3) << 1);                          // source-side swizzle, see the fragment reads
+            const int i = (int)(((float)lp + 0.5f) * inv_cw);                         // lp < 320: exact
+            const int j = lp - i * CW;
+            xij[k] = ((i <= TH ? i : 255) << 16) | (j << 8) | (chunk * 16);
+        }
+    }
+    const int row_bytes = W * p.in_cs * ES, px_bytes = p.in_cs * ES;
+    const int corner = ((gr0 * W + c0) * p.in_cs + p.in_co) * ES;
+    const int prow = wave * 16 + (lane >> 2);
+    const int wchunk = (lane & 3) ^ ((0x78 >> (((prow >> 2) & 3) * 2)) & 3);
+    uint32_t woff[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) woff[i] = (uint32_t)(((n0 + prow + PASS * i) * p.Kw + wchunk * 8) * ES);
+
+    // fragment addresses: this lane's output pixel (r, c) of every MFMA pixel tile reads buffer pixel (r + dy/2, c + dx/2) of the class
+    // of tap (dy, dx): four addresses per tile.  The only taps that can leave the image are dy = 0 on an image's first row and dx = 0 on
+    // the first column; masked lanes read the zero pixel everywhere.
+    const int wp = wave % WP, wc = wave / WP;
+    const int frow = lane & 15, fch = lane >> 4;
+    int xp[PT];                                    // buffer pixel of (r, c) in every class
+    uint32_t flg = 0;                              // per MFMA tile i, bits 3i .. 3i+2: masked lane, image's first row, first column
+    constexpr uint32_t ZADDR = (uint32_t)ZP * 128;
+    const float inv_tw = 1.0f / (float)TW, inv_ho = 1.0f / (float)Ho;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int q = wp * WTP + i * 16 + frow;                                       // slot of the tile, row-major over TH x TW
+        const int r = (int)(((float)q + 0.5f) * inv_tw);
+        const int c = q - r * TW;
+        const int g = g_top + r, x = x0 + c;
+        const bool ok = r < TH && g < G && x < Wo;
+        int b = (int)((float)g * inv_ho);                                             // image of the row, +-1 fix-up (g < 2^24)
+        b -= (b * Ho > g) ? 1 : 0;
+        b += ((b + 1) * Ho <= g) ? 1 : 0;
+        flg |= ((ok ? 0u : 1u) | (g - b * Ho == 0 ? 2u : 0u) | (x == 0 ? 4u : 0u)) << (3 * i);
+        xp[i] = r * CW + c;
+    }
+    int wfrag[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) wfrag[i] = 16 * lds_slot<4>(wc * WTC + i * 16 + frow, fch);
+
+    f32x4 acc[CT][PT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_inputs_settle<CT * PT>(&acc[0][0]);
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0];
+    constexpr uint32_t XBYTES = XCH * 16, WSTAGE = WROWS * KC * 16;
+    const uint32_t wring = lds_base + XBYTES;
+
+    if (tid < 8) lds[ZP * 8 + tid] = make_uint4(0u, 0u, 0u, 0u);
+
+    // stage class `cls` (row parity cls >> 1, column parity cls & 1) of channel group `cg`
+#define VC_XCLASS(cg, cls)                                                                                            \
+    {                                                                                                                     \
+        const int rp = (cls) >> 1, cp = (cls) & 1;                                                                         \
+        const int add = rp * row_bytes + cp * px_bytes + (cg) * 128;                                                       \
+        const bool live = (cg) < ncg;                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < XI; ++k) {                                                                   \
+            int ij = xij[k];                                                                                               \
+            asm volatile("" : "+v"(ij));               /* opaque: no per-class copies hoisted out of the group loop */      \
+            const int i = ij >> 16, j = (ij >> 8) & 255;                                                                   \
+            const int xo = corner + 2 * i * row_bytes + 2 * j * px_bytes + (ij & 255);                                     \
+            const bool in = live && i <= TH - rp && j <= TW - cp && (unsigned)(gr0 + 2 * i + rp) < (unsigned)GR &&         \
+                            (unsigned)(c0 + 2 * j + cp) < (unsigned)W;                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[(k * 4 + uwave) * 64], 16,                        \
+                                                     in ? xo + add : (int)OOB, 0, 0, 0);                                    \
+        }                                                                                                                 \
+    }
+    // weight tile of step `st` (0 .. 17) of channel group `cg` into ring stage `rs`
+#define VC_WSTEP(cg, st, rs)                                                                                              \
+    {                                                                                                                     \
+        const uint32_t ko = (cg) < ncg ? (uint32_t)((ST.tap[st] * p.Cin + (cg) * 64 + ST.sub[st] * 32) * ES) : OOB;        \
+        _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[XCH + (rs) * WROWS * KC + (PASS * i + uwave * 16) * KC], 16,  \
+                                                     (int)(ko >= OOB ? OOB : woff[i] + ko), 0, 0, 0);                       \
+    }
+
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (1)] = wall_clock64(); } while (0);
+    VC_XCLASS(0, 0);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) VC_WSTEP(0, st, st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (2)] = wall_clock64(); } while (0);
+    int sbuf = NS - 1;
+    uint32_t woffs = wring;
+    for (int cg = 0; cg < ncg; ++cg) {
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int cls = ST.cls[s], tap = ST.tap[s], dy = tap / 3, dx = tap % 3, v = (dy >> 1) * 2 + (dx >> 1);
+            const uint32_t xb = lds_base;
+            { const int s2 = (s + NS - 1) % 18, carry = (s + NS - 1) / 18; VC_WSTEP(cg + carry, s2, sbuf); }
+            sbuf = sbuf + 1 == NS ? 0 : sbuf + 1;
+            u32x4v xr[PT], wr[CT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                // 128-byte pixels: slot = chunk ^ 2 * ((P >> 1) & 3).  A ds_read_b128 lane group holds 8 consecutive-or-nearly pixels of one
+                // 16-byte chunk index and 8 of the next; per half of the 256-byte bank row (pixel parity) that is 4 + 4 pixels whose
+                // (P >> 1) & 3 are all different: 8 different slots for every base pixel.  Computed per step from the tile's one base
+                // pixel (VALU is idle here; 18 steps x PT precomputed addresses cost a wave of occupancy)
+                int P = xp[i];
+                asm volatile("" : "+v"(P));        // opaque: or the addresses of all 18 steps are hoisted out of the group loop
+                P += (v >> 1) * CW + (v & 1);
+                const uint32_t bad = flg & ((1u | (dy == 0 ? 2u : 0u) | (dx == 0 ? 4u : 0u)) << (3 * i));
+                const uint32_t a = bad ? ZADDR + (uint32_t)fch * 16 : (uint32_t)(P * 128 + ((fch ^ (((P >> 1) & 3) << 1)) * 16));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xr[i]) : "v"(xb + (a ^ (uint32_t)(ST.sub[s] << 6))) : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(wr[i]) : "v"(woffs + wfrag[i]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < PT; ++i) asm volatile("" : "+v"(xr[i]));
+#pragma unroll
+            for (int i = 0; i < CT; ++i) asm volatile("" : "+v"(wr[i]));
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) mfma_bf16_inplace(acc[a][b], wr[a], xr[b]);
+            woffs = woffs + WSTAGE == wring + NS * WSTAGE ? wring : woffs + WSTAGE;
+            const bool last_of_class = ST.pos[s] == ST.len[s] - 1;
+            if (last_of_class) {
+                // the one patch buffer: every wave is done with this class's taps (barrier), then the next class is fetched and waited
+                // for with everything before it (the ring's tiles are older) -- the other workgroups of the CU fill the gap
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI) : "memory");
+                if (cls < 3 || cg + 1 < ncg) {
+                    __builtin_amdgcn_s_barrier();
+                    if (cls < 3) { VC_XCLASS(cg, cls + 1); } else { VC_XCLASS(cg + 1, 0); }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * WI) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mfma_results_settle<CT * PT>(&acc[0][0]);
+    do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (3)] = wall_clock64(); } while (0);
+#undef VC_XCLASS
+#undef VC_WSTEP
+    const int nbase = n0 + wc * WTC + fch * 4;
+    int mrow[PT];                                  // this lane's output pixel per MFMA tile (M = none)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int q = wp * WTP + i * 16 + frow;
+        const int r = (int)(((float)q + 0.5f) * inv_tw);
+        mrow[i] = (flg >> (3 * i)) & 1u ? p.M : (g_top + r) * Wo + x0 + q - r * TW;
+    }
+    if (p.act == ACT_SILU) conv_epilogue_bf16_rows<PT, CT, ACT_SILU>(p, acc, mrow, nbase);
+    else if (p.act == ACT_RELU) conv_epilogue_bf16_rows<PT, CT, ACT_RELU>(p, acc, mrow, nbase);
+    else conv_epilogue_bf16_rows<PT, CT, ACT_NONE>(p, acc, mrow, nbase);
+    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (4)] = wall_clock64(); } while (0); }
+}
+
 // ---- 1x1 / stride 1 with the weights in registers (bf16) -------------------------------------------------------------------
 // The narrow pointwise layers (K <= 128) are bound by everything but the matrix work: two K tiles per output tile, each with its
 // DMA issue, vmcnt wait and workgroup barrier, around 16 MFMAs.  With K*N this small a wave can keep its share of the weight
@@ -941,13 +1227,18 @@ double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * 
 // 202 -> 148 us, 1x1 512->512 at 20^2 67 -> 56 us; 256 x 128, 512 x 128 and 512 x 64 tiles with 8 / 16 waves gained nothing)
 // 43: the same tile on 128-byte rows (2 x 64 KB): the only 256 x 256 tile of the fp8 path (its K = 128 MFMA step needs KC = 8)
 #define VC_CONV_BIG_CFGS(X) X(40, 256, 256, 4, 4, 4, 2) X(41, 256, 256, 4, 4, 4, 3) X(42, 256, 256, 4, 4, 4, 4) X(43, 256, 256, 4, 4, 8, 2)
+// halo-staged 3x3 / s2 / p1 (bf16), rectangular tiles of BP pixels: V(index, BP, BC, WP, WC, NS)
+// (measured on YOLOv5s, 128 frames: 3-P3 64->128 at 80^2 0.253 -> 0.198 ms with 256-pixel tiles, 18-P4 128->128 0.117 -> 0.096, 5-P4 a tie;
+// the 20^2 layers stay on the 256 x 256 implicit GEMM; 2 x 2 waves on 256 pixels never won)
+#define VC_S2HALO_CFGS(V) V(44, 128, 128, 2, 2, 2) V(45, 128, 128, 2, 2, 3) V(46, 256, 128, 4, 1, 3) V(47, 128, 128, 2, 2, 4) \
+                          V(48, 128, 256, 2, 2, 2) V(49, 256, 128, 4, 1, 2)
 struct ConvCfg { int bp, bc, wp, wc, kc, ns; };
 #define VC_X(i, bp, bc, wp, wc, kc, ns) {bp, bc, wp, wc, kc, ns},
 static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
 // weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
 #define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35) and the 16-wave 256 x 256 tiles (40-42)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43) and the halo-staged 3x3/s2 (44-49)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 template <class K>
@@ -1035,6 +1326,41 @@ static int launch_halo(ConvP p, hipStream_t s) {
     return VC_OK;
 }
 
+// tile rectangle of the stride-2 halo kernel: the th x tw (th * tw <= 128) whose parity classes ((th + 1) x (tw + 1) pixels) fit the patch
+// buffer and that covers the map with the fewest tiles (then the smallest patch): 8 x 16 at 80 columns, 16 x 8 at 40, 25 x 5 at 20
+// (the row space is batch * Ho deep)
+static bool s2halo_geom(const ConvP& p, int bp, int* th_out, int* tw_out) {
+    const long G = (long)p.B * p.Ho;
+    long best = -1;
+    for (int tw = 1; tw <= std::min(p.Wo, 254); ++tw) {
+        const int th = (int)std::min<long>(std::min(bp / tw, 254), G);
+        const int cls = (th + 1) * (tw + 1);
+        if (th < 1 || cls > bp / 128 * 5 * 32 - 1) continue;
+        const long tiles = (long)((p.Wo + tw - 1) / tw) * ((G + th - 1) / th);
+        const long cost = tiles * 4096 + cls;
+        if (best < 0 || cost < best) { best = cost; *th_out = th; *tw_out = tw; }
+    }
+    return best >= 0;
+}
+static bool s2halo_applicable(const ConvP& p) {
+    if (p.prec != PREC_BF16 || p.kh != 3 || p.kw != 3 || p.sh != 2 || p.sw != 2 || p.ph != 1 || p.pw != 1) return false;
+    if (p.Cin % 64 != 0 || p.in_cs % 8 != 0 || p.in_co % 8 != 0 || p.H != 2 * p.Ho || p.W != 2 * p.Wo) return false;
+    if (p.out_f32 || p.res_mode != RES_NONE || p.split != 0 || p.m_dev || p.Cout % 8 != 0 || p.out_cs % 8 != 0 || p.out_co % 8 != 0) return false;
+    return p.act == ACT_SILU || p.act == ACT_RELU || p.act == ACT_NONE;
+}
+template <int BP, int BC, int WP, int WC, int NS>
+static int launch_s2halo(ConvP p, hipStream_t s) {
+    static const bool enabled = !(getenv("VC_CONV_S2HALO") && atoi(getenv("VC_CONV_S2HALO")) == 0);   // A/B switch
+    if (!enabled || !s2halo_applicable(p) || !s2halo_geom(p, BP, &p.s2_th, &p.s2_tw)) return VC_ERR_ARG;  // quietly, like launch_halo
+    const long G = (long)p.B * p.Ho;
+    const long tiles = (long)((p.Wo + p.s2_tw - 1) / p.s2_tw) * ((G + p.s2_th - 1) / p.s2_th) * ((p.Cout + BC - 1) / BC);
+    p.Kw = p.Kp;
+    p.ntiles = (int)tiles;
+    launch_timed(p, conv3x3s2_halo_kernel<BP, BC, WP, WC, NS>, dim3((unsigned)tiles), dim3(256), 0, s, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 static bool direct1x1_applicable(const ConvP& p, int ct, int ks) {
     if (p.prec != PREC_BF16 || p.kh != 1 || p.kw != 1 || p.sh != 1 || p.sw != 1 || p.ph != 0 || p.pw != 0) return false;
     if (p.Cin != ks * 32 || p.K != p.Cin || p.Ho != p.H || p.Wo != p.W || p.in_cs % 8 != 0 || p.in_co % 8 != 0) return false;
@@ -1071,6 +1397,9 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #define VC_Y(i, bp, bc, wp, wc, ns) case i: return launch_halo<bp, bc, wp, wc, ns>(p, s);
         VC_HALO_CFGS(VC_Y)
 #undef VC_Y
+#define VC_V(i, bp, bc, wp, wc, ns) case i: return launch_s2halo<bp, bc, wp, wc, ns>(p, s);
+        VC_S2HALO_CFGS(VC_V)
+#undef VC_V
 #define VC_Z(i, ct, ks, pt, occ) case i: return launch_direct1x1<ct, ks, pt, occ>(p, s);
         VC_DIRECT_CFGS(VC_Z)
 #undef VC_Z

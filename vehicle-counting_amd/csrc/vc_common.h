@@ -137,6 +137,7 @@ struct ConvP {
                          // know, e.g. the sparse Detect head): the kernel processes min(M, *m_dev) pixels; M bounds the launch.  Only the
                          // implicit-GEMM family (conv_igemm_kernel) honours it
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
+    int s2_th, s2_tw;    // set by the launcher of conv3x3s2_halo_kernel: its output tile rectangle (rows x columns)
     int ablate;          // diagnostics only (VC_CONV_ABLATE, timing experiments with wrong results): 1 = no staging DMA after the first tiles,
                          // 2 = no output stores, 3 = both, 6 = return at once (launch floor of the grid); per-phase times come from dbg
 };
