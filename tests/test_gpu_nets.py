@@ -164,12 +164,16 @@ for H, W in ((640, 640), (360, 640), (416, 352)):
     fr = synth_frames(3, H, W, n_obj=6, seed=5)
     eng = E.Engine(sd, None, precision="bf16", num_classes=8, max_batch=3, max_frame_hw=(H, W))
     eng.detect([f[:, :, ::-1] for f in fr])
-    a = [eng.debug_layer(l, batch=3) for l in (4, 17)]
+    a = [eng.debug_layer(l, batch=3) for l in (4, 17)]          # last Bottleneck + cv3 in one kernel (bneck_fused_kernel<true>)
+    eng.set_option("bneck_cv3", 0)
+    eng.detect([f[:, :, ::-1] for f in fr])
+    c = [eng.debug_layer(l, batch=3) for l in (4, 17)]          # Bottlenecks fused, cv3 a launch of its own
     eng.set_option("bneck_fused", 0)
     eng.detect([f[:, :, ::-1] for f in fr])
-    b = [eng.debug_layer(l, batch=3) for l in (4, 17)]
-    for x, y in zip(a, b):
+    b = [eng.debug_layer(l, batch=3) for l in (4, 17)]          # every conv a launch of its own
+    for x, z, y in zip(a, c, b):
         assert x.shape == y.shape and np.abs(y).max() > 0.1
+        assert np.array_equal(z, y), (H, W, float((z == y).mean()))
         assert np.array_equal(x, y), (H, W, float((x == y).mean()))
     eng.close()
 print("BNECK_OK")
@@ -177,7 +181,8 @@ print("BNECK_OK")
 
 
 def test_bneck_fused_bit_identical():
-    """bneck_fused.hip (a 64-channel Bottleneck, 1x1 + 3x3 [+ shortcut], in one kernel with b1 in LDS) against the two launches it
+    """bneck_fused.hip (a 64-channel Bottleneck, 1x1 + 3x3 [+ shortcut], in one kernel with b1 in LDS; for the last Bottleneck of a
+    block also the block's cv3 on the tile, m never leaving the registers) against the launches it
     replaces, at the outputs of the blocks that contain it: layer 4 (both bottlenecks of the second backbone C3, with the shortcut)
     and layer 17 (the P3 head C3, without), tiles hanging over the edges included.  Bit for bit against the implicit-GEMM form of the
     3x3 (same tap-major k order): the comparison runs in its own process with VC_AUTOTUNE=0, because the halo-staged 3x3 variants the

@@ -505,6 +505,25 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     break;
                 }
                 const bool bneck_fused_on = e->opt.bneck_fused != 0;
+                if (bneck_fused_on && e->opt.bneck_cv3 != 0 && oi + 2 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV &&
+                    bneck_cv3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv)) {   // the last 64-channel Bottleneck of a C3 + the block's cv3 in one kernel
+                    const ConvP &o2 = ops[oi + 1].conv, &o3 = ops[oi + 2].conv;
+                    const double flb = fl + 2.0 * o2.M * (double)o2.Cout * ops[oi + 1].C + 2.0 * o3.M * (double)o3.Cout * ops[oi + 2].C;
+                    const double byb = ((double)cp.B * cp.H * cp.W * (cp.Cin + 64) + (double)cp.Cout * cp.K + (double)o2.Cout * o2.K + (double)o3.Cout * o3.K) * es + (double)o3.M * o3.Cout * es;
+                    cp.cfg = 105;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flb; e->prof_pairs[e->prof_used - 1].bytes = byb; }
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, flb, byb, s);
+                        VC_TRY(launch_bneck_cv3_fused(cp, o2, o3, s));
+                    }
+                    if (e->profiling && e->op_log.size() < (1u << 20)) {
+                        char line[256];
+                        snprintf(line, sizeof(line), "conv M=%d N=%d K=%d k=3x3 s=1 cfg=105 ms=%.4f tflops=%.1f\n", cp.M, 128, 768, e->last_ms, flb / (e->last_ms * 1e-3) / 1e12);
+                        e->op_log += line;
+                    }
+                    oi += 2;                                                  // the 3x3 conv and cv3 are done
+                    break;
+                }
                 if (bneck_fused_on && nx && nx->kind == Op::CONV && bneck_fused_applicable(cp, nx->conv)) {   // 64-channel Bottleneck in one kernel (bneck_fused.hip)
                     const ConvP& o2 = nx->conv;
                     const double flb = fl + 2.0 * o2.M * (double)o2.Cout * nx->C;
@@ -810,7 +829,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     e->act_scale = getenv("VC_FP8_ACT_SCALE") ? (float)atof(getenv("VC_FP8_ACT_SCALE")) : 1.0f;
     {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-        e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1);
+        e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
         e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1);
     }
@@ -987,6 +1006,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     const std::string n = name;
     if (n == "c3_fused") e->opt.c3_fused = value;
     else if (n == "bneck_fused") e->opt.bneck_fused = value;
+    else if (n == "bneck_cv3") e->opt.bneck_cv3 = value;
     else if (n == "front_fused") e->opt.front_fused = value;
     else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
     else if (n == "sparse_head") e->opt.sparse_head = value;

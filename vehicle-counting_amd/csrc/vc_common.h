@@ -165,6 +165,8 @@ bool c3_fused_applicable(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, c
 int launch_c3_fused(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, const ConvP& p3, hipStream_t s);
 bool bneck_fused_applicable(const ConvP& pm1, const ConvP& pm2);                                     // bneck_fused.hip: a 64-channel Bottleneck (1x1 + 3x3 [+ shortcut]) in one kernel
 int launch_bneck_fused(const ConvP& pm1, const ConvP& pm2, hipStream_t s);
+bool bneck_cv3_fused_applicable(const ConvP& pm1, const ConvP& pm2, const ConvP& p3);                // the same + the C3's cv3 (1x1 over [m | y2], 128 -> 128) on the tile
+int launch_bneck_cv3_fused(const ConvP& pm1, const ConvP& pm2, const ConvP& p3, hipStream_t s);
 bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)

@@ -74,7 +74,7 @@ class Engine:
         L.check(L.lib().vc_engine_sync(self._h))
 
     def set_option(self, name, value):
-        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "front_fused", "crop_per_pixel", "dot_arena_mb")."""
+        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "crop_per_pixel", "dot_arena_mb")."""
         L.check(L.lib().vc_engine_set_option(self._h, name.encode(), int(value)))
 
     def stream_reset(self):
