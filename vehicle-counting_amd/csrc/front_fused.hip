@@ -214,6 +214,8 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         // even columns 0 .. 30; tile 33 + r = row r, odd columns 1 .. 31; tiles 66 .. 68 = the 33 pixels of column 32, one row per lane.
         // LDS slot of a pixel: plane (column parity) * 561 + row * 17 + column / 2, as before. ------------------------------------------
         const bool interior = gy0 >= 0 && gy0 + FF_RH <= H0 && gx0 >= 0 && gx0 + 2 * FF_TW + 1 <= W0;     // block-uniform: no zero padding of layer 0 in this tile
+        // (four pixel tiles per pass and wave -- twice the independent work per dependency chain -- measured 0.535 against 0.528 ms: the passes
+        // already overlap)
         for (int tb = wave * 2; tb < FF_NT0R && !(abl & 16); tb += 2 * FF_NW) {    // two pixel tiles per pass and wave
             int ly[2], lx[2], slot[2];
             bool live[2];
