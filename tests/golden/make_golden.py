@@ -251,6 +251,93 @@ def gen_counting():
         json.dump(json.load(open(zone_path)), f, indent=1)
 
 
+def gen_overlay_calls():
+    """Visualisation egress: the reference's own drawing code (utilities/counting/utils.py draw_anno /
+    visualize_one_frame / draw_text / draw_frame_count / count_frame_directions, driven like the body of visualize_merged :307-331)
+    executed against a RECORDING cv2: every cv2 call it makes, in order, with its arguments.  OpenCV is not installed, so the pixels
+    cannot be pinned; the call list -- what is drawn, where, in which colour / thickness / order, including the one-frame delay of the
+    count text -- can.  cv2.getTextSize answers with the metric of the 5 x 7 substitute font (advance 6, height 7, at scale
+    max(1, round(2 * fontScale))): the reference lays its header boxes and text lines out from whatever the font reports."""
+    import types
+    import pandas as pd
+    calls = []
+
+    def _pt(p):
+        return [int(p[0]), int(p[1])]
+
+    def _col(c):
+        return [int(v) for v in c]
+
+    class _Rec(types.ModuleType):
+        FONT_HERSHEY_SIMPLEX, FONT_HERSHEY_PLAIN, LINE_AA = 0, 1, 16
+
+        def line(self, img, p0, p1, color, thickness=1, *a, **k):
+            calls.append(["line", _pt(p0), _pt(p1), _col(color), int(thickness)]); return img
+
+        def circle(self, img, c, r, color, thickness=1, *a, **k):
+            calls.append(["circle", _pt(c), int(r), _col(color), int(thickness)]); return img
+
+        def rectangle(self, img, c1, c2, color, thickness=1, *a, **k):
+            calls.append(["rectangle", _pt(c1), _pt(c2), _col(color), int(thickness)]); return img
+
+        def polylines(self, img, pts, closed, color, thickness=1, *a, **k):
+            calls.append(["polylines", [[_pt(q.reshape(-1)) for q in p] for p in pts], bool(closed), _col(color), int(thickness)]); return img
+
+        def putText(self, img, text, org, fontFace, fontScale, color, thickness=1, lineType=8, *a, **k):
+            calls.append(["putText", str(text), _pt(org), int(fontFace), float(fontScale), _col(color), int(thickness)]); return img
+
+        def getTextSize(self, text, fontFace, fontScale, thickness):
+            s = max(1, int(round(2.0 * float(fontScale))))
+            return (max(len(text) * 6 - 1, 0) * s, 7 * s), 0
+
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = _Rec("cv2")
+    for k in [k for k in sys.modules if k.startswith("ref_counting")]:
+        del sys.modules[k]
+    try:
+        cu = _refimport.load_counting_utils()
+        zone, dirs = cu.load_zone_anno(os.path.join(_refimport.REF, "demo", "sample", "cam_04.json"))
+        dirs = {"01": dirs["01"], "02": [[900.0, 300.0], [600.0, 600.0]]}           # the sample file has one direction; a second one for the counts
+        hw = (720, 1280)
+        img = np.zeros(hw + (3,), np.uint8)
+        rows = []
+        for f in (1, 2, 3):
+            rows.append(dict(track_id=1, frame_id=f, box=str([100 + 10 * f, 200, 180 + 10 * f, 300]), color=str((10, 200, 30)), label=0, direction=1,
+                             fpoint=str((150.0, 250.0)), lpoint=str((170.0, 250.0)), fframe=1, lframe=3))
+        for f in (2, 3):
+            rows.append(dict(track_id=2, frame_id=f, box=str([400, 100 + 5 * f, 460, 190 + 5 * f]), color=str((250, 20, 20)), label=1, direction=2,
+                             fpoint=str((430.0, 155.0)), lpoint=str((430.0, 160.0)), fframe=2, lframe=3))
+        rows.append(dict(track_id=11, frame_id=3, box=str([5, 3, 40.7, 60.2]), color=str((1, 2, 3)), label=1, direction=1,
+                         fpoint=str((22.9, 31.6)), lpoint=str((22.9, 31.6)), fframe=3, lframe=3))
+        df = pd.DataFrame(rows)
+        count = {int(d): {label: 0 for label in range(2)} for d in dirs}          # :301-305
+        prev_text = None
+        frames = []
+        for frame_id in (1, 2, 3, 4):                                              # the body of :312-331
+            del calls[:]
+            tmp = df[df.frame_id.astype(int) == frame_id]
+            count, text = cu.count_frame_directions(tmp, count)
+            im = cu.draw_anno(img, zone, dirs)
+            if len(tmp) > 0:
+                im = cu.visualize_one_frame(im, tmp)
+            if prev_text:
+                im = cu.draw_text(im, prev_text)
+            prev_text = text
+            im = cu.draw_frame_count(im, frame_id)
+            frames.append({"frame_id": frame_id, "calls": json.loads(json.dumps(calls)), "count_text": text})
+        out = {"hw": list(hw), "zone": zone, "directions": dirs, "rows": rows, "frames": frames,
+               "counts": {str(d): [count[d][c] for c in range(2)] for d in count}}
+    finally:
+        if saved is not None:
+            sys.modules["cv2"] = saved
+        else:
+            del sys.modules["cv2"]
+        for k in [k for k in sys.modules if k.startswith("ref_counting")]:
+            del sys.modules[k]
+    with open(os.path.join(HERE, "overlay_calls.json"), "w") as f:
+        json.dump(out, f, indent=None, separators=(",", ":"))
+
+
 if __name__ == "__main__":
-    gen_kalman(); gen_nms(); gen_iou(); gen_cosine(); gen_assignment(); gen_tracker_traces(); gen_reid(); gen_counting()
+    gen_kalman(); gen_nms(); gen_iou(); gen_cosine(); gen_assignment(); gen_tracker_traces(); gen_reid(); gen_counting(); gen_overlay_calls()
     print("golden fixtures written to", HERE)

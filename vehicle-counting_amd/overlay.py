@@ -3,7 +3,8 @@
 The host side follows the reference's draw_* helpers call by call and turns each call into primitives (line, disc, rectangle, filled
 box, glyph); `vc_overlay` rasterises them on the device, one workgroup per frame, in order.  The reference rasterises with OpenCV
 (anti-aliased Hershey fonts); OpenCV is not available here, so the PIXELS are not pinned against it -- the primitive list is the
-parity surface (tests/test_overlay.py), and the device rasteriser is pinned against the NumPy rasteriser in the tests.  Text uses one
+parity surface: tests/test_overlay.py compares it with the display list of the reference's own drawing code (recorded cv2 calls,
+tests/golden/overlay_calls.json, through oracle/overlay.py), and the device rasteriser is pinned against the NumPy rasteriser.  Text uses one
 5 x 7 bitmap alphabet (lower case is drawn with the capital glyphs); a text scale s maps OpenCV's fontScale as max(1, round(2 * fontScale))."""
 from __future__ import annotations
 
