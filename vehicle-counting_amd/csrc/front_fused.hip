@@ -354,6 +354,8 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_fused_kernel<true>, FF_NW * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         return per_cu * cus;
     }();
+    // (tiles handed out by an atomic counter instead of the static stride -- late-starting workgroups, e.g. behind the tracker's, would not carry
+    // a full share -- measured 7.09 against 7.13 ms per bench step over five alternating runs: inside the spread, not kept)
     const int grid = std::min(ntiles, std::max(256, slots_hw - slots_reserve));   // persistent: every workgroup walks tiles; at one workgroup per CU nothing is held back (as in launch_one)
     const uint4* x = (const uint4*)p0.in;
     uint16_t* y = (uint16_t*)p1.out;
