@@ -160,9 +160,13 @@ int vc_videotracker_run(vc_engine* e, const int* trackers, int num_classes, cons
 /* vc_stream_submit enqueues the detector for a batch and returns at once (at most two outstanding); vc_stream_run consumes
  * submissions in order (submitting itself when none is pending), so `submit(i+1); run(i)` overlaps detect(i+1) with track(i). */
 int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w);
-/* The same for frames in (pinned) HOST memory, as the reference's loader delivers them (modules/datasets.py:47-61): the batch is copied
- * to a device staging slot on the engine's copy stream, overlapped with the detector of the previous batch; *frames_dev_out is the
- * device address to hand to vc_stream_run / vc_stream_run_async for this batch (valid until its rows have been collected). */
+/* Frames in (pinned) HOST memory, as the reference's loader delivers them (modules/datasets.py:47-61).  vc_stream_stage_host copies the
+ * batch to one of four device staging slots on the engine's copy stream and returns at once; *frames_dev_out is the device address to
+ * hand to vc_stream_submit and then vc_stream_run / vc_stream_run_async for this batch (valid until its rows have been collected; at
+ * most four host batches may be alive).  vc_stream_submit of a staged address enqueues the detector behind the copy.  Staging one
+ * batch further ahead than submitting -- stage(i+2); submit(i+1); run(i); collect(i-1) -- puts the PCIe copy under the detector of the
+ * batch before.  vc_stream_submit_host = stage + submit in one call (the copy then sits in front of its own detector). */
+int vc_stream_stage_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out);
 int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out);
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,
                   int64_t* out_rows6, int cap_rows_per_frame, int* out_m /* b */, int* out_ndet /* b, may be NULL */);

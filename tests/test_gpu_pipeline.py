@@ -33,7 +33,7 @@ def test_csv_parity(golden_dir, tmp_path):
     cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
     args = types.SimpleNamespace(weight=None, mapping=None, output_path=str(tmp_path))
     cam_cfg = {"cam": {"cam_04": {"tracking_config": TRACK_CFG}}}
-    for mode in ("loop", "stream", "stream_async", "frame_sharded"):
+    for mode in ("loop", "stream", "stream_async", "stream_async_host", "stream_host", "frame_sharded"):
         eng = E.Engine(ysd, rsd, precision="f32", num_classes=NC, max_batch=8, max_frame_hw=(H, W), max_crops=512,
                        max_tracks=1024, nn_budget_cap=60)
         pipe = CountingPipeline(args, cfg, cam_cfg, engine=eng, class_names=[f"c{i}" for i in range(NC)])
@@ -42,8 +42,8 @@ def test_csv_parity(golden_dir, tmp_path):
             rows, counts = pipe.run(src, "cam_04", zone)
         elif mode == "frame_sharded":                    # SURVEY.md 8f.1 driver on one rank: detect + embed + external-feature tracker
             rows, counts = pipe.run_frame_sharded(src, "cam_04", zone, chunk=4)
-        else:
-            rows, counts = pipe.run_stream(src, "cam_04", zone, batch=4 if mode == "stream_async" else 8, asynchronous=mode == "stream_async")
+        else:                                           # "_host": frames stay in pinned host memory, staged two batches ahead (5 / 3 batches)
+            rows, counts = pipe.run_stream(src, "cam_04", zone, batch=4 if "async" in mode else 8, asynchronous="async" in mode, host_frames=mode.endswith("_host"))
         # track_id / label / frame / direction / first-last frame exact; boxes within 1 px (int truncation of an fp64 state
         # that only depends on fp32-identical detections); fpoint/lpoint within 0.5
         assert key(rows) == key(ref_rows), mode
@@ -115,14 +115,15 @@ def test_count_allgather_through_the_c_abi():
 
 
 def test_host_frames_ingest_same_rows():
-    """vc_stream_submit_host (pinned host frames copied on the engine's copy stream, four staging slots) returns exactly the rows
-    of the device-resident path, batch after batch, with the copies of later batches overlapping the work of earlier ones."""
+    """vc_stream_submit_host / vc_stream_stage_host (pinned host frames copied on the engine's copy stream, four staging slots) return
+    exactly the rows of the device-resident path, batch after batch, with the copies of later batches overlapping the work of earlier
+    ones -- staged one batch ahead of the submission (the bench's host-frames path) as well as stage + submit in one call."""
     import torch
     B, H, W, NB = 8, 360, 640, 6
     frames = synth_frames(B * NB, H, W, n_obj=8, seed=13)
     ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
     out = {}
-    for mode in ("device", "host"):
+    for mode in ("device", "host", "staged"):
         eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W), max_crops=B * 64, max_tracks=2048, nn_budget_cap=60)
         trk = [eng.tracker_create(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
                for _ in range(NC)]
@@ -130,16 +131,25 @@ def test_host_frames_ingest_same_rows():
         host = torch.from_numpy(frames).pin_memory()
         ptrs = {}
 
+        def stage(i):
+            ptrs[i] = eng.stream_stage_host(host[i * B:(i + 1) * B].data_ptr(), B, H, W)
+
         def submit(i):
             if mode == "host":
                 ptrs[i] = eng.stream_submit_host(host[i * B:(i + 1) * B].data_ptr(), B, H, W)
+            elif mode == "staged":                                  # the copy one batch further ahead than the detector
+                eng.stream_submit(ptrs[i], B, H, W)
             else:
                 ptrs[i] = dev[i * B:(i + 1) * B].data_ptr()
                 eng.stream_submit(ptrs[i], B, H, W)
 
         got = []
+        if mode == "staged":
+            stage(0); stage(1)
         submit(0)
         for i in range(NB):
+            if mode == "staged" and i + 2 < NB:
+                stage(i + 2)
             if i + 1 < NB:
                 submit(i + 1)
             eng.stream_run_async(trk, ptrs[i], B, H, W)
@@ -149,7 +159,19 @@ def test_host_frames_ingest_same_rows():
         out[mode] = got
         eng.close()
     assert sum(len(r[0]) for r in out["device"]) > 20
-    for (r0, f0, n0), (r1, f1, n1) in zip(out["device"], out["host"]):
-        np.testing.assert_array_equal(n0, n1)
-        np.testing.assert_array_equal(f0, f1)
-        np.testing.assert_array_equal(r0, r1)
+    for other in ("host", "staged"):
+        for (r0, f0, n0), (r1, f1, n1) in zip(out["device"], out[other]):
+            np.testing.assert_array_equal(n0, n1)
+            np.testing.assert_array_equal(f0, f1)
+            np.testing.assert_array_equal(r0, r1)
+    # a fifth host batch while four are alive is refused (its staging slot still belongs to an uncollected batch)
+    eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W), max_crops=B * 64, max_tracks=2048, nn_budget_cap=60)
+    host = torch.from_numpy(frames).pin_memory()
+    for i in range(4):
+        eng.stream_stage_host(host[i * B:(i + 1) * B].data_ptr(), B, H, W)
+    from vehicle_counting_amd._lib import VcError
+    with pytest.raises(VcError):
+        eng.stream_stage_host(host[4 * B:5 * B].data_ptr(), B, H, W)
+    eng.stream_reset()
+    eng.stream_stage_host(host[:B].data_ptr(), B, H, W)               # after a reset the slots are free again
+    eng.close()

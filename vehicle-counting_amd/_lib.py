@@ -8,6 +8,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# hardware queues of the HIP runtime: the engine's four streams must not share one (see vc_engine_create); a default, set as early as
+# possible because the runtime reads it when it builds its queue pool
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(_HERE, "libvcount_hip.so")   # override: A/B runs of two builds on one box
 
 VC_OK = 0
@@ -81,6 +84,7 @@ SIGNATURES = {
     "vc_stream_run": [_vp, _pi, _i, _vp, _i, _i, _i, _pl, _i, _pi, _pi],
     "vc_stream_inject": [_vp, _pf, _pi, _i, _i],
     "vc_stream_submit": [_vp, _vp, _i, _i, _i],
+    "vc_stream_stage_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_submit_host": [_vp, _vp, _i, _i, _i, _P(_vp)],
     "vc_stream_run_async": [_vp, _pi, _i, _vp, _i, _i, _i, _i],
     "vc_stream_collect": [_vp, _pl, _i, _pi, _pi, _i],

@@ -141,6 +141,7 @@ struct vc_engine {
     uint8_t* d_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ingest[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned ingest_seq = 0;
+    bool ingest_staged[4] = {false, false, false, false};   // copied (or being copied) by vc_stream_stage_host, not yet submitted
     // stream path: three feature / crop buffers -- the batch being tracked (tracker stream), the batch
     // whose ReID is running, and the one after it
     float* d_feat2[3] = {nullptr, nullptr, nullptr};
@@ -160,7 +161,7 @@ struct vc_engine {
     std::vector<Pending> pending;
     // asynchronous tracking (vc_stream_run_async / vc_stream_collect): a batch's tracker work is one kernel on the tracker stream;
     // the job remembers which staging slot its rows will land in
-    struct AsyncJob { int stage = 0, b = 0, cap = 0; std::vector<int> ndet; };
+    struct AsyncJob { int stage = 0, b = 0, cap = 0; std::vector<int> ndet; const void* frames = nullptr; };
     std::deque<AsyncJob> jobs;                   // submission order; front = next to collect
 
     // ---- ReID ---------------------------------------------------------------------------------------

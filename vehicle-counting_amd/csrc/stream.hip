@@ -78,6 +78,11 @@ int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w) 
     VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "engine not finalized");
     VC_CHECK(e->pending.size() < 2, VC_ERR_STATE, "two submissions are already in flight: call vc_stream_run first");
     VC_HIP(hipSetDevice(e->cfg.device));
+    for (int i = 0; i < 4; ++i)                          // a batch staged by vc_stream_stage_host: the detector starts behind its copy
+        if (e->d_ingest[i] && frames_dev == e->d_ingest[i] && e->ingest_staged[i]) {
+            VC_HIP(hipStreamWaitEvent(e->dstream, e->ev_ingest[i], 0));
+            e->ingest_staged[i] = false;
+        }
     const int slot = (int)(e->submit_seq++ & 1);
     const int md = e->cfg.max_det;
     VC_TRY(run_detector_dev(e, (const uint8_t*)frames_dev, b, h, w, /*swap_rb=*/true));
@@ -92,15 +97,17 @@ int vc_stream_submit(vc_engine* e, const void* frames_dev, int b, int h, int w) 
 }
 
 // Ingest from host memory (the reference decodes on the host and hands numpy frames over, modules/datasets.py:47-61):
-// the batch is copied into one of four device staging slots on the engine's copy stream while the detector works on the batch
-// before it, and the detector is enqueued behind the copy.  *frames_dev_out receives the device address to pass to
+// vc_stream_stage_host copies the batch into one of four device staging slots on the engine's copy stream and returns; a later
+// vc_stream_submit of the returned address enqueues the detector behind the copy.  Staged ONE BATCH FURTHER AHEAD than it is submitted
+// (stage i + 2, submit i + 1, run i, collect i - 1) the copy runs under the detector of the batch before it; vc_stream_submit_host
+// (stage + submit in one call) leaves the copy in front of its own detector, overlapped only with the ReID of the batch before --
+// 157 MB per 128 frames of 640 x 640 is 3 - 5 ms of PCIe in front of a 7 ms step.  *frames_dev_out receives the device address to pass to
 // vc_stream_run / vc_stream_run_async for this batch.  `frames_host` should be pinned (hipHostMalloc / hipHostRegister / torch
 // pin_memory) for the copy to overlap; it may be reused as soon as the call returns only if it is pinned AND the caller keeps
 // it untouched until the batch's rows have been collected -- plain pageable memory is copied synchronously by the runtime.
-int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out) {
+int vc_stream_stage_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out) {
     VC_CHECK(e && frames_host && frames_dev_out, VC_ERR_ARG, "null argument");
     VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "engine not finalized");
-    VC_CHECK(e->pending.size() < 2, VC_ERR_STATE, "two submissions are already in flight: call vc_stream_run first");
     VC_CHECK(b >= 1 && b <= e->cfg.max_batch && h >= 1 && w >= 1 && h <= e->cfg.max_frame_h && w <= e->cfg.max_frame_w, VC_ERR_CAPACITY,
              "batch of %d frames %dx%d exceeds max_batch / max_frame_h / max_frame_w", b, h, w);
     VC_HIP(hipSetDevice(e->cfg.device));
@@ -112,12 +119,25 @@ int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h
             VC_HIP(hipEventCreateWithFlags(&e->ev_ingest[i], hipEventDisableTiming));
         }
     }
-    const int slot = (int)(e->ingest_seq++ & 3);       // <= 2 submissions + <= 2 uncollected batches are alive: the fifth reuses the first's slot
+    // four slots: one batch staged ahead + <= 2 submissions + the batch whose rows are still to be collected
+    const int slot = (int)(e->ingest_seq & 3);
+    VC_CHECK(!e->ingest_staged[slot], VC_ERR_STATE, "four host batches are staged and none has been submitted: call vc_stream_submit");
+    for (const auto& pd : e->pending)
+        VC_CHECK(pd.frames != e->d_ingest[slot], VC_ERR_STATE, "the staging slot's previous batch is still waiting for vc_stream_run: at most four host batches may be alive");
+    for (const auto& job : e->jobs)                      // its crops may still be being cut on the ReID stream
+        VC_CHECK(job.frames != e->d_ingest[slot], VC_ERR_STATE, "the staging slot's previous batch has not been collected: at most four host batches may be alive");
+    ++e->ingest_seq;
     VC_HIP(hipMemcpyAsync(e->d_ingest[slot], frames_host, bytes, hipMemcpyHostToDevice, e->cstream));
     VC_HIP(hipEventRecord(e->ev_ingest[slot], e->cstream));
-    VC_HIP(hipStreamWaitEvent(e->dstream, e->ev_ingest[slot], 0));
+    e->ingest_staged[slot] = true;
     *frames_dev_out = e->d_ingest[slot];
-    return vc_stream_submit(e, e->d_ingest[slot], b, h, w);
+    return VC_OK;
+}
+
+int vc_stream_submit_host(vc_engine* e, const uint8_t* frames_host, int b, int h, int w, void** frames_dev_out) {
+    VC_CHECK(e && e->pending.size() < 2, e ? VC_ERR_STATE : VC_ERR_ARG, "two submissions are already in flight: call vc_stream_run first");
+    VC_TRY(vc_stream_stage_host(e, frames_host, b, h, w, frames_dev_out));
+    return vc_stream_submit(e, *frames_dev_out, b, h, w);
 }
 
 }  // extern "C"
@@ -297,7 +317,7 @@ int vc_stream_run_async_multi(vc_engine* e, const int* trackers, int n_cam, int 
     vc_engine::Pending pd;
     VC_TRY(take_front(e, frames_dev, b, h, w, pd));
     vc_engine::AsyncJob job;
-    job.stage = (int)(e->tstage_seq++ % 3); job.b = b; job.cap = cap_rows_per_frame;
+    job.stage = (int)(e->tstage_seq++ % 3); job.b = b; job.cap = cap_rows_per_frame; job.frames = frames_dev;
     VC_TRY(enqueue_batch_tracking(e, pd, trackers, num_classes, cam_of_frame, n_cam, job.stage, cap_rows_per_frame, job.ndet));
     e->jobs.push_back(std::move(job));
     g_tm.report();
@@ -422,6 +442,8 @@ int vc_stream_reset(vc_engine* e) {
         (void)track_collect(e, job.stage, rows.data(), job.cap, m.data());      // bookkeeping (pending_dets, known_tracks); errors are dropped with the rows
     }
     e->pending.clear();
+    if (e->cstream) VC_HIP(hipStreamSynchronize(e->cstream));         // staged host batches are abandoned with the rest
+    for (bool& st : e->ingest_staged) st = false;
     return VC_OK;
 }
 

@@ -269,6 +269,14 @@ class Engine:
         """Enqueue the detector for a batch (returns immediately); the matching stream_run consumes it."""
         L.check(L.lib().vc_stream_submit(self._h, C.c_void_p(frames_dev_ptr), b, h, w))
 
+    def stream_stage_host(self, frames_host_ptr, b, h, w):
+        """Enqueue ONLY the host-to-device copy of a batch of (pinned) host frames; returns the device address to pass to stream_submit
+        (which starts the detector behind the copy) and then stream_run / stream_run_async.  Stage batch i + 2 before submitting
+        batch i + 1 and the copy runs under the detector of the batch before it."""
+        out = C.c_void_p()
+        L.check(L.lib().vc_stream_stage_host(self._h, C.c_void_p(frames_host_ptr), b, h, w, C.byref(out)))
+        return out.value
+
     def stream_submit_host(self, frames_host_ptr, b, h, w):
         """Enqueue the host-to-device copy of a batch of (pinned) host frames and the detector behind it; returns the device
         address to pass to stream_run / stream_run_async for this batch."""

@@ -82,16 +82,26 @@ class CountingPipeline:
                     obj["boxes"].append(res["boxes"][j])
         return self._finish(counter, obj, cam_name)
 
-    def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False):
+    def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False, host_frames=False):
         """asynchronous=True: the tracker kernel of batch n runs on the engine's tracker stream while batch n+1 is submitted and
-        embedded (`stream_run_async` / `stream_collect`); rows are identical, they arrive one batch later."""
+        embedded (`stream_run_async` / `stream_collect`); rows are identical, they arrive one batch later.
+        host_frames=True: the frames stay in (pinned) host memory, as the reference's loader delivers them, and cross PCIe batch by
+        batch -- batch n+2 is staged (`stream_stage_host`) while the detector works on batch n+1, so a video of any length needs four
+        batches of device memory; otherwise the whole clip is uploaded once."""
         import torch
         tracker, counter = self._stages(cam_name, source.video_info, zone_path)
         obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
         frames = source.frames
         t, h, w, _ = frames.shape
-        dev = torch.from_numpy(frames).to(f"cuda:{self.engine.cfg.device}")      # tensor container only
         starts = list(range(0, t, batch))
+        size = lambda n: min(batch, t - starts[n])
+        ptr = {}
+        if host_frames:
+            host = torch.from_numpy(frames).pin_memory()
+            stage = lambda n: ptr.__setitem__(n, self.engine.stream_stage_host(host[starts[n]:starts[n] + size(n)].data_ptr(), size(n), h, w))
+        else:
+            dev = torch.from_numpy(frames).to(f"cuda:{self.engine.cfg.device}")      # tensor container only
+            stage = lambda n: ptr.__setitem__(n, dev[starts[n]:starts[n] + size(n)].data_ptr())
 
         def record(f0, rows, fidx):
             obj["frames"].extend((f0 + 1 + fidx).tolist())
@@ -99,18 +109,23 @@ class CountingPipeline:
             obj["labels"].extend(rows[:, 5].tolist())
             obj["boxes"].extend(list(rows[:, :4].copy()))
 
-        self.engine.stream_submit(dev[0:min(batch, t)].data_ptr(), min(batch, t), h, w)
+        for n in range(min(2, len(starts))):            # staging order = batch order (the engine hands its four host slots out round-robin)
+            stage(n)
+        if starts:
+            self.engine.stream_submit(ptr[0], size(0), h, w)
         for n, f0 in enumerate(starts):
-            b = min(batch, t - f0)
+            b = size(n)
+            if n + 2 < len(starts):                     # copy batch n+2 (host frames) under the detector of batch n+1
+                stage(n + 2)
             if n + 1 < len(starts):                     # detect the next batch while this one is tracked
-                g0 = starts[n + 1]
-                self.engine.stream_submit(dev[g0:g0 + min(batch, t - g0)].data_ptr(), min(batch, t - g0), h, w)
+                self.engine.stream_submit(ptr[n + 1], size(n + 1), h, w)
             if asynchronous:
-                self.engine.stream_run_async(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)
+                self.engine.stream_run_async(tracker.tracker_ids, ptr[n], b, h, w)
                 if n > 0:
                     record(starts[n - 1], *self.engine.stream_collect()[:2])
             else:
-                record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, dev[f0:f0 + b].data_ptr(), b, h, w)[:2])
+                record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, ptr[n], b, h, w)[:2])
+            ptr.pop(n - 1, None)
         if asynchronous and starts:
             record(starts[-1], *self.engine.stream_collect()[:2])
         return self._finish(counter, obj, cam_name)
