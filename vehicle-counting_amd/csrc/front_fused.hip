@@ -24,8 +24,15 @@ typedef float f32x4f __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
 union ChunkF { uint4 u; bf16x8f h; };
 
-#define FF_TH 16                  // layer-1 output tile
-#define FF_NW 8                   // waves per workgroup
+// (-DFF_TH=4 -DFF_NW=4: 4 x 16 tiles, 70 KB of LDS, TWO workgroups of four waves per CU whose phases drift apart -- the recipe of
+// c3_fused.hip -- is bit-identical and was measured 0.78 against 0.53 ms per 128 frames: 22 patch rows per 4 output rows instead of 70
+// per 16, 12 % more stem halo, four barriers per quarter of the work)
+#ifndef FF_TH
+#define FF_TH 16                  // layer-1 output tile rows (even)
+#endif
+#ifndef FF_NW
+#define FF_NW 8                   // waves per workgroup; FF_NW / (FF_TH / 2) = channel splits of the conv phase (1, 2 or 4)
+#endif
 #define FF_TW 16
 #define FF_RH (2 * FF_TH + 1)     // layer-0 region rows (33)
 #define FF_PW (FF_TW + 1)         // layer-0 pixels per parity plane row (17: columns 0, 2, .., 32 / 1, 3, .., 31 + one unused)
@@ -51,7 +58,7 @@ __device__ __forceinline__ f32x2f ff_silu2(f32x2f x) {
 __device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
 
 template <bool U8, bool DIAG = false>
-__global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
+__global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
                                                              const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
                                                              int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl_arg) {
@@ -73,11 +80,15 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         const int l = i & 63, ct = (i >> 6) & 3, t = i >> 8;
         w1s[i] = w1[(size_t)(ct * 16 + (l & 15)) * kw8_1 + 4 * t + (l >> 4)];
     }
-    float4 bv0[2], bv1[4];
+    // conv phase: a wave owns two output rows (row pair rp) and CTW of the 4 channel tiles (from ct0)
+    constexpr int RP = FF_TH / 2, CS = FF_NW / RP, CTW = 4 / CS;
+    static_assert(FF_TH % 2 == 0 && FF_NW % RP == 0 && (CS == 1 || CS == 2 || CS == 4), "conv phase split");
+    const int rp = wave % RP, ct0 = (wave / RP) * CTW;
+    float4 bv0[2], bv1[CTW];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) bv0[ct] = *(const float4*)(b0 + ct * 16 + kq * 4);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv1[ct] = *(const float4*)(b1 + ct * 16 + kq * 4);
+    for (int c = 0; c < CTW; ++c) bv1[c] = *(const float4*)(b1 + (ct0 + c) * 16 + kq * 4);
     int koff[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -282,38 +293,41 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
         }
         if (dbg) ts2 = wall_clock64();
         __syncthreads();
-        // ---- layer 1 from the LDS tile: wave w owns output rows 2w, 2w + 1 (one pixel tile each), all 64 channels; weights from LDS ---
+        // ---- layer 1 from the LDS tile: a wave owns two output rows (one pixel tile each) and CTW of the 4 channel tiles (all of them when
+        // there are as many waves as row pairs); weights from LDS ---
         if (!(abl & 32)) {
-            f32x4f acc[4][2];
+            f32x4f acc[CTW][2];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int c = 0; c < CTW; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[ct][q] = (f32x4f){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 2; ++q) acc[c][q] = (f32x4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const int r = tp / 3, s = tp % 3;
                 ChunkF xf[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int oyl = wave * 2 + q;
+                    const int oyl = rp * 2 + q;
                     const int px = (s & 1) * FF_PLANE + (2 * oyl + r) * FF_PW + col + (s >> 1);
                     xf[q].u = *(const uint4*)(l0b + ff_l0_addr(px, kq));
                 }
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
+                for (int c = 0; c < CTW; ++c) {
                     ChunkF wv;
-                    wv.u = w1s[(tp * 4 + ct) * 64 + lane];
+                    wv.u = w1s[(tp * 4 + ct0 + c) * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[ct][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv.h, xf[q].h, acc[ct][q], 0, 0, 0);
+                    for (int q = 0; q < 2; ++q) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv.h, xf[q].h, acc[c][q], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int c = 0; c < CTW; ++c) {
+                const int ct = ct0 + c;
+                const float4 bb = bv1[c];
                 uint2 P[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    f32x2f lo = (f32x2f){acc[ct][q][0], acc[ct][q][1]} + (f32x2f){bv1[ct].x, bv1[ct].y};
-                    f32x2f hi = (f32x2f){acc[ct][q][2], acc[ct][q][3]} + (f32x2f){bv1[ct].z, bv1[ct].w};
+                    f32x2f lo = (f32x2f){acc[c][q][0], acc[c][q][1]} + (f32x2f){bb.x, bb.y};
+                    f32x2f hi = (f32x2f){acc[c][q][2], acc[c][q][3]} + (f32x2f){bb.z, bb.w};
                     if (!(abl & 1)) { lo = ff_silu2(lo); hi = ff_silu2(hi); }
                     const bf16x2f p0 = {(__bf16)lo.x, (__bf16)lo.y}, p1 = {(__bf16)hi.x, (__bf16)hi.y};
                     P[q].x = __builtin_bit_cast(uint32_t, p0); P[q].y = __builtin_bit_cast(uint32_t, p1);
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(FF_NW * 64, 1) void front_fused_kernel(const uint4*
                 const u32x2f sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
                 const u32x2f sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
                 const uint4 o4 = make_uint4(sx.x, sy.x, sx.y, sy.y);
-                const int oy = oy0 + wave * 2 + (odd ? 1 : 0), ox = ox0 + col;
+                const int oy = oy0 + rp * 2 + (odd ? 1 : 0), ox = ox0 + col;
                 if (oy < H1 && ox < W1 && !(abl & 8))
                     *(uint4*)(y + (((size_t)b * H1 + oy) * W1 + ox) * out_cs + out_co + ct * 16 + (kq & ~1) * 4) = o4;
             }
