@@ -1,3 +1,5 @@
+"""Diagnosis tool: the crowded golden scenario (tests/golden/scenarios.py) step by step through vc_tracker_step against the oracle tracker,
+printing the first frame / track where ids, states or means diverge (used to find the set-order dependence, DESIGN.md section 2 ii)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
