@@ -45,6 +45,7 @@ TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_dis
 PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0, "f32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md; fp8 = MX-scaled K = 128 form; f32 = v_mfma_f32_16x16x4_f32, the vector rate)
 PEAK_HBM_GBS = 8000.0                              # HBM3E (MI355X_MICROARCH.md)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
+ZONE_720P = os.path.join(ROOT, "tests", "golden", "cam_04.json")           # the reference's own zone file (demo/sample/cam_04.json, 1280 x 720)
 
 WORKLOADS = {
     "s640-bf16": dict(model="yolov5s", size=640, precision="bf16", B=int(os.environ.get("VC_BENCH_B", 128)),
@@ -61,17 +62,46 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(ysd, rsd, frames, n_frames):
-    """The oracle (CPU port of the reference path) timed on this box's host cores over a bounded sample."""
+def host_cpu_info():
+    """`lscpu` of the box the CPU baseline runs on: model, sockets, physical cores, threads per core."""
+    import subprocess
+    info = {}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)", "NUMA node(s)"):
+                info[k.strip()] = v.strip()
+    except Exception as ex:                                             # no lscpu: say so in the line
+        info["error"] = str(ex)[:100]
+    try:
+        info["physical_cores"] = int(info["Socket(s)"]) * int(info["Core(s) per socket"])
+    except Exception:
+        info["physical_cores"] = os.cpu_count() or 1
+    return info
+
+
+def cpu_baseline(ysd, rsd, frames, n_frames, repeats=3):
+    """The oracle (CPU port of the reference path) timed on this box's host cores over a bounded sample: `repeats` runs of the same
+    n_frames-frame sample on one thread per PHYSICAL core (lscpu), the median reported, every run listed."""
     from oracle import pipeline as op
     cfg = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
-    op.run_video(frames[:1], ysd, rsd, cfg, ZONE, nc=NC)            # warm the CPU kernels
-    t0 = time.perf_counter()
-    _, _, nd = op.run_video(frames[:n_frames], ysd, rsd, cfg, ZONE, nc=NC)
-    dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"first {n_frames} frames of the rank-0 stream through oracle/pipeline.py (torch-CPU fp32 YOLOv5s + ReID, "
-                      f"NumPy/SciPy DeepSORT), {int(np.mean(nd))} det/frame, {dt:.1f} s"}
+    cpu = host_cpu_info()
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(max(1, cpu["physical_cores"]))
+    try:
+        op.run_video(frames[:1], ysd, rsd, cfg, ZONE, nc=NC)            # warm the CPU kernels
+        runs, nd = [], None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            _, _, nd = op.run_video(frames[:n_frames], ysd, rsd, cfg, ZONE, nc=NC)
+            runs.append(n_frames / (time.perf_counter() - t0))
+    finally:
+        torch.set_num_threads(threads_before)
+    return {"value": float(np.median(runs)), "unit": "frames/s", "cores": cpu["physical_cores"], "kind": "port",
+            "runs_fps": [round(r, 3) for r in runs], "lscpu": cpu,
+            "sample": f"median of {repeats} runs over the first {n_frames} frames of the rank-0 stream through oracle/pipeline.py (torch-CPU fp32 "
+                      f"YOLOv5s + ReID, NumPy/SciPy DeepSORT, batch 1), torch threads = physical cores, {int(np.mean(nd))} det/frame, "
+                      f"{sum(n_frames / r for r in runs):.1f} s of CPU work"}
 
 
 def spawn_ranks(n):
@@ -93,9 +123,9 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def injected_detections(n_frames, size, n_obj, seed):
+def injected_detections(n_frames, hw, n_obj, seed):
     """Ground-truth rectangles of the synthetic stream as detector output rows [x1, y1, x2, y2, conf, cls] (SURVEY.md 8d injection)."""
-    tr = synth_tracks(n_frames, size, size, n_obj=n_obj, seed=seed, bounce=True)
+    tr = synth_tracks(n_frames, hw[0], hw[1], n_obj=n_obj, seed=seed, bounce=True)
     det = np.zeros((n_frames, n_obj, 6), np.float32)
     for f, (xywh, labels, scores) in enumerate(tr):
         det[f, :, 0:2] = xywh[:, 0:2]
@@ -108,11 +138,12 @@ def injected_detections(n_frames, size, n_obj, seed):
 class Stream:
     """One camera stream on one engine: the three overlapped stages of the fused path."""
 
-    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1):
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1, frame_hw=None, zone=None):
         wl = dict(wl, precision=precision or wl["precision"])
         self.wl, self.dev = wl, dev
         self.B = B or wl["B"]
-        self.H = self.W = wl["size"]
+        self.H, self.W = frame_hw or (wl["size"], wl["size"])     # frame_hw: frames of another geometry through the same engine (1280 x 720 -> 384 x 640 tensor, Q8)
+        self.zone = zone or ZONE
         n_obj = n_obj or wl["n_obj"]
         inject = wl["inject"] if inject is None else inject
         clip = clip or wl["clip"]
@@ -120,15 +151,15 @@ class Stream:
         self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
         per_frame = max(64, 2 * max(inject, n_obj))
+        max_crops = max(512, self.B * per_frame)                     # (small batches: a single busy frame of the random head can carry > 64 boxes)
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
-                            img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=self.B * per_frame,
+                            img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=max_crops,
                             max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096,
                             max_trackers=max(256, n_cam * NC))
         k = 32
         sizes = []
-        while k <= self.B * per_frame:
+        while k <= max_crops:
             sizes.append(k); k *= 2
-        self.eng.pretune(tuple(sizes))                               # conv autotune for every ReID size bucket
         # n_cam > 1: S cameras interleaved frame by frame in every batch (vc_stream_run_async_multi): one engine, B / S frames of latency
         # per camera, S x 80 trackers walked in parallel by the tracker kernel
         self.n_cam = n_cam
@@ -142,10 +173,10 @@ class Stream:
         self.cams = np.tile(np.arange(n_cam, dtype=np.int32), self.B // n_cam)
         self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region
         self.clip = clip
-        self.inject = injected_detections(clip, self.H, inject, 1702 + rank) if inject else None
+        self.inject = injected_detections(clip, (self.H, self.W), inject, 1702 + rank) if inject else None
         assert not (inject and n_cam > 1)
-        self.counters = [VideoCounting([str(c) for c in range(NC)], ZONE) for _ in range(n_cam)]    # the Python restatement: checks the native counter after the timed region
-        self.ncounters = [NativeCounter(ZONE, NC) for _ in range(n_cam)]     # the count tensors behind the C ABI (vc_counter_* / vc_counts), one per camera
+        self.counters = [VideoCounting([str(c) for c in range(NC)], self.zone) for _ in range(n_cam)]    # the Python restatement: checks the native counter after the timed region
+        self.ncounters = [NativeCounter(self.zone, NC) for _ in range(n_cam)]     # the count tensors behind the C ABI (vc_counter_* / vc_counts), one per camera
         self.ncounter = self.ncounters[0]
         self.gather_via = None
         try:                                                                 # bring the RCCL communicator up before anything is timed
@@ -157,6 +188,15 @@ class Stream:
         self.kept = [[] for _ in range(n_cam)]
         self.host = None
         self._dev_ptr = {}
+        self.t_submit, self.lat = {}, []                            # submit -> rows-on-the-host latency of every recorded batch
+
+        def tune():                                                  # conv autotune: every ReID size bucket + one detector batch
+            self.eng.pretune(tuple(sizes))
+            self.eng.stream_submit(self.batch_ptr(0), self.B, self.H, self.W)
+            self.eng.sync()
+            self.eng.stream_reset()
+        # N ranks: rank 0 tunes, the others adopt its choices (one timing pass instead of N, identical tile configurations everywhere)
+        parallel.share_tune_cache(self.eng, tune)
 
     def use_host_frames(self):
         """Frames in pinned host memory: every batch crosses PCIe inside the timed region (vc_stream_submit_host)."""
@@ -167,6 +207,7 @@ class Stream:
         return self.d_frames[f0:f0 + self.B].data_ptr()
 
     def submit(self, i):
+        self.t_submit[i] = time.perf_counter()
         if self.inject is not None:                                  # batch i gets the rectangles of its own frames (captured at submit time)
             f0 = (i * self.B) % self.clip
             self.eng.stream_inject(self.inject[0][f0:f0 + self.B], self.inject[1][f0:f0 + self.B])
@@ -191,7 +232,10 @@ class Stream:
 
     def collect(self, i, record):
         rows, fidx, nd = self.eng.stream_collect()
+        t_sub = self.t_submit.pop(i, None)
         if record:
+            if t_sub is not None:
+                self.lat.append(time.perf_counter() - t_sub)
             self.ndet[0] += int(nd.sum()); self.ndet[1] += self.B
             self.nrows += len(rows)
             # VideoCounting.run for one batch behind the C ABI (zone filter, per-track rows), on the host while the GPU works on the
@@ -285,6 +329,7 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
     # the stream the kernel is launched on and resolved after the region (the launches overlap with the other two streams, as in
     # the rocprofv3 trace of this command).  The per-stage split comes from two extra steps with blocking events.
     conv_timed = eng.profile_read(L.PROF_CONV)
+    dense_flops, dense_bytes = eng.profile_read_dense(L.PROF_CONV)
     conv_union_ms, conv_span_ms = eng.profile_conv_busy()
     eng.profile(0)
     eng.profile(True); eng.profile_reset()
@@ -318,6 +363,8 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
         "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv3x3s2_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / front_fused_kernel<*> / c3_fused_kernel / bneck_fused_kernel / reid_stem_pool_kernel (all detector + ReID conv launches of a step)",
         "launches_per_step": conv["launches"] / 2.0,
         "algorithmic_gflop_per_step": flops_step / 1e9, "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
+        "algorithmic_note": "EXECUTED work of the launches: the sparse Detect head counts the gathered rows it computes (row counts read back from the device); the dense head it replaces is in algorithmic_dense_*, not in frac",
+        "algorithmic_dense_gflop_per_step": dense_flops / n_meas_steps / 1e9, "algorithmic_dense_bytes_per_launch": dense_bytes / max(conv_timed["launches"], 1),
         "avg_launch_us": conv_timed["ms"] * 1e3 / max(conv_timed["launches"], 1),
         "avg_launch_note": "HIP start/stop timestamps of every conv dispatch of the timed steps (hipExtLaunchKernel); launches of the detector and ReID streams overlap, so launches_per_step x avg_launch_us may exceed ms_per_step",
         "achieved_sum_of_overlapped_durations_tflops": overlapped, "frac_sum_of_overlapped_durations": overlapped / peak_tflops,
@@ -351,19 +398,95 @@ def quick_point_(wl, rank, local, dev, world, **kw):
     if full:
         dt, _, _, roof, stages = measure(st, warm, steps, world, PEAK_TFLOPS[st.wl["precision"]])
         keep = ("bound", "achieved", "peak", "unit", "frac", "mfma_frac", "mfma_tflops", "mfma_peak_tflops", "hbm_frac", "hbm_gbs", "launches_per_step",
-                "algorithmic_gflop_per_step", "algorithmic_bytes_per_launch", "avg_launch_us", "achieved_isolated_tflops")
+                "algorithmic_gflop_per_step", "algorithmic_bytes_per_launch", "algorithmic_dense_gflop_per_step", "avg_launch_us", "achieved_isolated_tflops")
         extra = {"roofline": {k: roof[k] for k in keep}, "stage_ms_per_step": stages, "ms_per_step": dt / steps * 1e3,
                  "dtype": st.wl["precision"], "workload": st.wl["desc"]}
     else:
         st.run_steps(0, warm, False)
         dt, _, _ = st.timed(warm, steps, world)
     out = {"value": steps * st.B / dt, "unit": "frames/s", "frames_per_step": st.B, "steps": steps,
-           "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "tracked_rows": st.nrows}
+           "det_per_frame": st.ndet[0] / max(st.ndet[1], 1), "tracked_rows": st.nrows,
+           # submit -> rows on the host, per batch: what a frame waits in the three-stage pipeline (detector of batch i + 1 and ReID /
+           # tracker of batch i overlap, rows come back one batch late)
+           "latency_ms_submit_to_rows": float(np.mean(st.lat)) * 1e3 if st.lat else None}
     out.update(extra)
     st.eng.close()
     del st
     torch.cuda.empty_cache()
     return out
+
+
+class RefLoaderFrames:
+    """What /root/reference/modules/datasets.py:47-76 hands the loop, batch_size = 1 (:93): {'imgs': [RGB copy], 'ori_imgs': [BGR frame],
+    'frames': [1-based id]} -- cv2.cvtColor makes `img` its own contiguous array.  Decode / colour conversion are the harness's input
+    contract, so the batches are built before the timed region."""
+
+    def __init__(self, frames_bgr, fps=10):
+        t, h, w, _ = frames_bgr.shape
+        self.frames = frames_bgr
+        self.video_info = {"name": "synthetic.mp4", "width": w, "height": h, "fps": fps, "num_frames": t}
+        self.batches = [{"imgs": [np.ascontiguousarray(f[:, :, ::-1])], "ori_imgs": [f], "frames": [i + 1]} for i, f in enumerate(frames_bgr)]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def dropin_point_(wl, local, frame_hw, n_frames, zone, n_obj=12, seed=1702):
+    """Frames/s of the reference's OWN loop through the drop-in classes: CountingPipeline.run = /root/reference/modules/__init__.py:54-84,
+    host frames, ImageDetect.run one image at a time (batch_size = 1, modules/datasets.py:93), VideoTracker.run per frame, VideoCounting
+    at the end -- every call crosses the C ABI with host buffers and blocks (PCIe both ways inside the timed region)."""
+    from types import SimpleNamespace
+
+    from vehicle_counting_amd.pipeline import CountingPipeline
+    H, W = frame_hw
+    ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
+    eng = E.Engine(ysd, synth_reid(1702), device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC, img_size=wl["size"],
+                   max_batch=1, max_frame_hw=(H, W), max_crops=512, max_tracks=8192, nn_budget_cap=60, max_candidates=4096, max_trackers=256)
+    args = SimpleNamespace(weight=None, output_path=None, mapping=None)
+    config = SimpleNamespace(model_name=wl["model"], min_conf=0.25, min_iou=0.45, max_det=300)
+    cam = {"cam": {"cam": {"tracking_config": dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)}}}
+    pipe = CountingPipeline(args, config, cam, engine=eng, class_names=[str(c) for c in range(NC)])
+    frames = synth_frames(n_frames, H, W, n_obj=n_obj, seed=seed, bounce=True)
+    warm = RefLoaderFrames(frames[:24])
+    src = RefLoaderFrames(frames)
+    pipe.run(warm, "cam", zone)                                          # conv autotune, first-use allocations; its trackers are discarded
+    eng.sync(); torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    t0 = time.perf_counter()
+    rows, counts = pipe.run(src, "cam", zone)                            # a new VideoTracker per video, like modules/__init__.py:32-36
+    eng.sync()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    # the same loop once more with the two stage calls timed separately
+    tracker, _ = pipe._stages("cam", src.video_info, zone)
+    t_det = t_trk = 0.0
+    n_det = 0
+    for batch in src.batches[:64]:
+        a = time.perf_counter()
+        preds = pipe.detector.run(batch)
+        b = time.perf_counter()
+        if len(preds["boxes"][0]):
+            tracker.run(batch["ori_imgs"][0], preds["boxes"][0], preds["labels"][0], preds["scores"][0])
+        c = time.perf_counter()
+        t_det += b - a; t_trk += c - b; n_det += len(preds["boxes"][0])
+    nb = len(src.batches[:64])
+    eng.close()
+    torch.cuda.empty_cache()
+    return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "frame_hw": [H, W], "batch_size": 1, "ms_per_frame": dt / n_frames * 1e3,
+            "ms_ImageDetect_run": t_det / nb * 1e3, "ms_VideoTracker_run": t_trk / nb * 1e3, "det_per_frame": n_det / nb, "csv_rows": len(rows),
+            "dtype": wl["precision"], "path": "CountingPipeline.run -> ImageDetect.run (vc_detect) + VideoTracker.run (vc_videotracker_run) per frame, host frames, blocking"}
+
+
+def dropin_point(*a, **kw):
+    try:
+        return dropin_point_(*a, **kw)
+    except Exception as ex:
+        print(f"bench.py: drop-in point failed: {ex}", file=sys.stderr)
+        torch.cuda.empty_cache()
+        return {"error": str(ex)[:300]}
 
 
 def main():
@@ -374,7 +497,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s640-bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra operating points (K = 32 / 256, fp32, m1024-bf16, l1280-fp8, host frames)")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--extras", default="", help="comma-separated subset of the extra operating points to run (default: all)")
+    ap.add_argument("--cpu-frames", type=int, default=8)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -395,7 +519,7 @@ def main():
     # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
     # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if args.workload == "s640-bf16" and os.path.exists(tp):
             with open(tp) as f:
@@ -426,20 +550,32 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.workload == "s640-bf16" and not args.no_extras:
         # other operating points of SURVEY.md 8(d), short runs of the same pipeline (extra keys; `value` above is the headline)
-        out["extra_points"] = {
-            "K32_injected": quick_point(wl, rank, local, dev, world, n_obj=32, inject=32, clip=256),
-            "K256_injected": quick_point(wl, rank, local, dev, world, n_obj=256, inject=256, B=32, clip=128, steps=6, full=True),
+        qp = lambda w=wl, **kw: (lambda: quick_point(w, rank, local, dev, world, **kw))
+        points = {
+            "K32_injected": qp(n_obj=32, inject=32, clip=256),
+            "K256_injected": qp(n_obj=256, inject=256, B=32, clip=128, steps=6, full=True),
             # the engine mode whose CSV is identical to the oracle's (tests/test_gpu_bench_config.py): fp32 MFMA convs, same stream
-            "s640_fp32_exact_csv": quick_point(wl, rank, local, dev, world, precision="f32", B=64, clip=128, steps=6, full=True),
+            "s640_fp32_exact_csv": qp(precision="f32", B=64, clip=128, steps=6, full=True),
             # BASELINE.json configs[2] and configs[4], short runs of `--workload m1024-bf16` / `--workload l1280-fp8`
-            "m1024_bf16": quick_point(WORKLOADS["m1024-bf16"], rank, local, dev, world, steps=4, warmup=2, full=True),
-            "l1280_fp8": quick_point(WORKLOADS["l1280-fp8"], rank, local, dev, world, steps=6, warmup=2, full=True),
+            "m1024_bf16": qp(WORKLOADS["m1024-bf16"], steps=4, warmup=2, full=True),
+            "l1280_fp8": qp(WORKLOADS["l1280-fp8"], steps=6, warmup=2, full=True),
             # BASELINE.json configs[3]'s 8 cameras on ONE GPU: 8 x 16 frames interleaved in every 128-frame batch (vc_stream_run_async_multi)
-            "s640_8cam_one_gpu": quick_point(wl, rank, local, dev, world, n_cam=8, clip=512, steps=12, warmup=3, full=True),
+            "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True),
+            # the boundary the reference itself calls: batch_size = 1 through the drop-in classes, host frames
+            "dropin_bs1": lambda: dropin_point(wl, local, (640, 640), 256, ZONE),
+            "dropin_bs1_720p": lambda: dropin_point(wl, local, (720, 1280), 256, ZONE_720P),
+            # the reference's only real input geometry (Q8, networks/yolo.py:69-70; demo/sample/cam_04.json): 1280 x 720 frames -> 384 x 640 tensor
+            "s720p_bf16": qp(frame_hw=(720, 1280), zone=ZONE_720P, clip=256, steps=12, warmup=3, full=True),
+            # batch-size sweep of the headline stream (frames per vc_stream_* call) with the submit -> rows latency of a batch
+            "batch_sweep": lambda: {f"B{b}": quick_point(wl, rank, local, dev, world, B=b, clip=256, steps=max(8, min(128, 512 // b)), warmup=max(3, min(16, 64 // b)))
+                                    for b in (1, 8, 16, 32, 128)},
         }
-        hp = quick_point(wl, rank, local, dev, world, host=True, steps=30, warmup=6)     # the clip is 4 batches: every pinned page has crossed PCIe once before the timed steps
-        out["value_host_frames"] = hp["value"]
-        out["value_host_frames_note"] = "same workload with the frames in pinned host memory: every batch is copied over PCIe inside the timed region (vc_stream_stage_host one batch ahead of vc_stream_submit: the copy runs under the detector of the batch before)"
+        only = set(args.extras.split(",")) if args.extras else None
+        out["extra_points"] = {k: f() for k, f in points.items() if only is None or k in only}
+        if only is None or "host_frames" in only:
+            hp = quick_point(wl, rank, local, dev, world, host=True, steps=30, warmup=6)     # the clip is 4 batches: every pinned page has crossed PCIe once before the timed steps
+            out["value_host_frames"] = hp["value"]
+            out["value_host_frames_note"] = "same workload with the frames in pinned host memory: every batch is copied over PCIe inside the timed region (vc_stream_stage_host one batch ahead of vc_stream_submit: the copy runs under the detector of the batch before)"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == "s640-bf16":
             out["cpu_baseline"] = cpu_baseline(ysd, rsd, frames, args.cpu_frames)

@@ -239,6 +239,24 @@ int vc_allgather_counts(vc_engine* e, const int32_t* local, int n, int32_t* out)
  * the way the reference's draw_* helpers are called.  Pixel parity with OpenCV's rasteriser / fonts is not claimed. */
 int vc_overlay(vc_engine* e, void* frames_dev, int b, int h, int w, const int32_t* prims12, const int32_t* frame_first);
 
+/* Host half of vc_allgather_rows: RCCL gathers equal-sized blocks, so every rank contributes `max_rows` rows (its own counts[r] rows
+ * followed by padding) and the receive buffer is rank-major [world][max_rows][row_bytes].  This compacts such a padded buffer into
+ * the first sum(counts) rows of `out` in rank-major order -- for frame chunks dealt round-robin to the ranks that is frame order
+ * (the ordering contract of /root/reference/modules/__init__.py:54-84).  Pure host function (no GPU): it is the logic a world of
+ * 2 / 3 / 8 ranks exercises and a single-GPU box cannot, so the CPU tests drive it directly.  vc_allgather_rows calls it for the rows
+ * and uses vc_gather_offsets for the device-side copies of the embeddings.  Returns the row count through *out_total. */
+int vc_gather_compact_host(const void* padded, int world, int max_rows, size_t row_bytes, const int* counts, void* out, size_t out_cap_rows,
+                           int64_t* out_total);
+/* src_off[r] / dst_off[r]: first row of rank r's block in the padded buffer / in the compacted output (rows, not bytes). */
+int vc_gather_offsets(int world, int max_rows, const int* counts, int64_t* src_off, int64_t* dst_off, int64_t* out_total);
+
+/* Conv autotune choices of this engine as text ("<shape key> <tile config>\n" per line, the VC_TUNE_CACHE file format), and their
+ * import into another engine (keys already present are overwritten; call before the first launch of those shapes).  Multi-GPU
+ * launches tune on rank 0 and broadcast the text (parallel.share_tune_cache): N ranks then neither time the candidates N times nor
+ * disagree on the member of a near-tie (bf16 results are identical across tile configurations of one kernel family only). */
+int vc_tune_export(vc_engine* e, char* buf, size_t cap, size_t* size);   /* buf may be NULL: *size receives the bytes needed (incl. NUL) */
+int vc_tune_import(vc_engine* e, const char* text);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 #define VC_PROF_CONV 0       /* all implicit-GEMM conv launches */
 #define VC_PROF_DETECT_AUX 1 /* letterbox, pools, upsample, decode, NMS */
@@ -251,6 +269,10 @@ int vc_profile_read(vc_engine* e, int category, double* total_ms, int64_t* launc
 /* After vc_profile_read(VC_PROF_CONV) resolved an in-flight (mode 2) region: milliseconds during which at least one conv kernel was
  * running, and the window from the first conv start to the last conv stop. */
 int vc_profile_conv_busy(vc_engine* e, double* union_ms, double* span_ms);
+/* vc_profile_read reports the work the launches EXECUTE (the sparse Detect head: the gathered rows only).  This returns the same
+ * category with the sparse head credited as the dense Detect.m[i] it replaces -- the reference's algorithmic work -- as a separate
+ * figure (bench.py: roofline.algorithmic_dense_*).  Call vc_profile_read first. */
+int vc_profile_read_dense(vc_engine* e, int category, double* flops_dense, double* bytes_dense);
 int vc_profile_reset(vc_engine* e);
 int vc_profile_ops(vc_engine* e, char* buf, size_t cap);   /* per-conv-launch lines "conv M= N= K= ... ms= tflops=" recorded while profiling */
 int vc_engine_sync(vc_engine* e);

@@ -55,6 +55,51 @@ def test_720p_frames_fp32():
     eng.close()
 
 
+def test_720p_frames_bf16():
+    """The reference's only real input geometry in the benchmarked precision: 1280x720 frames -> 384x640 tensor
+    (Q8) on the bf16 engine, through vc_detect (host RGB frames) AND the stream path (device BGR frames, the path bench.py's
+    s720p_bf16 point times).  Tolerances = the bf16 ladder of test_gpu_nets.py::test_detector_layers_and_pred: per-layer max-norm
+    <= 6e-2 / rms <= 3e-2 of the fp32 oracle's tensor; every oracle box with conf >= 0.30 has a same-class partner with IoU >= 0.45,
+    >= 85 % are the same box (IoU >= 0.9, |dconf| <= 6e-2).  The two ingest paths must agree with each other bit for bit."""
+    import torch
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=8.0, obj_shift=1.0)       # the head calibration of test_720p_frames_fp32
+    frames = synth_frames(2, 720, 1280, n_obj=6, seed=9)
+    imgs = [f[:, :, ::-1] for f in frames]
+    eng = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=2, max_frame_hw=(720, 1280))
+    dets = eng.detect(imgs)
+    x, s0, s1 = oy.preprocess(imgs, 640)
+    assert s1 == [384, 640]
+    pred, ys, raw = oy.forward(sd, x, "yolov5s", NC, return_layers=True)
+    host_layers = {}
+    for layer in (1, 2, 4, 9, 17, 20, 23):
+        got, ref = nchw(eng.debug_layer(layer, batch=2)), ys[layer].numpy()
+        host_layers[layer] = got
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 6e-2 * np.abs(ref).max(), layer
+        assert np.sqrt(((got - ref) ** 2).mean()) <= 3e-2 * np.sqrt((ref ** 2).mean()), layer
+    ref_dets = oy.autoshape_detect(sd, imgs, "yolov5s", NC)
+    n_ref = n_same = 0
+    for d, r in zip(dets, ref_dets):
+        for rb in r[r[:, 4] >= 0.30]:
+            same = d[d[:, 5] == rb[5]]
+            assert len(same) > 0
+            iou = iou_one(rb, same)
+            j = int(iou.argmax())
+            assert iou[j] >= 0.45, (rb, iou[j], same[j])
+            n_ref += 1
+            if iou[j] >= 0.9:
+                n_same += 1
+                assert abs(same[j, 4] - rb[4]) <= 6e-2
+    assert n_ref > 5 and n_same >= 0.85 * n_ref, (n_ref, n_same)
+    # stream path: device-resident BGR frames (R/B swap folded into the ingest), same tensors bit for bit
+    dev = torch.from_numpy(frames).cuda()
+    eng.stream_submit(dev.data_ptr(), 2, 720, 1280)
+    eng.sync()
+    for layer, a in host_layers.items():
+        np.testing.assert_array_equal(nchw(eng.debug_layer(layer, batch=2)), a)
+    eng.close()
+
+
 def test_yolov5m_graph_fp32():
     """yolov5m (0.67 / 0.75 multiples: 48..768 channels, 2-4-6-2 bottlenecks, 82 convs) at AutoShape size 320."""
     sd = synth_yolo("yolov5m", nc=NC, seed=7, det_scale=4.0, obj_shift=0.5)

@@ -199,6 +199,39 @@ def test_unembeddable_batch_is_dropped_and_the_stream_continues(eng_f32):
         eng_f32.tracker_reset(t)
 
 
+def test_lookahead_drop_does_not_lose_the_current_batch(eng_f32):
+    """two submissions in flight, the SECOND cannot be embedded.  The calls made for the first batch (run_async,
+    collect) succeed and return its rows; the error comes back from the call that consumes the second batch, once; a third batch
+    then runs normally and Engine's bookkeeping (`_async_shapes`) stays in step with the native job queue."""
+    import time
+
+    import torch
+    B, H, W = 4, 640, 640
+    frames = synth_frames(3 * B, H, W, n_obj=4, seed=5)
+    dev = torch.from_numpy(frames).cuda()
+    good, cnt = injected(synth_tracks(3 * B, H, W, n_obj=4, seed=5))
+    bad = good[B:2 * B].copy()
+    bad[1, 2, :4] = [100.2, 100.2, 100.4, 100.4]
+    tids = [eng_f32.tracker_create(**TRACK_KW) for _ in range(3)]
+    p = [dev[k * B:(k + 1) * B].data_ptr() for k in range(3)]
+    eng_f32.stream_inject(good[:B], cnt[:B]); eng_f32.stream_submit(p[0], B, H, W)
+    eng_f32.stream_inject(bad, cnt[B:2 * B]); eng_f32.stream_submit(p[1], B, H, W)
+    eng_f32.sync()                                                     # both detectors have finished: the look-ahead WILL try batch 1
+    time.sleep(0.05)
+    eng_f32.stream_run_async(tids, p[0], B, H, W)                      # batch 0: must not report batch 1's refusal
+    rows0, fidx0, nd0 = eng_f32.stream_collect()                       # ... and its rows come back
+    assert nd0.tolist() == [4] * B
+    with pytest.raises(E.L.VcError, match="empty crop"):
+        eng_f32.stream_run_async(tids, p[1], B, H, W)                  # reported here, by the call that consumes batch 1
+    assert eng_f32._async_shapes == []
+    eng_f32.stream_inject(good[2 * B:], cnt[2 * B:]); eng_f32.stream_submit(p[2], B, H, W)
+    rows2, nd2 = eng_f32.stream_run(tids, p[2], B, H, W)
+    assert nd2.tolist() == [4] * B
+    eng_f32.stream_inject(None)
+    for t in tids:
+        eng_f32.tracker_reset(t)
+
+
 def test_config2_yolov5m_1024_end_to_end_fp32(golden_dir, tmp_path):
     """BASELINE.json configs[2] on ONE stream: YOLOv5m at 1024x1024 -> NMS (max_det 256) -> ReID -> DeepSORT -> counting, through
     the fused stream path, fp32; CSV identical to oracle.pipeline.run_video (ids / frames / directions exact, boxes +-1 px)."""

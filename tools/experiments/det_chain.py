@@ -1,7 +1,7 @@
 """Detector chain alone: time per 128-frame batch of submit + run with zero injected detections (no ReID crops, empty tracker steps),
 against the sum of the detector kernels' isolated durations -- the difference is what the gaps between dependent launches cost."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 import vehicle_counting_amd._lib as L

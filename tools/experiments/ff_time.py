@@ -1,6 +1,6 @@
 """front_fused_kernel / c3_fused_kernel / bneck timing (profiling events), five repetitions -- for A/B runs of two library builds (VC_LIB_PATH)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import vehicle_counting_amd.engine as E
 from vehicle_counting_amd.synth import synth_frames

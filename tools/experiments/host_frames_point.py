@@ -2,7 +2,7 @@
 detector (vc_stream_stage_host) against copies in front of their own detector (VC_BENCH_HOST_INLINE=1), alternating, and the
 device-resident rate on the same box."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 wl = bench.WORKLOADS["s640-bf16"]

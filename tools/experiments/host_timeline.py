@@ -1,6 +1,6 @@
 """Where does a bench step spend host time?  (python-side timers around submit / run)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import vehicle_counting_amd.engine as E
 from vehicle_counting_amd.synth import synth_frames

@@ -1,6 +1,6 @@
 """Aggregate frames/s of S independent camera streams on ONE GPU (one Engine + one host thread per stream)."""
 import os, sys, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import vehicle_counting_amd.engine as E
 from vehicle_counting_amd.synth import synth_frames

@@ -1,7 +1,7 @@
 """Phase split of the tracker kernel (VC_TRACK_DBG=1 prints it per batch) on a bench stream: VC_K detections injected per frame."""
 import os, sys
 os.environ["VC_TRACK_DBG"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 K, B = int(os.environ.get("VC_K", 256)), int(os.environ.get("VC_B", 32))
 wl = bench.WORKLOADS[os.environ.get("VC_WL", "s640-bf16")]

@@ -1,7 +1,7 @@
 """Experiment: two camera streams on one GPU (two engines, B frames each) interleaved from one host thread vs one stream with 2B frames.
 Do the detector kernels of one stream fill the other's memory-bound / tail phases?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gc
 import torch
 import bench

@@ -1,4 +1,4 @@
-"""front_fused_kernel timing under VC_FF_ABLATE masks (diagnostics, wrong results): which component bounds the kernel."""
+"""front_fused_kernel / c3_fused_kernel timing under ablation masks (engine options "ff_ablate" / "c3_ablate" (diagnostics, wrong results): which component bounds the kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,7 +14,7 @@ for _ in range(2):
     eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync(); eng.stream_reset()
 names.update({128: "no global fetch", 192: "no fetch, no patch writes", 256: "no patch LDS reads (stem)", 257: "no patch reads, no trans", 384: "no fetch, no patch reads"})
 for abl in (0, 128, 192, 256, 257, 384, 1, 16, 32, 0):
-    os.environ["VC_FF_ABLATE"] = str(abl)
+    eng.set_option("ff_ablate", abl)
     eng.profile(True); eng.profile_reset()
     eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync()
     l = [x for x in eng.profile_ops().strip().split("\n") if "cfg=102" in x]
@@ -22,11 +22,11 @@ for abl in (0, 128, 192, 256, 257, 384, 1, 16, 32, 0):
     eng.stream_reset()
     print(f"abl {abl:3d} {names.get(abl, ''):32s} {l[0].split('ms=')[1].split()[0] if l else '?'} ms", flush=True)
 
-os.environ.pop("VC_FF_ABLATE", None)
+eng.set_option("ff_ablate", 0)
 cn = {0: "full", 1: "no transcendentals", 2: "no global fetch", 4: "no output stores", 8: "no 3x3 pass", 16: "no cv12 pass", 32: "no m.cv1 pass", 64: "no cv3 pass",
       6: "no fetch, no stores", 120: "staging only (no passes)", 7: "no trans/fetch/stores"}
 for abl in (0, 1, 2, 4, 6, 8, 16, 32, 64, 120, 7, 0):
-    os.environ["VC_C3_ABLATE"] = str(abl)
+    eng.set_option("c3_ablate", abl)
     eng.profile(True); eng.profile_reset()
     eng.stream_submit(fr.data_ptr(), B, H, W); eng.sync()
     l = [x for x in eng.profile_ops().strip().split("\n") if "cfg=103" in x]

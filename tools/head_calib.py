@@ -6,11 +6,15 @@ import vehicle_counting_amd.engine as E
 from vehicle_counting_amd.synth import synth_frames
 from vehicle_counting_amd.weights import synth_yolo
 MODEL, PREC, S = os.environ.get("VC_MODEL", "yolov5l"), os.environ.get("VC_PREC", "fp8"), int(os.environ.get("VC_SIZE", 1280))
-fr = synth_frames(4, S, S, 16, 1702)
-for ds in (0.25, 1.0):
-    for sh in (-12.0, -16.0, -24.0, -32.0, -48.0):
+FH, FW = (int(v) for v in os.environ.get("VC_FRAME_HW", f"{S},{S}").split(","))      # frame geometry (the tensor follows AutoShape: 720,1280 -> 384 x 640)
+SCALES = [float(v) for v in os.environ.get("VC_SCALES", "0.25,1.0").split(",")]
+SHIFTS = [float(v) for v in os.environ.get("VC_SHIFTS", "-12,-16,-24,-32,-48").split(",")]
+S_FRAME = (FH, FW)
+fr = synth_frames(4, FH, FW, int(os.environ.get("VC_OBJECTS", 16)), 1702, bounce=True)
+for ds in SCALES:
+    for sh in SHIFTS:
         eng = E.Engine(synth_yolo(MODEL, nc=80, det_scale=ds, obj_shift=sh), None, precision=PREC, model_name=MODEL, num_classes=80, max_batch=4,
-                       img_size=S, max_frame_hw=(S, S), max_candidates=8192)
+                       img_size=S, max_frame_hw=S_FRAME, max_candidates=8192)
         try:
             d = eng.detect([f[:, :, ::-1] for f in fr])
             n = [len(x) for x in d]

@@ -107,6 +107,11 @@ SIGNATURES = {
     "vc_overlay": [_vp, _vp, _i, _i, _i, _pi, _pi],
     "vc_profile_enable": [_vp, _i],
     "vc_profile_conv_busy": [_vp, _pd, _pd],
+    "vc_profile_read_dense": [_vp, _i, _pd, _pd],
+    "vc_gather_compact_host": [_vp, _i, _i, C.c_size_t, _pi, _vp, C.c_size_t, _pl],
+    "vc_gather_offsets": [_i, _i, _pi, _pl, _pl, _pl],
+    "vc_tune_export": [_vp, C.c_char_p, C.c_size_t, _P(C.c_size_t)],
+    "vc_tune_import": [_vp, C.c_char_p],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
     "vc_profile_reset": [_vp],
     "vc_profile_ops": [_vp, C.c_char_p, C.c_size_t],

@@ -290,7 +290,7 @@ int launch_c3_fused(const ConvP& p12, const ConvP& pm1, const ConvP& pm2, const 
     }();
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     const int grid = std::min(ntiles, std::max(256, slots_hw - slots_reserve / 2));   // persistent; two workgroups per CU: half the usual number of slots stays free
-    a.abl = getenv("VC_C3_ABLATE") ? atoi(getenv("VC_C3_ABLATE")) : 0;                 // diagnostics only (tools/ff_ablate.py)
+    a.abl = p12.ablate;                                                              // diagnostics only (engine option "c3_ablate", tools/ff_ablate.py)
     if (a.abl) launch_timed(p12, c3_fused_kernel<true>, dim3(grid), dim3(C3_NW * 64), 0, s, a);
     else launch_timed(p12, c3_fused_kernel<false>, dim3(grid), dim3(C3_NW * 64), 0, s, a);
     VC_HIP(hipGetLastError());

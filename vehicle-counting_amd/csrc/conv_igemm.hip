@@ -1259,7 +1259,7 @@ static int launch_one(ConvP p, hipStream_t s) {
     p.ntiles = tiles;
     static const int dyn_lds = getenv("VC_CONV_DYN_LDS") ? atoi(getenv("VC_CONV_DYN_LDS")) : 0;   // diagnostics: caps workgroups per CU
     static const bool persist = !(getenv("VC_CONV_PERSIST") && atoi(getenv("VC_CONV_PERSIST")) == 0);
-    const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;        // tests: force long tile walks
+    const int slots_override = p.slots;                                                              // tests: force long tile walks (ConvP::slots)
     // A persistent grid that fills every workgroup slot of the chip leaves no room for the kernels of the other streams (ReID next to the
     // detector, the tracker walk), which then wait for a conv launch to end: 64 slots are left free (round 2, 128-frame steps:
     // 0 / 32 / 64 / 96 / 128 free slots = 14.9 / 15.1 / 15.6 / 15.6 / 15.4 k frames/s; 256 free slots cost 9 % of conv time).
@@ -1381,7 +1381,7 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
     const int need = (nblk * ng + 3) / 4;
     static const int slots_hw = resident_workgroups(conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>);
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
-    const int slots_override = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;
+    const int slots_override = p.slots;
     const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
     p.ntiles = nblk * ng;
     if (p.act == ACT_SILU) launch_timed(p, conv1x1_direct_kernel<CT, KS, PT, OCC, ACT_SILU>, dim3(std::min(need, slots)), dim3(256), 0, s, p);

@@ -201,6 +201,32 @@ int vc_allgather_counts(vc_engine* e, const int32_t* local, int n, int32_t* out)
 // rank-major (a rank's rows keep their order), their counts per rank, and the device address of the gathered embeddings in the same
 // order.  Two collectives on the engine's stream: the counts, then rows + embeddings padded to the largest count (ncclAllGather wants
 // equal contributions).  The gathered embeddings stay valid until the next vc_allgather_rows.
+int vc_gather_offsets(int world, int max_rows, const int* counts, int64_t* src_off, int64_t* dst_off, int64_t* out_total) {
+    VC_CHECK(world >= 1 && max_rows >= 0 && counts && src_off && dst_off && out_total, VC_ERR_ARG, "bad argument");
+    int64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+        VC_CHECK(counts[r] >= 0 && counts[r] <= max_rows, VC_ERR_ARG, "rank %d contributes %d rows, blocks hold %d", r, counts[r], max_rows);
+        src_off[r] = (int64_t)r * max_rows;                  // RCCL's receive buffer: equal blocks, rank-major
+        dst_off[r] = off;                                    // compacted: rank-major, no padding
+        off += counts[r];
+    }
+    *out_total = off;
+    return VC_OK;
+}
+
+int vc_gather_compact_host(const void* padded, int world, int max_rows, size_t row_bytes, const int* counts, void* out, size_t out_cap_rows,
+                           int64_t* out_total) {
+    VC_CHECK(world >= 1 && counts && out_total && row_bytes > 0, VC_ERR_ARG, "bad argument");
+    std::vector<int64_t> src(world), dst(world);
+    VC_TRY(vc_gather_offsets(world, max_rows, counts, src.data(), dst.data(), out_total));
+    VC_CHECK((size_t)*out_total <= out_cap_rows, VC_ERR_CAPACITY, "gather: %lld rows, room for %zu", (long long)*out_total, out_cap_rows);
+    VC_CHECK(*out_total == 0 || (padded && out), VC_ERR_ARG, "null buffer");
+    for (int r = 0; r < world; ++r)
+        if (counts[r] > 0)
+            memmove((char*)out + (size_t)dst[r] * row_bytes, (const char*)padded + (size_t)src[r] * row_bytes, (size_t)counts[r] * row_bytes);
+    return VC_OK;
+}
+
 int vc_allgather_rows(vc_engine* e, const double* rows7, const float* feat_dev, int n, double* out_rows7, int cap_rows, int* out_counts,
                       const float** out_feat_dev) {
     VC_CHECK(e && out_rows7 && out_counts && out_feat_dev && n >= 0 && (n == 0 || (rows7 && feat_dev)), VC_ERR_ARG, "bad argument");
@@ -242,19 +268,16 @@ int vc_allgather_rows(vc_engine* e, const double* rows7, const float* feat_dev, 
     ncclGroupEnd();
     VC_CHECK(r == ncclSuccess && r2 == ncclSuccess, VC_ERR_HIP, "ncclAllGather(rows): %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
     VC_HIP(hipMemcpyAsync(e->h_gather, recv, (size_t)world * rb, hipMemcpyDeviceToHost, s));
-    size_t off = 0;
-    for (int k = 0; k < world; ++k) {                       // compact the embeddings on the device, rank-major
+    std::vector<int64_t> src_off(world), dst_off(world);
+    int64_t total_rows = 0;
+    VC_TRY(vc_gather_offsets(world, maxn, out_counts, src_off.data(), dst_off.data(), &total_rows));
+    for (int k = 0; k < world; ++k)                         // compact the embeddings on the device, rank-major
         if (out_counts[k] > 0)
-            VC_HIP(hipMemcpyAsync((char*)e->d_gather_feat + off * VC_FEAT_DIM * sizeof(float), recv + (size_t)world * rb + (size_t)k * fb,
+            VC_HIP(hipMemcpyAsync((char*)e->d_gather_feat + (size_t)dst_off[k] * VC_FEAT_DIM * sizeof(float),
+                                  recv + (size_t)world * rb + (size_t)src_off[k] * VC_FEAT_DIM * sizeof(float),
                                   (size_t)out_counts[k] * VC_FEAT_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
-        off += out_counts[k];
-    }
     VC_HIP(hipStreamSynchronize(s));
-    off = 0;
-    for (int k = 0; k < world; ++k) {
-        memcpy(out_rows7 + off * 7, (const char*)e->h_gather + (size_t)k * rb, (size_t)out_counts[k] * 7 * sizeof(double));
-        off += out_counts[k];
-    }
+    VC_TRY(vc_gather_compact_host(e->h_gather, world, maxn, 7 * sizeof(double), out_counts, out_rows7, (size_t)cap_rows, &total_rows));
     *out_feat_dev = (const float*)e->d_gather_feat;
     return VC_OK;
 }

@@ -32,7 +32,12 @@ struct ConvParam {
 struct Op {
     enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL, TO_FP8, HEAD_COMPACT } kind;
     int level = 0;                   // HEAD_COMPACT: detection level
-    double flops_override = -1, bytes_override = -1;   // CONV: algorithmic work to report instead of the launch's own (sparse head)
+    double flops_override = -1, bytes_override = -1;   // CONV: algorithmic work to report instead of the launch's own (fixed part)
+    // CONV with a device-side row count (sparse Detect head): the EXECUTED work is flops_override + rows x flops_per_row (bytes alike),
+    // rows = the count the compaction left on the device, read back after the pass; dense_* = what the dense head this launch replaces
+    // would have done -- reported separately (vc_profile_read_dense), never mixed into the executed figures (VERDICT r03 / ADVICE r03)
+    int rows_level = -1;
+    double flops_per_row = 0, bytes_per_row = 0, dense_flops = -1, dense_bytes = -1;
     ConvP conv{};
     View a{}, b{};
     int C = 0;
@@ -54,6 +59,7 @@ struct Net {
 
 struct ProfCat {
     double ms = 0, flops = 0, bytes = 0;
+    double flops_dense = 0, bytes_dense = 0;     // the same launches with the sparse Detect head credited as the dense head it replaces
     int64_t launches = 0;
 };
 
@@ -97,8 +103,8 @@ struct vc_engine {
     hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
     // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
-    // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv
-    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1; } opt;
+    // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv per launch
+    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 
@@ -117,6 +123,9 @@ struct vc_engine {
     void* d_hc_logits[3] = {nullptr, nullptr, nullptr};
     int hc_cap[3] = {0, 0, 0};
     int* d_hc_count = nullptr;                   // [4]
+    int* h_hc_ring = nullptr;                    // pinned [HC_RING][4]: the gathered-row counts of the last HC_RING detector passes (profiling)
+    static constexpr int HC_RING = 16384;
+    unsigned hc_ring_seq = 0; int hc_ring_cur = 0;
     bool sparse_pass = false;                    // the pass being built / last run used the sparse head
     float anchors[3][6];                         // Detect anchors in pixels (default: the COCO set of yolov5{s,m,l}.yaml)
     vc::DetectPostBuffers post{};
@@ -153,6 +162,7 @@ struct vc_engine {
     struct Pending {
         const void* frames; int b, h, w, slot;
         int stage = 0;                   // 0: detector enqueued, 1: ReID enqueued as well
+        bool embed_refused = false;      // a look-ahead attempt to embed this batch failed; the call that consumes it reports why (stream.hip)
         int fslot = 0;                   // feature / crop buffer of this batch
         std::vector<FrameDets> fd;       // per frame, as VideoTracker.run sees them
         std::vector<int> row0;           // first feature row of each frame
@@ -210,7 +220,11 @@ struct vc_engine {
     // in-flight conv profiling (vc_profile_enable(e, 2)): event pairs recorded on the launch stream WITHOUT synchronising, so the
     // timed steps keep their three overlapping streams; resolved by vc_profile_read.  Only the thread that issues convs uses it.
     bool prof_async = false;
-    struct ProfPair { hipEvent_t a, b; double flops, bytes; };
+    struct ProfPair {
+        hipEvent_t a, b; double flops, bytes;
+        const int* rows = nullptr; double flops_per_row = 0, bytes_per_row = 0;   // + *rows x per-row work (pinned copy of the device row count)
+        double flops_dense = 0, bytes_dense = 0;
+    };
     std::vector<ProfPair> prof_pairs;
     size_t prof_used = 0;
     double prof_conv_union_ms = 0, prof_conv_span_ms = 0;     // set when the in-flight pairs are resolved (vc_profile_read)
@@ -230,6 +244,7 @@ struct vc_engine {
 namespace vc {
 // engine.hip
 int dev_alloc(vc_engine* e, void** p, size_t bytes);
+int dev_realloc(vc_engine* e, void** p, size_t bytes);            // frees *p (if it belongs to the engine) and allocates anew
 int host_alloc(vc_engine* e, void** p, size_t bytes);
 int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w, bool swap_rb);   // frames same size, on device
 int run_reid_dev(vc_engine* e, const uint8_t* d_frames, int H, int W, int k);                      // crops in e->d_crops -> e->d_feat

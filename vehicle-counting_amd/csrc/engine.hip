@@ -31,6 +31,18 @@ int dev_alloc(vc_engine* e, void** p, size_t bytes) {
     e->allocs.push_back(*p);
     return VC_OK;
 }
+// Replace *p (an allocation of this engine, or null) by a fresh block of `bytes`; the old block is freed.  The caller makes sure no
+// kernel still uses it.  Contents are not carried over.
+int dev_realloc(vc_engine* e, void** p, size_t bytes) {
+    void* fresh = nullptr;
+    VC_HIP(hipMalloc(&fresh, bytes ? bytes : 16));
+    bool swapped = false;
+    for (void*& q : e->allocs)
+        if (*p && q == *p) { (void)hipFree(q); q = fresh; swapped = true; break; }
+    if (!swapped) e->allocs.push_back(fresh);
+    *p = fresh;
+    return VC_OK;
+}
 int host_alloc(vc_engine* e, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     VC_HIP(hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocPortable));
@@ -50,6 +62,7 @@ ProfScope::~ProfScope() {
     hipEventElapsedTime(&ms, e->ev0, e->ev1);
     ProfCat& c = e->prof[cat];
     c.ms += ms; c.flops += flops; c.bytes += bytes; c.launches += 1;
+    c.flops_dense += flops; c.bytes_dense += bytes;
     e->last_ms = ms;
 }
 
@@ -253,16 +266,20 @@ static int yolo_alloc(vc_engine* e) {
     const int strides[3] = {8, 16, 32};
     for (int i = 0; i < 3; ++i) VC_TRY(dev_alloc(e, (void**)&e->d_logits[i], px(strides[i]) * lcs * sizeof(float)));
     if (e->prec == PREC_BF16) {
-        // sparse head: per level an 8-channel objectness plane and room for B x min(pixels per frame, max_candidates) gathered pixels
+        // sparse head: per level an 8-channel objectness plane and room for EVERY pixel of the batch in the gathered list (a
+        // pooled B x max_candidates capacity could overflow on one busy frame where the dense head, which only counts anchors with
+        // obj x cls > conf against max_candidates per frame, succeeds; 0.6 GB at B = 128 / 640 x 640 of 288 GB buys "cannot overflow")
         for (int i = 0; i < 3; ++i) {
             const size_t ppf = (size_t)(S / strides[i]) * (S / strides[i]);
-            e->hc_cap[i] = (int)(B * std::min(ppf, (size_t)e->cfg.max_candidates));
+            e->hc_cap[i] = (int)(B * ppf);
             VC_TRY(dev_alloc(e, &e->d_obj[i], px(strides[i]) * 8 * 2));
             VC_TRY(dev_alloc(e, (void**)&e->d_hc_list[i], (size_t)e->hc_cap[i] * sizeof(int)));
             VC_TRY(dev_alloc(e, &e->d_hc_x[i], (size_t)e->hc_cap[i] * c[2 + i] * 2));
             VC_TRY(dev_alloc(e, &e->d_hc_logits[i], (size_t)e->hc_cap[i] * lcs * 2));
         }
         VC_TRY(dev_alloc(e, (void**)&e->d_hc_count, 64));
+        VC_TRY(host_alloc(e, (void**)&e->h_hc_ring, (size_t)vc_engine::HC_RING * 4 * sizeof(int)));
+        memset(e->h_hc_ring, 0, (size_t)vc_engine::HC_RING * 4 * sizeof(int));
     }
     // post-processing
     const size_t mc = e->cfg.max_candidates, md = e->cfg.max_det;
@@ -364,14 +381,18 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     e->sparse_pass = e->prec == PREC_BF16 && e->opt.sparse_head && !e->want_pred_debug && e->d_hc_count;
     for (int i = 0; i < 3 && e->sparse_pass; ++i) {
         // sparse Detect head (detect_post.hip): objectness conv over every pixel -> gather the pixels that can pass conf_thres -> the
-        // full head on the gathered rows (row count on the device).  The algorithmic work reported is the dense head's.
+        // full head on the gathered rows (row count on the device).  The work reported is what RUNS (the gathered rows); the dense
+        // head's figures travel beside it as dense_* (round 3 credited the launch with the dense head's work: a 6 us launch showed
+        // 3.4 x the chip's peak in the per-layer table).
         const std::string hp = "model.24.m." + std::to_string(i);
         const View& x = heads[i];
         const double es = 2.0, Mh = (double)x.B * x.H * x.W;
         View ov{}; ov.ptr = e->d_obj[i]; ov.cs = 8; ov.co = 0;
         pb.conv(hp + ".obj", x, ov, 1, 1, 0, ACT_NONE);
         if (pb.status != VC_OK) break;
-        ops.back().flops_override = 2.0 * Mh * 3 * x.C; ops.back().bytes_override = 0;
+        ops.back().flops_override = 2.0 * Mh * 3 * x.C;                                    // the three objectness rows (the launch covers 8 zero-padded channels)
+        ops.back().bytes_override = (Mh * x.C + 8.0 * x.C) * es + Mh * 8 * es;
+        ops.back().dense_flops = 0; ops.back().dense_bytes = 0;                            // the dense head has no such launch: its work is on the head conv below
         { Op op{}; op.kind = Op::HEAD_COMPACT; op.level = i; op.a = x; ops.push_back(op); }
         View gx{}; gx.ptr = e->d_hc_x[i]; gx.B = 1; gx.H = 1; gx.W = e->hc_cap[i]; gx.C = x.C; gx.cs = x.C; gx.co = 0;
         View go{}; go.ptr = e->d_hc_logits[i]; go.cs = lcs; go.co = 0;
@@ -380,8 +401,12 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
         Op& hop = ops.back();
         hop.cout_logical = hop.conv.Cout; hop.conv.Cout = lcs;
         hop.conv.m_dev = e->d_hc_count + i;
-        hop.flops_override = 2.0 * Mh * (no - 3) * x.C;
-        hop.bytes_override = (Mh * x.C + (double)no * x.C) * es + Mh * lcs * es;      // the dense head's in + weights + out
+        // executed: the head on the gathered rows only (row count on the device, read back after the pass)
+        hop.rows_level = i;
+        hop.flops_override = 0; hop.bytes_override = (double)no * x.C * es;                // weights
+        hop.flops_per_row = 2.0 * no * x.C; hop.bytes_per_row = (x.C + (double)lcs) * es;  // one gathered feature row in, one logit row out
+        hop.dense_flops = 2.0 * Mh * no * x.C;
+        hop.dense_bytes = (Mh * x.C + (double)no * x.C) * es + Mh * lcs * es;              // the dense head's in + weights + out
     }
     for (int i = 0; i < 3 && !e->sparse_pass; ++i) {
         View o{}; o.ptr = e->d_logits[i]; o.cs = lcs; o.co = 0;
@@ -470,10 +495,13 @@ static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
 
 // in-flight profiling of one conv launch (see vc_engine::prof_async): the launch itself reports its start / stop timestamps
 // into an event pair (hipExtLaunchKernel), no host wait
-static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes) {
+static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes, const Op& op) {
     if (!e->prof_async || e->profiling || e->prof_used >= e->prof_pairs.size()) return;
     vc_engine::ProfPair& pp = e->prof_pairs[e->prof_used++];
     pp.flops = flops; pp.bytes = bytes;
+    pp.rows = op.rows_level >= 0 && e->h_hc_ring ? e->h_hc_ring + (size_t)e->hc_ring_cur * 4 + op.rows_level : nullptr;
+    pp.flops_per_row = op.flops_per_row; pp.bytes_per_row = op.bytes_per_row;
+    pp.flops_dense = op.dense_flops >= 0 ? op.dense_flops : -1; pp.bytes_dense = op.dense_bytes >= 0 ? op.dense_bytes : -1;   // -1: same as executed
     cp.ev_start = pp.a; cp.ev_stop = pp.b;
 }
 
@@ -488,10 +516,11 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                                                          : ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
                                                                (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
                 ConvP cp = op.conv;
+                double fl_exec = -1;                                          // executed FLOPs when they differ from `fl` (device-side row count)
                 static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
                 const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
-                conv_timer_arm(e, cp, fl, by);
+                conv_timer_arm(e, cp, fl, by, op);
                 if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only the u8 stem can run it
                     VC_CHECK(stem_direct_on && stem_u8_applicable(cp, e->stem_geom), VC_ERR_STATE, "letterbox fold-in: the direct stem does not apply");
                 const int front_fused_mode = e->opt.front_fused;   // 0 off, 1 stream path, 2 always
@@ -507,7 +536,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     double wbytes = 0;
                     for (int j = 0; j <= 3; ++j) wbytes += (double)ops[oi + j].conv.Cout * ops[oi + j].conv.K * es;
                     const double byc = (double)cp.B * cp.H * cp.W * cp.Cin * es + wbytes + (double)o3.M * o3.Cout * es;
-                    cp.cfg = 103;
+                    cp.cfg = 103; cp.ablate = e->opt.c3_ablate;
                     if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flc; e->prof_pairs[e->prof_used - 1].bytes = byc; }   // the pair armed above times all four layers
                     {
                         ProfScope ps(e, VC_PROF_CONV, flc, byc, s);
@@ -564,7 +593,7 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     const Op& o1 = *nx;
                     const double fl1 = 2.0 * o1.conv.M * (double)o1.conv.Cout * o1.C;
                     const double by01 = ((double)cp.B * cp.H * cp.W * cp.Cin + (double)cp.Cout * cp.K + (double)o1.conv.Cout * o1.conv.K) * es + (double)o1.conv.M * o1.conv.Cout * es;
-                    cp.cfg = 102;
+                    cp.cfg = 102; cp.ablate = e->opt.ff_ablate;
                     if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = fl + fl1; e->prof_pairs[e->prof_used - 1].bytes = by01; }   // the pair armed above now times both layers
                     ProfScope ps(e, VC_PROF_CONV, fl + fl1, by01, s);
                     const bool u8 = e->stem_src && cp.in == e->ybuf["in"].ptr;
@@ -586,14 +615,31 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     ++oi;                                                    // the pool op is done
                 } else {
                     cp.cfg = cp.m_dev ? -1 : tuned_cfg(e, cp, s);          // a device-side row count: the implicit-GEMM heuristic (the only family that honours it)
-                    ProfScope ps(e, VC_PROF_CONV, fl, by, s);
-                    VC_TRY(launch_conv(cp, s));
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, fl, by, s);
+                        VC_TRY(launch_conv(cp, s));
+                    }
+                    if (e->profiling && (op.rows_level >= 0 || op.dense_flops >= 0)) {   // blocking profile: the scope has synchronised
+                        ProfCat& pc = e->prof[VC_PROF_CONV];
+                        double fe = fl, be = by;
+                        if (op.rows_level >= 0) {                            // executed work = fixed part + gathered rows x per-row work
+                            int rows = 0;
+                            VC_HIP(hipMemcpy(&rows, e->d_hc_count + op.rows_level, sizeof(int), hipMemcpyDeviceToHost));
+                            rows = std::min(rows, e->hc_cap[op.rows_level]);
+                            fe += rows * op.flops_per_row; be += rows * op.bytes_per_row;
+                            pc.flops += fe - fl; pc.bytes += be - by;
+                            fl_exec = fe;
+                        }
+                        // the scope credited (fl, by) to the dense-equivalent accumulators as well: replace them by the dense head's figures
+                        pc.flops_dense += (op.dense_flops >= 0 ? op.dense_flops : fe) - fl;
+                        pc.bytes_dense += (op.dense_bytes >= 0 ? op.dense_bytes : be) - by;
+                    }
                 }
                 if (e->profiling && e->op_log.size() < (1u << 20)) {
                     char line[256];
                     const ConvP& c = op.conv;
                     snprintf(line, sizeof(line), "%s M=%d N=%d K=%d k=%dx%d s=%d cfg=%d ms=%.4f tflops=%.1f\n", c.M > 0 ? "conv" : "?", c.M, c.Cout, c.K,
-                             c.kh, c.kw, c.sh, cp.cfg, e->last_ms, fl / (e->last_ms * 1e-3) / 1e12);
+                             c.kh, c.kw, c.sh, cp.cfg, e->last_ms, (fl_exec >= 0 ? fl_exec : fl) / (e->last_ms * 1e-3) / 1e12);
                     e->op_log += line;
                 }
                 break;
@@ -643,11 +689,14 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
     e->l0_stale = false;
     if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
+        e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
         VC_HIP(hipMemsetAsync(e->d_hc_count, 0, 64, ds));
         VC_HIP(hipMemsetAsync(e->post.overflow, 0, sizeof(int) * B, ds));
         VC_HIP(hipMemsetAsync(e->post.cand_count, 0, sizeof(int) * B, ds));
     }
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
+    if (e->sparse_pass && e->prof_async && e->h_hc_ring)     // executed-work accounting: this pass's gathered-row counts, next to the event pairs
+        VC_HIP(hipMemcpyAsync(e->h_hc_ring + (size_t)e->hc_ring_cur * 4, e->d_hc_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ds));
     // decode + NMS
     const int nc = e->cfg.num_classes, no = nc + 5, lcs = round_up(3 * no, 8);
     DecodeLevel lv[3];
@@ -839,9 +888,18 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     // runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): two of the engine's streams on one queue
     // serialise, e.g. a batch's PCIe copy in front of the detector kernels of the batch before it.  Measured on the second engine of a
     // process (the first happens to get distinct queues): 15.1 k -> 17.3 k frames/s with host frames, 17.7 k -> 18.6 k device-resident.
-    // A default, not an override (the runtime reads it when it builds its queue pool; an application that has created streams before
-    // its first engine has to set it itself).
-    setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+    // GPU_MAX_HW_QUEUES >= 8 is therefore a DEPLOYMENT requirement; the runtime reads it once, when it builds its queue
+    // pool, so the embedding application has to export it before its first HIP call.  The library does not touch the process
+    // environment (setenv is not thread-safe against concurrent getenv); the Python binding sets a default at import
+    // (_lib.py), and an engine created without it says so once.
+    {
+        static bool warned = false;
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        if (!warned && (!q || atoi(q) < 8) && !getenv("VC_QUIET")) {
+            warned = true;
+            fprintf(stderr, "libvcount_hip: GPU_MAX_HW_QUEUES is %s; export GPU_MAX_HW_QUEUES=8 before the first HIP call or the engine's streams share hardware queues (INTEGRATION.md)\n", q ? q : "unset");
+        }
+    }
     int ndev = 0;
     VC_HIP(hipGetDeviceCount(&ndev));
     VC_CHECK(cfg->device >= 0 && cfg->device < ndev, VC_ERR_HIP, "device %d not present (%d visible)", cfg->device, ndev);
@@ -1024,7 +1082,8 @@ int vc_engine_finalize(vc_engine* e) {
 }
 
 // Kernel-selection switches of a live engine (the parity tests compare a fused kernel with the launches it replaces on the same
-// engine).  Initial values come from the environment at vc_engine_create; the launch path itself never calls getenv.
+// engine).  Initial values come from the environment at vc_engine_create; the launch path itself never calls getenv (what is left in
+// the launchers are function-local statics initialised once per process: VC_CONV_RESERVE, VC_CONV_PERSIST and the A/B switches).
 int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     VC_CHECK(e && name, VC_ERR_ARG, "null argument");
     const std::string n = name;
@@ -1034,8 +1093,41 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "front_fused") e->opt.front_fused = value;
     else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
     else if (n == "sparse_head") e->opt.sparse_head = value;
+    else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
+    else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
     else { set_error("unknown option '%s'", name); return VC_ERR_NOTFOUND; }
+    return VC_OK;
+}
+
+int vc_tune_export(vc_engine* e, char* buf, size_t cap, size_t* size) {
+    VC_CHECK(e && size, VC_ERR_ARG, "null argument");
+    std::string text;
+    for (const auto& kv : e->tuned) text += kv.first + " " + std::to_string(kv.second) + "\n";
+    *size = text.size() + 1;
+    if (!buf) return VC_OK;
+    VC_CHECK(cap >= text.size() + 1, VC_ERR_CAPACITY, "vc_tune_export: %zu bytes needed", text.size() + 1);
+    memcpy(buf, text.c_str(), text.size() + 1);
+    return VC_OK;
+}
+
+int vc_tune_import(vc_engine* e, const char* text) {
+    VC_CHECK(e && text, VC_ERR_ARG, "null argument");
+    const char* p = text;
+    int n = 0, cfg = 0, used = 0;
+    char key[200];
+    while (sscanf(p, "%199s %d%n", key, &cfg, &used) == 2) {
+        VC_CHECK(cfg >= -1 && cfg < conv_num_cfgs(), VC_ERR_ARG, "vc_tune_import: tile configuration %d of '%s' does not exist in this build", cfg, key);
+        e->tuned[key] = cfg;
+        p += used; ++n;
+    }
+    while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r') ++p;
+    VC_CHECK(*p == 0, VC_ERR_ARG, "vc_tune_import: malformed text after %d entries", n);
+    {   // the engines of this process on the same device follow (tuned_cfg consults g_tuned before timing anything)
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        for (const auto& kv : e->tuned) g_tuned["d" + std::to_string(e->cfg.device) + "_" + kv.first] = kv.second;
+    }
+    if (n) e->tuned_dirty = true;
     return VC_OK;
 }
 
@@ -1226,7 +1318,11 @@ int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double
             float t = 0.f, t0 = 0.f;
             if (hipEventElapsedTime(&t, e->prof_pairs[i].a, e->prof_pairs[i].b) != hipSuccess) continue;
             ProfCat& c = e->prof[VC_PROF_CONV];
-            c.ms += t; c.flops += e->prof_pairs[i].flops; c.bytes += e->prof_pairs[i].bytes; c.launches += 1;
+            const vc_engine::ProfPair& pp = e->prof_pairs[i];
+            const double rows = pp.rows ? (double)*pp.rows : 0.0;              // the pass's D2H copy of the row count has completed (streams synchronised above)
+            const double fe = pp.flops + rows * pp.flops_per_row, be = pp.bytes + rows * pp.bytes_per_row;
+            c.ms += t; c.flops += fe; c.bytes += be; c.launches += 1;
+            c.flops_dense += pp.flops_dense >= 0 ? pp.flops_dense : fe; c.bytes_dense += pp.bytes_dense >= 0 ? pp.bytes_dense : be;
             if (hipEventElapsedTime(&t0, e->prof_pairs[0].a, e->prof_pairs[i].a) == hipSuccess) iv.emplace_back(t0, t0 + t);
         }
         // how much of the wall-clock window between the first start and the last stop had at least one conv kernel running
@@ -1249,6 +1345,15 @@ int vc_profile_read(vc_engine* e, int cat, double* ms, int64_t* launches, double
     if (launches) *launches = e->prof[cat].launches;
     if (flops) *flops = e->prof[cat].flops;
     if (bytes) *bytes = e->prof[cat].bytes;
+    return VC_OK;
+}
+
+// The same category with the sparse Detect head credited as the DENSE head it replaces (the algorithmic work of the reference's
+// Detect.m[i] over every pixel): kept apart from vc_profile_read, whose figures are the work the launches execute.
+int vc_profile_read_dense(vc_engine* e, int cat, double* flops_dense, double* bytes_dense) {
+    VC_CHECK(e && cat >= 0 && cat < VC_PROF_NCAT && flops_dense && bytes_dense, VC_ERR_ARG, "bad argument");
+    VC_CHECK(!(cat == VC_PROF_CONV && e->prof_used > 0), VC_ERR_STATE, "call vc_profile_read first (it resolves the in-flight event pairs)");
+    *flops_dense = e->prof[cat].flops_dense; *bytes_dense = e->prof[cat].bytes_dense;
     return VC_OK;
 }
 
@@ -1300,6 +1405,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
         c.M = d->b * Ho * Wo;
         c.cfg = getenv("VC_CONV_CFG") ? atoi(getenv("VC_CONV_CFG")) : -1;
         c.ablate = getenv("VC_CONV_ABLATE") ? atoi(getenv("VC_CONV_ABLATE")) : 0;
+        c.slots = getenv("VC_CONV_SLOTS") ? atoi(getenv("VC_CONV_SLOTS")) : 0;       // tests: a short persistent grid walks all tiles
         long long* dbg = nullptr;
         const size_t dbg_n = (size_t)1 << 16;
         if (getenv("VC_CONV_DBG") && hipMalloc((void**)&dbg, dbg_n * 64) == hipSuccess) { hipMemset(dbg, 0, dbg_n * 64); c.dbg = dbg; }

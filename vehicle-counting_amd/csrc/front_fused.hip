@@ -374,7 +374,7 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     const uint4* x = (const uint4*)p0.in;
     uint16_t* y = (uint16_t*)p1.out;
     static const bool dbg_on = getenv("VC_FF_DBG") != nullptr;
-    const int abl = getenv("VC_FF_ABLATE") ? atoi(getenv("VC_FF_ABLATE")) : 0;       // diagnostics only (tools/ff_ablate.py)
+    const int abl = p0.ablate;                                                        // diagnostics only (engine option "ff_ablate", tools/ff_ablate.py)
     long long* dbg = nullptr;
     if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 64) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 64, s);
     if (src8 && abl) launch_timed(p0, front_fused_kernel<true, true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,

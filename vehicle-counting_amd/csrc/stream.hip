@@ -198,27 +198,32 @@ int issue_reid(vc_engine* e, vc_engine::Pending& pd) {
 }
 
 // A submission whose detections cannot be embedded (candidate overflow, more boxes than max_crops, an empty crop) is DROPPED: the
-// error is reported once by the call that found it and the stream continues with the next submission (it used to stay
-// at the front of the queue and fail every following call).
+// error is reported once, by the call that CONSUMES that submission (vc_stream_run* / vc_stream_embed for its frames), and the stream
+// continues with the next one (it used to stay at the front of the queue and fail every following call).
 int issue_reid_or_drop(vc_engine* e, size_t idx) {
     const int st = issue_reid(e, e->pending[idx]);
     if (st != VC_OK) e->pending.erase(e->pending.begin() + idx);
     return st;
 }
 
-// If the detector of the next submission has finished, start its ReID now (it then overlaps the tracking in progress).
-int try_issue_next(vc_engine* e) {
+// Look-ahead: if the detector of the next submission has finished, start its ReID now (it then overlaps the tracking in progress).
+// Never fails on behalf of the look-ahead submission (a drop of batch n + 1 used to come back as the status of the
+// run_async / collect call made for batch n -- whose rows were then lost and whose job stayed queued behind the caller's back).  A
+// submission that cannot be embedded stays queued at stage 0 with `embed_refused` set; take_front runs the same checks again when the
+// caller asks for THAT batch, reports the error there and drops it.  issue_reid checks everything before it takes a feature / crop
+// slot, so the refused attempt leaves no state behind.
+void try_issue_next(vc_engine* e) {
     int next = -1;
     int embedded = 0;                                   // batches that own one of the three feature buffers
     for (size_t i = 0; i < e->pending.size(); ++i) {
         if (e->pending[i].stage == 0) { next = (int)i; break; }
         ++embedded;
     }
-    if (next < 0) return VC_OK;
+    if (next < 0 || e->pending[next].embed_refused) return;
     embedded += (int)e->jobs.size();
-    if (embedded >= 3) return VC_OK;
-    if (hipEventQuery(e->ev_det[e->pending[next].slot]) != hipSuccess) return VC_OK;
-    return issue_reid_or_drop(e, (size_t)next);
+    if (embedded >= 3) return;
+    if (hipEventQuery(e->ev_det[e->pending[next].slot]) != hipSuccess) return;
+    if (issue_reid(e, e->pending[next]) != VC_OK) e->pending[next].embed_refused = true;
 }
 
 }  // namespace
@@ -321,7 +326,8 @@ int vc_stream_run_async_multi(vc_engine* e, const int* trackers, int n_cam, int 
     VC_TRY(enqueue_batch_tracking(e, pd, trackers, num_classes, cam_of_frame, n_cam, job.stage, cap_rows_per_frame, job.ndet));
     e->jobs.push_back(std::move(job));
     g_tm.report();
-    return try_issue_next(e);
+    try_issue_next(e);
+    return VC_OK;
 }
 
 // Results of the oldest asynchronous batch (blocks until its tracker kernel has finished).  While waiting, the ReID of the
@@ -333,14 +339,15 @@ int vc_stream_collect(vc_engine* e, int64_t* out_rows6, int cap_rows_per_frame, 
     const vc_engine::AsyncJob& front = e->jobs.front();
     VC_CHECK(front.b == b && front.cap == cap_rows_per_frame, VC_ERR_ARG, "collect: batch of %d frames x %d rows expected", front.b, front.cap);
     while (hipEventQuery(e->tstage[front.stage].done) == hipErrorNotReady) {
-        VC_TRY(try_issue_next(e));
+        try_issue_next(e);
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     vc_engine::AsyncJob job = std::move(e->jobs.front());
     e->jobs.pop_front();
     VC_TRY(track_collect(e, job.stage, out_rows6, cap_rows_per_frame, out_m));
     if (out_ndet) memcpy(out_ndet, job.ndet.data(), (size_t)b * sizeof(int));
-    return try_issue_next(e);
+    try_issue_next(e);
+    return VC_OK;
 }
 
 int vc_stream_run(vc_engine* e, const int* trackers, int num_classes, const void* frames_dev, int b, int h, int w,

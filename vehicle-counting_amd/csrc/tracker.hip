@@ -275,17 +275,18 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
         VC_TRY(dev_alloc(e, (void**)&e->d_track_scratch, bytes));
         e->track_scratch_bytes = bytes;
     }
-    // appearance-table arena: grown to what this batch needs (bounded by dot_arena_max_floats); a batch that does not fit runs the
-    // instance that computes its appearance rows inside the walk
+    // appearance-table arena: grown to what this batch needs (bounded by dot_arena_max_floats).  When every tracker's table fits for
+    // certain the lean kernel instance runs; otherwise the arena still grows towards the bound (it used to stay at its
+    // 16-byte initial size then, and the per-tracker fit check on the device sent EVERY tracker to the in-walk appearance rows although
+    // most tables would have fitted) and the general instance serves the trackers whose tables fit from it.
     const bool tables_fit = all_tables && table_floats <= (long long)e->dot_arena_max_floats && table_rows <= (long long)e->row_src_cap;
-    if (tables_fit && (size_t)table_floats > e->dot_arena_floats) {
+    const size_t want_now = (size_t)std::min<long long>(std::max<long long>(table_floats, 0), (long long)e->dot_arena_max_floats);
+    if (want_now > e->dot_arena_floats) {
         VC_TRY(track_idle(e));
         VC_HIP(hipStreamSynchronize(e->stream));
-        const size_t want = std::min(e->dot_arena_max_floats, std::max((size_t)table_floats * 3 / 2, (size_t)1 << 22));
-        float* fresh = nullptr;
-        VC_HIP(hipMalloc((void**)&fresh, want * sizeof(float)));
-        for (void*& q : e->allocs) if (q == (void*)e->d_dot_arena) { (void)hipFree(q); q = fresh; }
-        e->d_dot_arena = fresh; e->dot_arena_floats = want;
+        const size_t want = std::min(e->dot_arena_max_floats, std::max(want_now * 3 / 2, (size_t)1 << 22));
+        VC_TRY(dev_realloc(e, (void**)&e->d_dot_arena, want * sizeof(float)));
+        e->dot_arena_floats = want;
     }
     for (auto& td : s.tracker_dets) e->trackers[td.first]->pending_dets += td.second;
     hipStream_t ts = e->stream;

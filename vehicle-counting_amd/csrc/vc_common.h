@@ -138,6 +138,8 @@ struct ConvP {
                          // implicit-GEMM family (conv_igemm_kernel) honours it
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
     int s2_th, s2_tw;    // set by the launcher of conv3x3s2_halo_kernel: its output tile rectangle (rows x columns)
+    int slots;           // tests only: > 0 forces the persistent grid to this many workgroups (long tile walks); set by vc_conv2d_host from
+                         // VC_CONV_SLOTS -- the launchers themselves never read the environment
     int ablate;          // diagnostics only (VC_CONV_ABLATE, timing experiments with wrong results): 1 = no staging DMA after the first tiles,
                          // 2 = no output stores, 3 = both, 6 = return at once (launch floor of the grid); per-phase times come from dbg
 };

@@ -74,7 +74,7 @@ class Engine:
         L.check(L.lib().vc_engine_sync(self._h))
 
     def set_option(self, name, value):
-        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "crop_per_pixel", "dot_arena_mb")."""
+        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "sparse_head", "crop_per_pixel", "dot_arena_mb"; diagnostics: "ff_ablate", "c3_ablate")."""
         L.check(L.lib().vc_engine_set_option(self._h, name.encode(), int(value)))
 
     def stream_reset(self):
@@ -346,6 +346,24 @@ class Engine:
         u, sp = C.c_double(), C.c_double()
         L.check(L.lib().vc_profile_conv_busy(self._h, C.byref(u), C.byref(sp)))
         return u.value, sp.value
+
+    def profile_read_dense(self, cat):
+        """(flops, bytes) of the category with the sparse Detect head credited as the dense head it replaces (after profile_read)."""
+        fl, by = C.c_double(), C.c_double()
+        L.check(L.lib().vc_profile_read_dense(self._h, cat, C.byref(fl), C.byref(by)))
+        return fl.value, by.value
+
+    def tune_export(self) -> str:
+        """Conv autotune choices of this engine as text (the VC_TUNE_CACHE file format)."""
+        n = C.c_size_t()
+        L.check(L.lib().vc_tune_export(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        L.check(L.lib().vc_tune_export(self._h, buf, n.value, C.byref(n)))
+        return buf.value.decode()
+
+    def tune_import(self, text: str):
+        """Adopt another engine's autotune choices (before the first launch of those shapes)."""
+        L.check(L.lib().vc_tune_import(self._h, text.encode()))
 
     def profile_read(self, cat):
         ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()

@@ -96,6 +96,41 @@ def allgather_counts_native(engine, local_counts):
     return out.reshape((world * t.shape[0],) + t.shape[1:])
 
 
+def share_tune_cache(engine, warm=None, src=0):
+    """Rank `src` runs `warm()` (its conv autotune: one pass over every shape the run will use), exports the choices and broadcasts
+    them; every other rank imports them BEFORE its own first launches.  N ranks then time the candidates once instead of N times, and
+    -- what matters for parity -- all ranks run the same tile configuration for every layer (two members of a near-tie from different
+    kernel families may differ in the last bf16 bit).  Single process: just runs `warm`.  Returns the text."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if rank == src and warm is not None:
+        warm()
+    text = engine.tune_export() if rank == src else None
+    if world > 1:
+        obj = [text]
+        dist.broadcast_object_list(obj, src=src)
+        text = obj[0]
+        if rank != src:
+            engine.tune_import(text)
+    return text
+
+
+def gather_compact(padded, counts):
+    """vc_gather_compact_host through ctypes: padded (world, max_rows, ...) rank-major blocks -> the first sum(counts) rows."""
+    import ctypes as C
+
+    from . import _lib as L
+    a = np.ascontiguousarray(padded)
+    world, max_rows = a.shape[0], a.shape[1]
+    row_bytes = int(a.dtype.itemsize * int(np.prod(a.shape[2:], dtype=np.int64)))
+    cnt = np.ascontiguousarray(counts, dtype=np.int32)
+    out = np.zeros((world * max_rows,) + a.shape[2:], a.dtype)
+    total = C.c_int64()
+    L.check(L.lib().vc_gather_compact_host(C.c_void_p(a.ctypes.data), world, max_rows, row_bytes, L.ptr(cnt, C.c_int), C.c_void_p(out.ctypes.data),
+                                           world * max_rows, C.byref(total)))
+    return out[: total.value]
+
+
 def shard_streams(n_streams, rank, world):
     """Stream i is owned by rank i % world (whole streams only: tracker state never shards below a camera)."""
     return [i for i in range(n_streams) if i % world == rank]
