@@ -80,6 +80,12 @@ def host_cpu_info():
     return info
 
 
+# The same detector on the reference's real geometry (1280 x 720 frames -> 384 x 640 tensor, Q8): the seeded random head is calibrated per
+# frame geometry (tools/head_calib.py, VC_FRAME_HW=720,1280: obj_shift 6 -> 1 box per frame, 8 -> 21) so that the point carries the
+# headline's ~15 detections per frame through ReID and the tracker
+WL_720P = dict(WORKLOADS["s640-bf16"], obj_shift=7.8, desc="YOLOv5s, 1280x720 frames (384x640 tensor, Q8), single camera stream per GPU, bf16 convs")
+
+
 def cpu_baseline(ysd, rsd, frames, n_frames, repeats=3):
     """The oracle (CPU port of the reference path) timed on this box's host cores over a bounded sample: `repeats` runs of the same
     n_frames-frame sample on one thread per PHYSICAL core (lscpu), the median reported, every run listed."""
@@ -563,9 +569,13 @@ def main():
             "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True),
             # the boundary the reference itself calls: batch_size = 1 through the drop-in classes, host frames
             "dropin_bs1": lambda: dropin_point(wl, local, (640, 640), 256, ZONE),
-            "dropin_bs1_720p": lambda: dropin_point(wl, local, (720, 1280), 256, ZONE_720P),
+            "dropin_bs1_720p": lambda: dropin_point(WL_720P, local, (720, 1280), 256, ZONE_720P),
             # the reference's only real input geometry (Q8, networks/yolo.py:69-70; demo/sample/cam_04.json): 1280 x 720 frames -> 384 x 640 tensor
-            "s720p_bf16": qp(frame_hw=(720, 1280), zone=ZONE_720P, clip=256, steps=12, warmup=3, full=True),
+            "s720p_bf16": qp(WL_720P, frame_hw=(720, 1280), zone=ZONE_720P, clip=256, steps=12, warmup=3, full=True),
+            # the same frames with the clip's 12 ground-truth rectangles injected after the detector has run in full (the random head needs
+            # obj_shift 7.8 at this geometry: thousands of candidates per frame reach the NMS and persistent noise boxes load the tracker --
+            # artefacts of the synthetic head, not of the geometry)
+            "s720p_bf16_K12_injected": qp(frame_hw=(720, 1280), zone=ZONE_720P, n_obj=12, inject=12, clip=256, steps=12, warmup=3, full=True),
             # batch-size sweep of the headline stream (frames per vc_stream_* call) with the submit -> rows latency of a batch
             "batch_sweep": lambda: {f"B{b}": quick_point(wl, rank, local, dev, world, B=b, clip=256, steps=max(8, min(128, 512 // b)), warmup=max(3, min(16, 64 // b)))
                                     for b in (1, 8, 16, 32, 128)},

@@ -210,10 +210,14 @@ def test_crop_resize_per_crop_kernel(frames):
     eng.close()
 
 
-@pytest.mark.parametrize("hw", [(640, 640), (360, 640), (480, 352)])
+@pytest.mark.parametrize("hw", [(640, 640), (360, 640), (480, 352), (720, 1280), (333, 500), (1080, 1920)])
 def test_front_fused_layers_0_1_bit_identical(hw):
     """front_fused.hip (stem + 3x3/s2 conv in one kernel, layer 0 kept in LDS; used by the stream path on u8 frames) against the
-    two separate launches of vc_detect on the same frames: layer 1 identical bit for bit, letterbox padding rows included."""
+    separate launches of vc_detect on the same frames (letterbox kernel, stem, conv): layer 1 identical bit for bit, letterbox padding
+    rows included.  Round 4: geometries that need the letterbox RESIZE take the fused kernel too (the 11-bit fixed-point bilinear of
+    cv::resize evaluated at patch-build time): 1280x720 -> 640x360 (the reference's demo video, Q8: scale 1/2), 480x352 and 333x500
+    (up-scaling by 4/3 and 1.28, source rows whose byte alignment changes from row to row); 1920x1080 (scale 1/3) does not fit the
+    kernel's staging area and keeps the separate launches."""
     import torch
     H, W = hw
     nc = 8
@@ -242,7 +246,7 @@ def test_front_fused_layers_0_1_bit_identical(hw):
         b0 = None
     if b0 is not None:                                            # ... unless the geometry took the two-launch path, which writes it
         np.testing.assert_array_equal(a0, b0)
-    assert (b0 is None) == (hw != (480, 352)), hw
+    assert (b0 is None) == (hw != (1080, 1920)), hw
     assert a1.shape == b1.shape and np.abs(a1).max() > 0.5
     np.testing.assert_array_equal(a1, b1)
     np.testing.assert_array_equal(a2, b2)

@@ -45,22 +45,7 @@ template <> struct Vec<false> {           // 8 x bf16, held as f32
 };
 
 // ------------------------------------------------------------------------------------------ letterbox (A5)
-// cv::resize INTER_LINEAR on 8-bit data: 11-bit fixed point coefficients, see oracle/imageops.py.
-__device__ __forceinline__ void lin_coef(int d, int src, double scale, int& s0, int& s1, int& c0, int& c1, bool horizontal) {
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    int s = (int)floorf(f);
-    f -= (float)s;
-    if (horizontal) {
-        if (s < 0) { s = 0; f = 0.f; }
-        if (s >= src - 1) { s = src - 1; f = 0.f; }
-        s0 = s; s1 = min(s + 1, src - 1);
-    } else {
-        s0 = min(max(s, 0), src - 1); s1 = min(max(s + 1, 0), src - 1);
-    }
-    c0 = min(max(__float2int_rn((1.f - f) * 2048.f), -32768), 32767);
-    c1 = min(max(__float2int_rn(f * 2048.f), -32768), 32767);
-}
-
+// cv::resize INTER_LINEAR on 8-bit data: 11-bit fixed point coefficients (lin_coef, vc_common.h; see oracle/imageops.py).
 template <bool F32>
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, void* __restrict__ dst, int B, LetterboxGeom g) {
     const long total = (long)B * g.net_h * g.net_w;

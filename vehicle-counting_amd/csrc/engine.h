@@ -43,7 +43,14 @@ struct Op {
     int C = 0;
     int cout_logical = 0;            // > 0: the launch covers zero-padded output channels, FLOPs count this many
     int param = -1;                  // index into Net::params for CONV
+    int tuned = -2;                  // CONV: tile configuration resolved at the first launch of this (cached) op; -2 = not yet
 };
+
+// The op list of one network pass is a pure function of its shape: built once per (batch, tensor size, head variant) / (crop count)
+// and replayed -- at batch 1 (the reference's own loop, vc_detect + vc_videotracker_run per frame) rebuilding 70 ops with their
+// string-keyed parameter look-ups and autotune keys cost more host time than launching them.
+struct YoloPlan { std::vector<Op> ops; View layer_view[24]; bool sparse = false; };
+struct ReidPlan { std::vector<Op> ops; View out{}; };
 
 struct Net {
     std::vector<ConvParam> params;
@@ -113,6 +120,8 @@ struct vc_engine {
     int ch[5] = {0, 0, 0, 0, 0}, rep[4] = {0, 0, 0, 0};
     std::map<std::string, vc::View> ybuf;        // named activation buffers (max shape)
     vc::View layer_view[24];
+    std::map<std::vector<int>, vc::YoloPlan> yolo_plans;          // key: B, nh, nw, sparse head?
+    std::map<std::pair<int, int>, vc::ReidPlan> reid_plans;   // key: first crop, crop count
     uint8_t* d_frames = nullptr;                 // staging for host images / stream frames
     size_t d_frames_bytes = 0;
     float* d_logits[3] = {nullptr, nullptr, nullptr};

@@ -505,9 +505,9 @@ static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes, 
     cp.ev_start = pp.a; cp.ev_stop = pp.b;
 }
 
-static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStream_t s) {
+static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s) {
     for (size_t oi = 0; oi < ops.size(); ++oi) {
-        const Op& op = ops[oi];
+        Op& op = ops[oi];
         switch (op.kind) {
             case Op::CONV: {
                 const double es = elem_size(op.conv.prec);
@@ -521,11 +521,12 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
                 const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
                 conv_timer_arm(e, cp, fl, by, op);
-                if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only the u8 stem can run it
-                    VC_CHECK(stem_direct_on && stem_u8_applicable(cp, e->stem_geom), VC_ERR_STATE, "letterbox fold-in: the direct stem does not apply");
                 const int front_fused_mode = e->opt.front_fused;   // 0 off, 1 stream path, 2 always
                 const bool fuse_front = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv) &&
                                         (front_fused_mode == 2 || (e->stem_src && cp.in == e->ybuf["in"].ptr));
+                if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only a u8 stem can run it (the resize: only the fused front)
+                    VC_CHECK(stem_direct_on && (stem_u8_applicable(cp, e->stem_geom) || (fuse_front && front_fused_resize_ok(e->stem_geom))), VC_ERR_STATE,
+                             "letterbox fold-in: no u8 stem kernel applies to this geometry");
                 const bool c3_fused_on = e->opt.c3_fused != 0;
                 const bool fuse_c3 = c3_fused_on && oi + 3 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV && ops[oi + 3].kind == Op::CONV &&
                                      c3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv, ops[oi + 3].conv);
@@ -614,7 +615,8 @@ static int run_ops(vc_engine* e, const std::vector<Op>& ops, int aux_cat, hipStr
                     VC_TRY(launch_reid_stem_pool(cp, nx->b.ptr, s));
                     ++oi;                                                    // the pool op is done
                 } else {
-                    cp.cfg = cp.m_dev ? -1 : tuned_cfg(e, cp, s);          // a device-side row count: the implicit-GEMM heuristic (the only family that honours it)
+                    if (op.tuned == -2) op.tuned = cp.m_dev ? -1 : tuned_cfg(e, cp, s);   // a device-side row count: the implicit-GEMM heuristic (the only family that honours it)
+                    cp.cfg = op.tuned;
                     {
                         ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                         VC_TRY(launch_conv(cp, s));
@@ -685,8 +687,18 @@ static LetterboxGeom letterbox_geom(int h0, int w0, int nh, int nw, bool swap_rb
 
 static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     hipStream_t ds = e->dstream;
-    std::vector<Op> ops;
-    VC_TRY(yolo_build_ops(e, B, nh, nw, ops));
+    const bool want_sparse = e->prec == PREC_BF16 && e->opt.sparse_head && !e->want_pred_debug && e->d_hc_count;
+    YoloPlan& plan = e->yolo_plans[{B, nh, nw, want_sparse ? 1 : 0}];
+    if (plan.ops.empty()) {
+        const int st = yolo_build_ops(e, B, nh, nw, plan.ops);
+        if (st != VC_OK) { plan.ops.clear(); return st; }
+        memcpy(plan.layer_view, e->layer_view, sizeof(plan.layer_view));
+        plan.sparse = e->sparse_pass;
+    } else {
+        memcpy(e->layer_view, plan.layer_view, sizeof(plan.layer_view));
+        e->sparse_pass = plan.sparse;
+    }
+    std::vector<Op>& ops = plan.ops;
     e->l0_stale = false;
     if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
         e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
@@ -744,8 +756,11 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     // bf16, frame already at network scale: the stem reads the u8 frames itself (same arithmetic per pixel, bit-identical stem
     // output) and the 8-byte-per-pixel letterboxed tensor is neither written nor read back
     static const bool fuse_on = !(getenv("VC_STEM_U8") && atoi(getenv("VC_STEM_U8")) == 0) && !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
-    const bool fuse = fuse_on && e->aux_prec == PREC_BF16 && g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0 &&
-                      e->ch[0] % 16 == 0 && e->ch[0] <= 64;
+    const bool same_scale = g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0;
+    // frames that need the resize (1280 x 720 -> 384 x 640, Q8): only front_fused_kernel evaluates it at patch-build time, so the fold-in
+    // needs that kernel to be the one that runs (YOLOv5s widths, bf16 engine, option on) and the tile's source footprint to fit its staging
+    const bool resize_ok = !same_scale && e->prec == PREC_BF16 && e->opt.front_fused > 0 && e->ch[0] == 32 && e->ch[1] == 64 && front_fused_resize_ok(g);
+    const bool fuse = fuse_on && e->aux_prec == PREC_BF16 && (same_scale || resize_ok) && e->ch[0] % 16 == 0 && e->ch[0] <= 64;
     e->stem_src = fuse ? d_frames : nullptr;
     e->stem_geom = g;
     e->in_stale = fuse;
@@ -814,7 +829,14 @@ static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     return VC_OK;
 }
 static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float* feat_out) {
-    std::vector<Op> ops;
+    if (e->reid_plans.size() > 8192) e->reid_plans.clear();                 // crop counts vary from call to call: bounded cache
+    ReidPlan& plan = e->reid_plans[{k0, k}];
+    std::vector<Op>& ops = plan.ops;
+    if (!ops.empty()) {
+        VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, rs));
+        ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs);
+        return launch_avgpool_l2norm(plan.out, feat_out, e->aux_prec, rs);
+    }
     PlanBuilder pb{e, &e->reid, &ops, e->aux_prec};
     auto& m = e->rbuf;
     View x = mkview(m["in"], k, 50, 50, reid_cpad(e->aux_prec), 0);
@@ -829,7 +851,8 @@ static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float
         if (b.down || b.cin != b.cout) sc = pb.conv(p + ".downsample", x, mkview(m[p + ".d"], k, 0, 0, b.cout, 0), 1, s, 0, ACT_NONE);
         x = pb.conv(p + ".conv2", t, mkview(m[p + ".y"], k, 0, 0, b.cout, 0), 3, 1, 1, ACT_RELU, &sc, RES_BEFORE_ACT);
     }
-    VC_TRY(pb.status);
+    if (pb.status != VC_OK) { const int st = pb.status; ops.clear(); return st; }
+    plan.out = x;
     VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, rs));
     { ProfScope ps(e, VC_PROF_REID_AUX, 0, 0, rs); VC_TRY(launch_avgpool_l2norm(x, feat_out, e->aux_prec, rs)); }               // model.py:70,93
     return VC_OK;

@@ -57,17 +57,28 @@ __device__ __forceinline__ f32x2f ff_silu2(f32x2f x) {
 }
 __device__ __forceinline__ int ff_l0_addr(int px, int chunk) { return (px * 4 + (chunk ^ ((px >> 1) & 2))) * 16; }   // byte offset in the layer-0 tile
 
-template <bool U8, bool DIAG = false>
+// Resize mode (RS, round 4): frames that are NOT at network scale (the reference's only real geometry, 1280 x 720 -> 384 x 640, Q8).
+// The letterbox's INTER_LINEAR resize (cv::resize on u8: 11-bit fixed point, aux_kernels.hip::letterbox_kernel) is evaluated when the
+// patch is built: the source rows / columns the tile's 70 x 70 tensor pixels sample are fetched as aligned 16-byte chunks into the raw
+// staging area (rs_rows x rs_chunks, planned by the launcher with the kernel's own lin_coef), the per-column and per-row taps and
+// coefficients of the tile are computed once into two small LDS tables, and every patch pixel is two rows x two taps x three bytes
+// from LDS.  Same integer arithmetic per pixel as the stand-alone kernel: layer 1 is bit-identical to letterbox + stem + conv.
+struct FrontRS { int rows, chunks; double sx, sy; };     // staged source rows per tile, 16-byte chunks per staged row, source / tensor scale
+#define FF_RS_NRAW 8              // raw chunks per thread in resize mode: rows x chunks <= 4 096 (1280 x 720 -> 640 x 360 stages 140 rows x 28 chunks = 3 920); more spills registers
+
+template <bool U8, bool DIAG = false, bool RS = false>
 __global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_kernel(const uint4* __restrict__ x, const uint4* __restrict__ w0, const float* __restrict__ b0,
                                                              const uint4* __restrict__ w1, const float* __restrict__ b1, uint16_t* __restrict__ y,
                                                              int B, int H, int Wp, int H0, int W0, int H1, int W1, int kw8_0, int kw8_1, int out_cs,
-                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl_arg) {
+                                                             int out_co, int tiles_x, int tiles_y, const uint8_t* __restrict__ src8, LetterboxGeom g, long long* dbg, int abl_arg, FrontRS rs) {
     const int abl = DIAG ? abl_arg : 0;        // the production instance folds every ablation branch away (they fragment the MFMA loops)
     // abl (VC_FF_ABLATE, diagnostics with WRONG results; 0 in production): 1 no transcendentals, 2 no stem MFMAs, 4 no stem LDS stores,
     // 8 no output stores, 16 no stem phase, 32 no conv phase, 64 no patch writes, 128 no global fetch, 256 no patch reads in the stem
     __shared__ uint4 patch[FF_PR * FF_PP];                 // 40.3 KB
     __shared__ uint4 l0t[FF_NT0 * 16 * 4];                 // 72.7 KB: [pixel slot][4 chunks], swizzled
     __shared__ uint4 w1s[9 * 4 * 64];                      // 36.9 KB: layer-1 weights, [tap][channel tile][lane] = one fragment load per wave
+    __shared__ int4 rs_col[RS ? 2 * FF_PC + 2 : 1];        // resize mode: per tensor column of the patch (byte offset of tap 0 / tap 1 in a staged row, a0, a1 or -1)
+    __shared__ int4 rs_row[RS ? FF_PR + 2 : 1];            // per tensor row of the patch (byte offset of source row y0 / y1 in the staging area, b0, b1 or -1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     // weights in registers for the whole launch
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_ke
     // The raw bytes wait in registers during the tile's compute like `pre` did, go to a raw staging area in LDS at the top of the next
     // tile (aliased with the layer-0 tile, which is dead between a tile's conv phase and the next tile's stem phase) and are converted
     // from there.  Out-of-buffer chunks (before the first / after the last frame) are buffer loads past num_records: zeros.
-    constexpr int NRAW = (FF_PR * FF_RAWC + NT - 1) / NT;   // 3
+    constexpr int NRAW = RS ? FF_RS_NRAW : (FF_PR * FF_RAWC + NT - 1) / NT;   // 3 (resize mode: 10)
     uint4 praw[NRAW];
     const __amdgpu_buffer_rsrc_t s8rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, U8 ? (int)((size_t)B * g.src_h * g.src_w * 3) : 0, 0x00020000);
     auto row_start = [&](int b, int gy0, int gx0, int pr, bool& valid) -> long long {       // byte offset of the source pixel under the patch row's first pixel
@@ -116,9 +127,33 @@ __global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_ke
         valid = uy >= 0 && uy < g.unpad_h;
         return (((long long)b * g.src_h + uy) * g.src_w + (2 * (gx0 - 1) - g.left)) * 3;
     };
+    // resize mode: first source row / column a tile samples = tap 0 of its first tensor row / column that lies inside the resized image
+    auto rs_origin = [&](int gy0, int gx0, int& srow0, int& scol0) {
+        const int uy = min(max(2 * gy0 - 2 - g.top, 0), g.unpad_h - 1), ux = min(max(2 * (gx0 - 1) - g.left, 0), g.unpad_w - 1);
+        int s1, c0, c1;
+        lin_coef(uy, g.src_h, rs.sy, srow0, s1, c0, c1, false);
+        lin_coef(ux, g.src_w, rs.sx, scol0, s1, c0, c1, true);
+    };
     auto fetch_raw = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int gy0 = 2 * ty * FF_TH - 1, gx0 = 2 * tx * FF_TW - 1;
+        if constexpr (RS) {
+            int srow0, scol0;
+            rs_origin(gy0, gx0, srow0, scol0);
+            const int total = rs.rows * rs.chunks;
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) {
+                const int c = threadIdx.x + k * NT;
+                const int r = c / rs.chunks, j = c - r * rs.chunks;
+                const int sr = min(srow0 + r, g.src_h - 1);                            // rows past the image are never sampled (taps clamp): any valid row will do
+                const long long rs0 = (((long long)b * g.src_h + sr) * g.src_w + scol0) * 3;
+                typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+                u32x4r v = {0u, 0u, 0u, 0u};
+                if (c < total && !(abl & 128)) v = __builtin_amdgcn_raw_buffer_load_b128(s8rd, (int)(((rs0 >> 4) << 4) + 16 * j), 0, 0);
+                praw[k] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NRAW; ++k) {
             const int c = threadIdx.x + k * NT;
@@ -183,7 +218,73 @@ __global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_ke
         long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
         if (dbg) ts0 = wall_clock64();
         __syncthreads();                                    // the previous tile's LDS reads are done
-        if constexpr (U8) {
+        if constexpr (U8 && RS) {
+            char* rawb = (char*)l0t;                        // staged source rows: [rs.rows][rs.chunks * 16] bytes in the (dead) layer-0 tile
+            const int total = rs.rows * rs.chunks, pitch = rs.chunks * 16;
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) {
+                const int c = threadIdx.x + k * NT;
+                if (c < total) *(uint4*)(rawb + c * 16) = praw[k];
+            }
+            int srow0, scol0;
+            rs_origin(gy0, gx0, srow0, scol0);
+            if (threadIdx.x < 2 * FF_PC) {                  // tensor column j of the patch: taps relative to the staged row's first fetched pixel
+                const int j = threadIdx.x, ix = 2 * (gx0 - 1) + j, ux = ix - g.left;
+                int4 e = make_int4(0, 0, -1, -1);           // a1 = -1: letterbox padding (114) or outside the tensor
+                if (ix >= 0 && ix < 2 * Wp && ux >= 0 && ux < g.unpad_w) {
+                    int x0, x1, a0, a1;
+                    lin_coef(ux, g.src_w, rs.sx, x0, x1, a0, a1, true);
+                    e = make_int4((x0 - scol0) * 3, (x1 - scol0) * 3, a0, a1);
+                }
+                rs_col[j] = e;
+            } else if (threadIdx.x >= 128 && threadIdx.x < 128 + FF_PR) {
+                const int pr = threadIdx.x - 128, iy = 2 * gy0 - 2 + pr, uy = iy - g.top;
+                int4 e = make_int4(0, 0, -1, -1);
+                if (iy >= 0 && iy < H && uy >= 0 && uy < g.unpad_h) {
+                    int y0, y1, c0, c1;
+                    lin_coef(uy, g.src_h, rs.sy, y0, y1, c0, c1, false);
+                    // byte position of source pixel scol0 of a staged row inside its first 16-byte chunk: differs from row to row unless src_w * 3 is a multiple of 16
+                    const long long q0 = (((long long)b * g.src_h + y0) * g.src_w + scol0) * 3, q1 = (((long long)b * g.src_h + y1) * g.src_w + scol0) * 3;
+                    e = make_int4((y0 - srow0) * pitch + (int)(q0 & 15), (y1 - srow0) * pitch + (int)(q1 & 15), c0, c1);
+                }
+                rs_row[pr] = e;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = threadIdx.x + k * NT;
+                if (i < FF_PR * FF_PC && !(abl & 64)) {
+                    const int pr = i / FF_PC, pc = i - pr * FF_PC;
+                    const int iy = 2 * gy0 - 2 + pr, ip = gx0 - 1 + pc;
+                    uint4 o = make_uint4(0u, 0u, 0u, 0u);                        // outside the network input: the stem's zero padding
+                    if (iy >= 0 && iy < H && ip >= 0 && ip < Wp) {
+                        const int4 rw = rs_row[pr];
+                        int pv[6] = {114, 114, 114, 114, 114, 114};
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int4 cl = rs_col[2 * pc + h];
+                            if (rw.w >= 0 && cl.w >= 0) {
+                                const uint8_t* r0 = (const uint8_t*)rawb + rw.x;
+                                const uint8_t* r1 = (const uint8_t*)rawb + rw.y;
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    const int h0 = r0[cl.x + c] * cl.z + r0[cl.y + c] * cl.w;
+                                    const int h1 = r1[cl.x + c] * cl.z + r1[cl.y + c] * cl.w;
+                                    const int v = (((rw.z * (h0 >> 4)) >> 16) + ((rw.w * (h1 >> 4)) >> 16) + 2) >> 2;
+                                    pv[3 * h + c] = min(max(v, 0), 255);
+                                }
+                                if (g.swap_rb) { const int tsw = pv[3 * h]; pv[3 * h] = pv[3 * h + 2]; pv[3 * h + 2] = tsw; }
+                            }
+                        }
+                        o.x = pack2_bf16(div255_exact((float)pv[0]), div255_exact((float)pv[1]));
+                        o.y = pack2_bf16(div255_exact((float)pv[2]), 0.f);
+                        o.z = pack2_bf16(div255_exact((float)pv[3]), div255_exact((float)pv[4]));
+                        o.w = pack2_bf16(div255_exact((float)pv[5]), 0.f);
+                    }
+                    patch[pr * FF_PP + pc] = o;
+                }
+            }
+        } else if constexpr (U8) {
             char* rawb = (char*)l0t;                        // raw source rows: [FF_PR][FF_RAWP] bytes in the (dead) layer-0 tile
 #pragma unroll
             for (int k = 0; k < NRAW; ++k) {
@@ -356,8 +457,41 @@ bool front_fused_applicable(const ConvP& p0, const ConvP& p1) {
            p1.B == p0.B && p1.H == p0.Ho && p1.W == p0.Wo && p1.K == 288 && p1.out_cs % 8 == 0 && p1.out_co % 8 == 0;
 }
 
+// Resize mode: what a tile has to stage.  For every tile row / column of the layer-1 output the source rows / columns its 70 tensor rows
+// / columns sample, with the kernel's own lin_coef (host and device agree bit for bit); the staging area is the layer-0 tile.
+static bool front_rs_plan(const LetterboxGeom& g, FrontRS& rs) {
+    if (g.unpad_h < 1 || g.unpad_w < 1 || g.net_h % 4 || g.net_w % 4) return false;
+    rs.sx = 1.0 / ((double)g.unpad_w / (double)g.src_w); rs.sy = 1.0 / ((double)g.unpad_h / (double)g.src_h);   // letterbox_kernel's scales
+    const int H1 = g.net_h / 4, W1 = g.net_w / 4;
+    const int tiles_x = (W1 + FF_TW - 1) / FF_TW, tiles_y = (H1 + FF_TH - 1) / FF_TH;
+    int rows = 1, bytes = 16;
+    for (int ty = 0; ty < tiles_y; ++ty) {
+        const int gy0 = 2 * ty * FF_TH - 1;
+        const int u0 = std::min(std::max(2 * gy0 - 2 - g.top, 0), g.unpad_h - 1), u1 = std::min(std::max(2 * gy0 - 2 + FF_PR - 1 - g.top, 0), g.unpad_h - 1);
+        int a0, a1, b0, b1, c0, c1;
+        lin_coef(u0, g.src_h, rs.sy, a0, a1, c0, c1, false);
+        lin_coef(u1, g.src_h, rs.sy, b0, b1, c0, c1, false);
+        rows = std::max(rows, b1 - a0 + 1);
+    }
+    for (int tx = 0; tx < tiles_x; ++tx) {
+        const int gx0 = 2 * tx * FF_TW - 1;
+        const int u0 = std::min(std::max(2 * (gx0 - 1) - g.left, 0), g.unpad_w - 1), u1 = std::min(std::max(2 * (gx0 - 1) + 2 * FF_PC - 1 - g.left, 0), g.unpad_w - 1);
+        int a0, a1, b0, b1, c0, c1;
+        lin_coef(u0, g.src_w, rs.sx, a0, a1, c0, c1, true);
+        lin_coef(u1, g.src_w, rs.sx, b0, b1, c0, c1, true);
+        bytes = std::max(bytes, (b1 - a0 + 1) * 3 + 15);           // + the worst position of the first pixel inside its 16-byte chunk
+    }
+    rs.rows = rows; rs.chunks = (bytes + 15) / 16;
+    // monotone taps: lin_coef's s0 / s1 never decrease with d, so the first / last tensor row bound every row in between
+    return (long)rs.rows * rs.chunks <= (long)FF_RS_NRAW * FF_NW * 64 && (size_t)rs.rows * rs.chunks * 16 <= sizeof(uint4) * FF_NT0 * 16 * 4;
+}
+
+bool front_fused_resize_ok(const LetterboxGeom& g) {
+    FrontRS rs;
+    return front_rs_plan(g, rs);
+}
+
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, const LetterboxGeom& g, hipStream_t s) {
-    if (!front_fused_applicable(p0, p1)) return VC_ERR_ARG;
     const int tiles_x = (p1.Wo + FF_TW - 1) / FF_TW, tiles_y = (p1.Ho + FF_TH - 1) / FF_TH;
     const int ntiles = p1.B * tiles_x * tiles_y;
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
@@ -377,12 +511,15 @@ int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* src8, co
     const int abl = p0.ablate;                                                        // diagnostics only (engine option "ff_ablate", tools/ff_ablate.py)
     long long* dbg = nullptr;
     if (dbg_on && hipMalloc((void**)&dbg, (size_t)grid * FF_NW * 64) == hipSuccess) hipMemsetAsync(dbg, 0, (size_t)grid * FF_NW * 64, s);
-    if (src8 && abl) launch_timed(p0, front_fused_kernel<true, true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
-                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
-    else if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B,
-                           p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
-    else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H,
-                      p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl);
+    const bool resize = src8 && !(g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0);
+    FrontRS rs{0, 0, 1.0, 1.0};
+    if (resize && !front_rs_plan(g, rs)) { set_error("front_fused: the resize geometry %dx%d -> %dx%d does not fit the staging area", g.src_h, g.src_w, g.unpad_h, g.unpad_w); return VC_ERR_ARG; }
+#define FF_ARGS x, (const uint4*)p0.w, p0.bias, (const uint4*)p1.w, p1.bias, y, p0.B, p0.H, p0.W, p0.Ho, p0.Wo, p1.Ho, p1.Wo, p0.Kp / 8, p1.Kp / 8, p1.out_cs, p1.out_co, tiles_x, tiles_y, src8, g, dbg, abl, rs
+    if (resize) launch_timed(p0, front_fused_kernel<true, false, true>, dim3(grid), dim3(FF_NW * 64), 0, s, FF_ARGS);
+    else if (src8 && abl) launch_timed(p0, front_fused_kernel<true, true>, dim3(grid), dim3(FF_NW * 64), 0, s, FF_ARGS);
+    else if (src8) launch_timed(p0, front_fused_kernel<true>, dim3(grid), dim3(FF_NW * 64), 0, s, FF_ARGS);
+    else launch_timed(p0, front_fused_kernel<false>, dim3(grid), dim3(FF_NW * 64), 0, s, FF_ARGS);
+#undef FF_ARGS
     VC_HIP(hipGetLastError());
     if (dbg) {
         hipStreamSynchronize(s);

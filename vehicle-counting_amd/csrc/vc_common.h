@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -101,6 +102,33 @@ __device__ __forceinline__ float div255_exact(float p) {
 }
 #endif
 
+// cv::resize INTER_LINEAR on 8-bit data (the letterbox of AutoShape): source taps s0 / s1 and their 11-bit fixed-point
+// coefficients c0 / c1 for destination index d; restated in oracle/imageops.py.  Host and device evaluate the same IEEE operations
+// (no contraction: the reference rounds the multiply and the subtraction separately), so a launcher can plan with it what a kernel
+// will fetch.  Used by letterbox_kernel (aux_kernels.hip) and by front_fused_kernel's resize mode.
+__host__ __device__ inline void lin_coef(int d, int src, double scale, int& s0, int& s1, int& c0, int& c1, bool horizontal) {
+#pragma clang fp contract(off)
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (horizontal) {
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        s0 = s; s1 = s + 1 < src - 1 ? s + 1 : src - 1;
+    } else {
+        s0 = s < 0 ? 0 : (s > src - 1 ? src - 1 : s);
+        s1 = s + 1 < 0 ? 0 : (s + 1 > src - 1 ? src - 1 : s + 1);
+    }
+    const float w0 = (1.f - f) * 2048.f, w1 = f * 2048.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r0 = __float2int_rn(w0), r1 = __float2int_rn(w1);
+#else
+    int r0 = (int)nearbyintf(w0), r1 = (int)nearbyintf(w1);           // round to nearest even, like v_cvt_i32_f32's default mode
+#endif
+    c0 = r0 < -32768 ? -32768 : (r0 > 32767 ? 32767 : r0);
+    c1 = r1 < -32768 ? -32768 : (r1 > 32767 ? 32767 : r1);
+}
+
 // ---- convolution as implicit GEMM (conv_igemm.hip) ----------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 enum ResMode : int { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
@@ -171,6 +199,7 @@ bool bneck_cv3_fused_applicable(const ConvP& pm1, const ConvP& pm2, const ConvP&
 int launch_bneck_cv3_fused(const ConvP& pm1, const ConvP& pm2, const ConvP& p3, hipStream_t s);
 bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
+bool front_fused_resize_ok(const LetterboxGeom& g);            // u8 frames that need the letterbox RESIZE: does the tile's source footprint fit the kernel's staging area?
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
 int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s);
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)
