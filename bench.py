@@ -144,7 +144,7 @@ def injected_detections(n_frames, hw, n_obj, seed):
 class Stream:
     """One camera stream on one engine: the three overlapped stages of the fused path."""
 
-    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1, frame_hw=None, zone=None):
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1, frame_hw=None, zone=None, distinct_cams=False):
         wl = dict(wl, precision=precision or wl["precision"])
         self.wl, self.dev = wl, dev
         self.B = B or wl["B"]
@@ -156,7 +156,7 @@ class Stream:
         clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
         self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
-        per_frame = max(64, 2 * max(inject, n_obj))
+        per_frame = max(160 if distinct_cams else 64, 2 * max(inject, n_obj))
         max_crops = max(512, self.B * per_frame)                     # (small batches: a single busy frame of the random head can carry > 64 boxes)
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
                             img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=max_crops,
@@ -175,6 +175,8 @@ class Stream:
         # headline -- other seeds draw 4 x more boxes from the random head
         one = synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True)
         per_cam = [one] * n_cam
+        if distinct_cams:                                            # eight different scenes (other seeds: other objects, and more boxes from the random head)
+            per_cam = [one] + [synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank + 101 * c, bounce=True) for c in range(1, n_cam)]
         self.frames = per_cam[0] if n_cam == 1 else np.stack(per_cam, 1).reshape((clip,) + per_cam[0].shape[1:])     # frame j: camera j % S, time j // S
         self.cams = np.tile(np.arange(n_cam, dtype=np.int32), self.B // n_cam)
         self.d_frames = torch.from_numpy(self.frames).to(dev)       # resident in HBM before the timed region
@@ -456,6 +458,7 @@ def dropin_point_(wl, local, frame_hw, n_frames, zone, n_obj=12, seed=1702):
     cam = {"cam": {"cam": {"tracking_config": dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)}}}
     pipe = CountingPipeline(args, config, cam, engine=eng, class_names=[str(c) for c in range(NC)])
     frames = synth_frames(n_frames, H, W, n_obj=n_obj, seed=seed, bounce=True)
+    eng.pretune(tuple(range(1, 65)))                                     # ReID conv autotune for every crop count a frame of this clip can bring (size buckets)
     warm = RefLoaderFrames(frames[:24])
     src = RefLoaderFrames(frames)
     pipe.run(warm, "cam", zone)                                          # conv autotune, first-use allocations; its trackers are discarded
@@ -567,6 +570,7 @@ def main():
             "l1280_fp8": qp(WORKLOADS["l1280-fp8"], steps=6, warmup=2, full=True),
             # BASELINE.json configs[3]'s 8 cameras on ONE GPU: 8 x 16 frames interleaved in every 128-frame batch (vc_stream_run_async_multi)
             "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True),
+            "s640_8cam_distinct_clips": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True, distinct_cams=True),
             # the boundary the reference itself calls: batch_size = 1 through the drop-in classes, host frames
             "dropin_bs1": lambda: dropin_point(wl, local, (640, 640), 256, ZONE),
             "dropin_bs1_720p": lambda: dropin_point(WL_720P, local, (720, 1280), 256, ZONE_720P),

@@ -127,6 +127,39 @@ def test_bench_config_bf16_track_level_tolerance(bench_case, tmp_path):
     assert cd <= 3, (counts, ref_counts)
 
 
+def test_timed_configuration_b128_autotuned_bf16_directly(tmp_path):
+    """"the exact configuration timed (B = 128, autotune on, bf16) is compared with nothing directly".  Here it is: bench.py's
+    weights and its 128-frame batch through submit / run_async / collect on a bf16 engine with max_batch = 128 and the autotuner ON (this
+    process's default, the tile configurations the timed run picks), against the fp32 engine on the same clip -- the mode whose CSV equals
+    the oracle's row for row (test_bench_config_fp32_csv_equals_oracle, test_rows_of_b128_equal_rows_of_b16[f32]).  Tolerance = the stated
+    bf16 track-level tolerance of DESIGN.md section 5 (found / id-consistent >= 0.70, box p95 <= 5 px, extra rows <= 0.45)."""
+    import sys
+
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_round3 import TRACK_KW, stream_rows
+    assert os.environ.get("VC_AUTOTUNE", "1") != "0", "this test is about the autotuned configuration"
+    T128 = 128
+    ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=1.0), synth_reid(1702)
+    frames = synth_frames(T128, H, W, n_obj=12, seed=1702, bounce=True)
+    dev = torch.from_numpy(frames).cuda()
+
+    def rows_of(precision, batch):
+        eng = E.Engine(ysd, rsd, precision=precision, num_classes=NC, max_batch=batch, max_frame_hw=(H, W), max_crops=batch * 64, max_tracks=8192, nn_budget_cap=60)
+        tids = [eng.tracker_create(**TRACK_KW) for _ in range(NC)]
+        per_frame = stream_rows(eng, tids, dev, batch, H, W)
+        eng.close()
+        return [{"frame_id": f + 1, "label": int(r[5]), "track_id": int(r[4]), "box": [int(v) for v in r[:4]], "direction": "-"}
+                for f, rows in enumerate(per_frame) for r in rows]
+    ref = rows_of("f32", 16)
+    got = rows_of("bf16", T128)                                     # one 128-frame batch, autotuned: what bench.py times
+    assert len(ref) > 100, len(ref)
+    a = track_level_agreement(got, ref)
+    print("bf16 B=128 autotuned vs fp32 engine:", a, "rows", len(got), "ref", len(ref))
+    assert a["found"] >= 0.70 and a["id_consistent"] >= 0.70, a
+    assert a["box_px_p95"] <= 5.0 and a["extra_rows"] <= 0.45, a
+
+
 def test_bench_config_bf16_against_the_bf16_restatement(bench_case, tmp_path):
     """How far apart are two CORRECT bf16 implementations of this network?  oracle/yolov5.py::forward(bf16=True) and oracle/reid.py::
     reid_forward_bf16 restate both networks in the product's arithmetic -- every weight, the input and every activation rounded to

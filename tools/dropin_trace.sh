@@ -6,6 +6,8 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/dropin}
 mkdir -p $OUT
 ROOT=$(pwd)
+export VC_TUNE_CACHE=$ROOT/$OUT/tune.txt      # the untraced run picks the tile configurations, the traced run launches no tuning candidates
+python tools/dropin_profile.py > /dev/null 2>&1
 python tools/dropin_profile.py > $OUT/untraced.json 2> $OUT/untraced.err
 cd /tmp && rm -rf /tmp/dt && rocprofv3 --kernel-trace --stats -d /tmp/dt -o d -- python $ROOT/tools/dropin_profile.py > $ROOT/$OUT/traced.json 2> $ROOT/$OUT/traced.err
 cd $ROOT
