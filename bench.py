@@ -160,7 +160,7 @@ class Stream:
         max_crops = max(512, self.B * per_frame)                     # (small batches: a single busy frame of the random head can carry > 64 boxes)
         self.eng = E.Engine(self.ysd, self.rsd, device=local, precision=wl["precision"], model_name=wl["model"], num_classes=NC,
                             img_size=wl["size"], max_batch=self.B, max_frame_hw=(self.H, self.W), max_crops=max_crops,
-                            max_tracks=max(8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096,
+                            max_tracks=max(32768 if distinct_cams else 8192, 64 * inject), nn_budget_cap=60, max_candidates=8192 if wl["size"] > 640 else 4096,
                             max_trackers=max(256, n_cam * NC))
         k = 32
         sizes = []

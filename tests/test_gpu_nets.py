@@ -196,6 +196,40 @@ def test_bneck_fused_bit_identical():
     assert r.returncode == 0 and "BNECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_REID_BLOCK_SCRIPT = r"""
+import numpy as np
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.weights import synth_reid
+eng = E.Engine(None, synth_reid(1702), precision="bf16", max_crops=1024)
+rng = np.random.default_rng(7)
+for k in (1, 7, 40, 300, 777):                                      # fewer crops than CUs, and several crops per workgroup
+    x = rng.standard_normal((k, 3, 50, 50)).astype(np.float32)
+    eng.set_option("reid_block_fused", 1)
+    a = eng.embed_tensor(x)
+    eng.set_option("reid_block_fused", 0)
+    b = eng.embed_tensor(x)
+    assert a.shape == (k, 512) and np.isfinite(a).all() and abs(np.linalg.norm(a, axis=1) - 1).max() < 1e-3
+    assert np.array_equal(a, b), (k, float((a == b).mean()), float(np.abs(a - b).max()))
+eng.close()
+print("REID_BLOCK_OK")
+"""
+
+
+def test_reid_block_fused_bit_identical():
+    """reid_block_fused.hip (a 64-channel BasicBlock of the ReID net -- conv3x3 + ReLU + conv3x3 + residual + ReLU on a 25 x 25 map -- in
+    one kernel, the crop in LDS, t never leaving the CU; both blocks of layer1) against the two launches per block it replaces:
+    identical 512-d embeddings bit for bit, for crop counts below and above the number of CUs.  Own process with VC_AUTOTUNE=0 so that
+    the unfused 3x3 runs in its implicit-GEMM form (tap-major k order, the fused kernel's order; the halo-staged variants the autotuner
+    may pick sum slice-major and differ in the last bf16 bit)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC_AUTOTUNE="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("VC_TUNE_CACHE", None)
+    r = subprocess.run([sys.executable, "-c", _REID_BLOCK_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REID_BLOCK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_crop_resize_per_crop_kernel(frames):
     """crop_resize_wg_kernel (one workgroup per crop, tap tables in LDS, exact two-instruction /255) against the per-pixel kernel it
     replaces in the bf16 path: identical embeddings bit for bit (same crops: resized, clamped at the frame border, exactly 50 x 50)."""

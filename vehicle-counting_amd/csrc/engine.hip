@@ -551,6 +551,24 @@ static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t 
                     oi += 3;                                                  // m.cv1, m.cv2 and cv3 are done
                     break;
                 }
+                if (e->opt.reid_block_fused != 0 && nx && nx->kind == Op::CONV && reid_block_fused_applicable(cp, nx->conv)) {   // a 64-channel ReID BasicBlock in one kernel (reid_block_fused.hip)
+                    const ConvP& o2 = nx->conv;
+                    const double flb = fl + 2.0 * o2.M * (double)o2.Cout * nx->C;
+                    const double byb = ((double)cp.B * cp.H * cp.W * cp.Cin + (double)cp.Cout * cp.K + (double)o2.Cout * o2.K) * es + (double)o2.M * o2.Cout * es;   // x in, both weights, y out
+                    cp.cfg = 106;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flb; e->prof_pairs[e->prof_used - 1].bytes = byb; }
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, flb, byb, s);
+                        VC_TRY(launch_reid_block_fused(cp, o2, s));
+                    }
+                    if (e->profiling && e->op_log.size() < (1u << 20)) {
+                        char line[256];
+                        snprintf(line, sizeof(line), "conv M=%d N=%d K=%d k=3x3 s=1 cfg=106 ms=%.4f tflops=%.1f\n", cp.M, 64, 1152, e->last_ms, flb / (e->last_ms * 1e-3) / 1e12);
+                        e->op_log += line;
+                    }
+                    ++oi;                                                     // conv2 is done
+                    break;
+                }
                 const bool bneck_fused_on = e->opt.bneck_fused != 0;
                 if (bneck_fused_on && e->opt.bneck_cv3 != 0 && oi + 2 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV &&
                     bneck_cv3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv)) {   // the last 64-channel Bottleneck of a C3 + the block's cv3 in one kernel
@@ -936,7 +954,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
-        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1);
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -1116,6 +1134,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "front_fused") e->opt.front_fused = value;
     else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
     else if (n == "sparse_head") e->opt.sparse_head = value;
+    else if (n == "reid_block_fused") e->opt.reid_block_fused = value;
     else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }

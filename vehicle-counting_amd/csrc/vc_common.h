@@ -200,6 +200,8 @@ int launch_bneck_cv3_fused(const ConvP& pm1, const ConvP& pm2, const ConvP& p3, 
 bool front_fused_applicable(const ConvP& p0, const ConvP& p1);
 int launch_front_fused(const ConvP& p0, const ConvP& p1, const uint8_t* frames_u8 /* nullable */, const LetterboxGeom& g, hipStream_t s);
 bool front_fused_resize_ok(const LetterboxGeom& g);            // u8 frames that need the letterbox RESIZE: does the tile's source footprint fit the kernel's staging area?
+bool reid_block_fused_applicable(const ConvP& p1, const ConvP& p2);          // reid_block_fused.hip: a 64-channel BasicBlock (two 3x3 + residual) on a 25 x 25 map in one kernel
+int launch_reid_block_fused(const ConvP& p1, const ConvP& p2, hipStream_t s);
 bool reid_stem_applicable(const ConvP& p, int out_cs, int out_co);          // reid_stem.hip: conv1 + ReLU + MaxPool fused (bf16)
 int launch_reid_stem_pool(const ConvP& p, void* pooled, hipStream_t s);
 int conv_k_tile(int prec);    // K elements per tile (weights are padded to a multiple of it)

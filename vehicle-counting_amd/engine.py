@@ -74,7 +74,7 @@ class Engine:
         L.check(L.lib().vc_engine_sync(self._h))
 
     def set_option(self, name, value):
-        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "sparse_head", "crop_per_pixel", "dot_arena_mb"; diagnostics: "ff_ablate", "c3_ablate")."""
+        """Kernel-selection switch of the live engine ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "sparse_head", "reid_block_fused", "crop_per_pixel", "dot_arena_mb"; diagnostics: "ff_ablate", "c3_ablate")."""
         L.check(L.lib().vc_engine_set_option(self._h, name.encode(), int(value)))
 
     def stream_reset(self):
