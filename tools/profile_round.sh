@@ -2,7 +2,7 @@
 # One round of committed profiles (run on the GPU box through gpurun, from the repo root):
 #   kernel trace + stats, FETCH_SIZE / WRITE_SIZE / MFMA-busy PMC passes (each in its own run), bench JSON with cpu baseline.
 # usage: bash tools/profile_round.sh r01
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
