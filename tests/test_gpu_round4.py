@@ -1,0 +1,118 @@
+"""GPU: round-4 additions behind the C ABI --
+  * conv autotune choices exported from one engine and imported into another (vc_tune_export / vc_tune_import): same text back, no
+    re-timing, identical results;
+  * executed-work accounting of the sparse Detect head (vc_profile_read / vc_profile_read_dense): the head's FLOPs follow the gathered
+    row count, the dense figure is the reference's Detect.m[i] over every pixel;
+  * cached op plans: alternating batch sizes / geometries on one engine give what a fresh engine gives;
+  * the literal per-frame loop (CountingPipeline.run, batch 1, host frames) == the batched stream path, rows and counts."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from vehicle_counting_amd import _lib as L  # noqa: E402
+from vehicle_counting_amd.pipeline import CountingPipeline, FrameSource  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+
+NC = 8
+
+
+def test_tune_export_import_roundtrip():
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0)
+    frames = synth_frames(2, 360, 640, n_obj=6, seed=3)
+    imgs = [f[:, :, ::-1] for f in frames]
+    a = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=2, max_frame_hw=(360, 640))
+    da = a.detect(imgs)                                           # times the tile candidates of every layer shape
+    text = a.tune_export()
+    lines = [l.split() for l in text.strip().splitlines()]
+    assert len(lines) > 20 and all(len(l) == 2 and l[1].lstrip("-").isdigit() for l in lines)
+    b = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=2, max_frame_hw=(360, 640))
+    b.tune_import(text)
+    assert b.tune_export() == text                                 # adopted verbatim ...
+    db = b.detect(imgs)
+    assert b.tune_export() == text                                 # ... and nothing was added: no shape was timed again
+    for x, y in zip(da, db):
+        np.testing.assert_array_equal(x, y)                        # same kernel family per layer -> the same bits
+    with pytest.raises(L.VcError):
+        b.tune_import("p0_ci64_co64_k3x3_s1 9999\n")               # a tile configuration this build does not have
+    with pytest.raises(L.VcError):
+        b.tune_import("garbage without a number\n")
+    a.close(); b.close()
+
+
+def test_sparse_head_reports_executed_work():
+    nc = 80
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=1.0)
+    frames = synth_frames(4, 640, 640, n_obj=12, seed=1702)
+    imgs = [f[:, :, ::-1] for f in frames]
+    res = {}
+    for sparse in (1, 0):
+        eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=4, max_frame_hw=(640, 640))
+        eng.set_option("sparse_head", sparse)
+        eng.detect(imgs)                                           # autotune outside the profiled pass
+        eng.profile(True); eng.profile_reset()
+        dets = eng.detect(imgs)
+        conv = eng.profile_read(L.PROF_CONV)
+        dense = eng.profile_read_dense(L.PROF_CONV)
+        ops = eng.profile_ops()
+        eng.profile(False)
+        res[sparse] = (conv, dense, dets, ops)
+        eng.close()
+    (cs, ds, dets_s, ops_s), (cd, dd, dets_d, _) = res[1], res[0]
+    for x, y in zip(dets_s, dets_d):
+        np.testing.assert_array_equal(x, y)                        # the two heads agree (test_sparse_detect_head_equals_dense), so the work is comparable
+    # dense engine: executed == dense credit; sparse engine: its dense credit equals the dense engine's executed work, its executed work is less
+    assert abs(dd[0] - cd["flops"]) <= 1e-6 * cd["flops"] and abs(dd[1] - cd["bytes"]) <= 1e-6 * cd["bytes"]
+    assert abs(ds[0] - cd["flops"]) <= 1e-6 * cd["flops"], (ds[0], cd["flops"])
+    head_dense = sum(2.0 * 4 * (640 // s) ** 2 * 255 * c for s, c in ((8, 128), (16, 256), (32, 512)))
+    assert cd["flops"] - cs["flops"] > 0.5 * head_dense            # most pixels carry no candidate: most of the head is not executed ...
+    assert cs["flops"] > cd["flops"] - head_dense                  # ... the objectness rows and the gathered rows are
+    for line in ops_s.strip().splitlines():                        # no launch above the chip's peak in the per-launch log
+        assert float(line.split("tflops=")[1]) < 2500.0, line
+
+
+def test_cached_plans_follow_shape_changes():
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0)
+    rsd = synth_reid(1702)
+    fa = synth_frames(3, 360, 640, n_obj=6, seed=3)
+    fb = synth_frames(2, 640, 640, n_obj=6, seed=4)
+    eng = E.Engine(sd, rsd, precision="f32", num_classes=NC, max_batch=3, max_frame_hw=(640, 640), max_crops=64)
+    seq = [[f[:, :, ::-1] for f in fa], [fb[0][:, :, ::-1]], [f[:, :, ::-1] for f in fa[:2]], [f[:, :, ::-1] for f in fb], [f[:, :, ::-1] for f in fa]]
+    got = [eng.detect(imgs) for imgs in seq]
+    boxes = np.array([[100.3, 80.7, 60.2, 90.9], [320.0, 200.0, 50.0, 50.0], [300.5, 180.5, 101.0, 33.0]])
+    emb = [eng.embed(fa[0], boxes[:k]) for k in (3, 1, 2, 3, 1)]    # ReID plans per crop count, revisited
+    eng.close()
+    for imgs, g in zip(seq, got):
+        fresh = E.Engine(sd, None, precision="f32", num_classes=NC, max_batch=3, max_frame_hw=(640, 640))
+        ref = fresh.detect(imgs)
+        fresh.close()
+        for x, y in zip(g, ref):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(emb[0], emb[3])
+    np.testing.assert_array_equal(emb[1], emb[4])
+    np.testing.assert_array_equal(emb[0][:2], emb[2])
+
+
+def test_per_frame_loop_equals_stream_path(golden_dir):
+    """bench.py's dropin_bs1 point times CountingPipeline.run; this holds its rows and counts equal to run_stream's on the same clip (bf16
+    engine, one engine, so both paths run the same tile configurations)."""
+    nc = 8
+    sd, rsd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+    frames = synth_frames(24, 360, 640, n_obj=6, seed=3)
+    zone = os.path.join(golden_dir, "cam_04_halfres.json")
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+    track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    eng = E.Engine(sd, rsd, precision="f32", num_classes=nc, max_batch=8, max_frame_hw=(360, 640), max_crops=512, max_tracks=1024, nn_budget_cap=60)
+    pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": track}}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+    rows_loop, counts_loop = pipe.run(FrameSource(frames), "cam_04", zone)
+    rows_stream, counts_stream = pipe.run_stream(FrameSource(frames), "cam_04", zone, batch=8, asynchronous=True)
+    eng.close()
+    key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
+    assert len(rows_loop) > 10 and key(rows_loop) == key(rows_stream)
+    assert counts_loop == counts_stream

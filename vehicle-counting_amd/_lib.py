@@ -140,6 +140,17 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VcError(-1, f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and loads it by path; libvcount_hip.so links /opt/rocm's.
+        # If this library is loaded FIRST, a later `import torch` brings a second runtime into the process and its device enumeration
+        # fails ("No HIP GPUs are available" at the first torch.cuda call -- found by running tests/test_gpu_round4.py alone).  Loaded
+        # after torch, the dynamic linker resolves this library's dependency to the copy that is already there.  So when torch is
+        # installed it is imported here, before the CDLL; a process that never uses torch is not affected either way.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
