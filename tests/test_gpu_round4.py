@@ -116,3 +116,33 @@ def test_per_frame_loop_equals_stream_path(golden_dir):
     key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
     assert len(rows_loop) > 10 and key(rows_loop) == key(rows_stream)
     assert counts_loop == counts_stream
+
+
+def test_front_fused_resize_random_geometries():
+    """The letterbox resize folded into front_fused_kernel (round 4) against the separate letterbox + stem + conv launches over a seeded
+    sweep of frame geometries: odd widths (row byte stride 3 W not a multiple of 4), portrait and landscape, down- and up-scaling, and
+    sizes on either side of the kernel's staging limit (front_fused_resize_ok decides; both outcomes must give the same layer 1).
+    Bit for bit, letterbox padding included."""
+    import torch
+    rng = np.random.default_rng(20260929)
+    geoms = [(int(rng.integers(48, 1100)), int(rng.integers(48, 1400))) for _ in range(int(os.environ.get("VC_SWEEP_N", 20)))] + [(65, 1279), (1279, 65), (641, 639), (96, 96)]
+    nc = 4
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0)
+    fused = 0
+    for H, W in geoms:
+        fr = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)          # noise: every tap of every pixel matters
+        eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=2, max_frame_hw=(H, W))
+        eng.detect([f[:, :, ::-1] for f in fr])
+        a1 = eng.debug_layer(1, batch=2)
+        dev = torch.from_numpy(fr).cuda()
+        eng.stream_submit(dev.data_ptr(), 2, H, W)
+        eng.sync()
+        b1 = eng.debug_layer(1, batch=2)
+        try:
+            eng.debug_layer(0, batch=2)
+        except E.L.VcError:
+            fused += 1
+        assert a1.shape == b1.shape, (H, W)
+        assert np.array_equal(a1, b1), (H, W, float((a1 == b1).mean()))
+        eng.close()
+    assert fused >= len(geoms) // 2, fused

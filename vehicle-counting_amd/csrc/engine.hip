@@ -777,7 +777,7 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     const bool same_scale = g.unpad_h == g.src_h && g.unpad_w == g.src_w && g.src_w % 2 == 0 && g.left % 2 == 0;
     // frames that need the resize (1280 x 720 -> 384 x 640, Q8): only front_fused_kernel evaluates it at patch-build time, so the fold-in
     // needs that kernel to be the one that runs (YOLOv5s widths, bf16 engine, option on) and the tile's source footprint to fit its staging
-    const bool resize_ok = !same_scale && e->prec == PREC_BF16 && e->opt.front_fused > 0 && e->ch[0] == 32 && e->ch[1] == 64 && front_fused_resize_ok(g);
+    const bool resize_ok = !same_scale && ((uintptr_t)d_frames & 3) == 0 && e->prec == PREC_BF16 && e->opt.front_fused > 0 && e->ch[0] == 32 && e->ch[1] == 64 && front_fused_resize_ok(g);
     const bool fuse = fuse_on && e->aux_prec == PREC_BF16 && (same_scale || resize_ok) && e->ch[0] % 16 == 0 && e->ch[0] <= 64;
     e->stem_src = fuse ? d_frames : nullptr;
     e->stem_geom = g;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(FF_NW * 64, FF_NW == 8 ? 1 : 2) void front_fused_ke
     // from there.  Out-of-buffer chunks (before the first / after the last frame) are buffer loads past num_records: zeros.
     constexpr int NRAW = RS ? FF_RS_NRAW : (FF_PR * FF_RAWC + NT - 1) / NT;   // 3 (resize mode: 10)
     uint4 praw[NRAW];
-    const __amdgpu_buffer_rsrc_t s8rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, U8 ? (int)((size_t)B * g.src_h * g.src_w * 3) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s8rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src8), 0, U8 ? (int)(((size_t)B * g.src_h * g.src_w * 3 + 3) & ~(size_t)3) : 0, 0x00020000);   // whole dwords: the range check is per dword, and the last pixels of an odd-sized clip share theirs with up to 3 bytes past the end (same page: the engine requires a 4-byte-aligned base for this kernel)
     auto row_start = [&](int b, int gy0, int gx0, int pr, bool& valid) -> long long {       // byte offset of the source pixel under the patch row's first pixel
         const int uy = 2 * gy0 - 2 + pr - g.top;
         valid = uy >= 0 && uy < g.unpad_h;
