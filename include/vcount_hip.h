@@ -112,6 +112,8 @@ int vc_detect_debug_pred(vc_engine* e, float* out /* B * n_candidates * (5+nc) *
 /* bgr: H x W x 3 uint8 (the `ori_img` the reference crops from).  boxes_cxcywh: k x 4 float64 centre boxes
  * (deep_sort.py:28 bbox_xywh).  out_feat: k x 512 float32, unit L2 norm. */
 int vc_embed(vc_engine* e, const uint8_t* bgr, int h, int w, const double* boxes_cxcywh, int k, float* out_feat);
+/* Diagnostics: the k x 50 x 50 x 3 network input the last vc_embed built (Extractor._preprocess: resize, /255, Normalize), as float32. */
+int vc_embed_debug_input(vc_engine* e, int k, float* out_nhwc, size_t cap_floats, int dims[4] /* k,50,50,3 */);
 int vc_embed_tensor(vc_engine* e, const float* x_nchw /* k x 3 x 50 x 50 */, int k, float* out_feat);
 
 /* ---- tracker: sort/tracker.py + deep_sort.py ------------------------------------------------------ */

@@ -146,3 +146,97 @@ def test_front_fused_resize_random_geometries():
         assert np.array_equal(a1, b1), (H, W, float((a1 == b1).mean()))
         eng.close()
     assert fused >= len(geoms) // 2, fused
+
+
+_FUSION_SWEEP = r"""
+import os
+import numpy as np
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.synth import synth_frames
+from vehicle_counting_amd.weights import synth_yolo
+rng = np.random.default_rng(4)
+N = int(os.environ.get("VC_SWEEP_N", 10))
+geoms = [(int(rng.integers(200, 1000)), int(rng.integers(200, 1300)), int(rng.integers(1, 6))) for _ in range(N)] + [(640, 33, 2), (40, 640, 3)]
+sd = synth_yolo("yolov5s", nc=5, seed=1702, det_scale=6.0, obj_shift=float(os.environ.get("VC_SWEEP_SHIFT", 4.0)))
+ndet = 0
+for H, W, B in geoms:
+    fr = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    eng = E.Engine(sd, None, precision="bf16", num_classes=5, max_batch=B, max_frame_hw=(H, W))
+    a = eng.detect(list(fr))
+    la = [eng.debug_layer(l, batch=B) for l in (2, 4, 17, 23)]
+    for o in ("c3_fused", "bneck_fused", "bneck_cv3", "front_fused", "sparse_head"):
+        eng.set_option(o, 0)
+    b = eng.detect(list(fr))
+    lb = [eng.debug_layer(l, batch=B) for l in (2, 4, 17, 23)]
+    for l, x, y in zip((2, 4, 17, 23), la, lb):
+        assert np.array_equal(x, y), (H, W, B, l, float((x == y).mean()))
+    assert len(a) == len(b) == B
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y), (H, W, B)
+        ndet += len(x)
+    eng.close()
+assert ndet > 0
+print("SWEEP_OK", ndet)
+"""
+
+
+def test_detector_fusions_random_geometries():
+    """Every fused detector kernel (c3_fused, bneck_fused with and without cv3, the sparse Detect head) against the one-launch-per-conv
+    form over a seeded sweep of frame geometries and batch sizes, on noise frames: layers 2, 4, 17, 23 and the detections bit for bit.
+    Own process with VC_AUTOTUNE=0 (the halo-staged 3x3 variants the autotuner may pick sum K slice-major, see
+    test_bneck_fused_bit_identical in test_gpu_nets.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC_AUTOTUNE="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("VC_TUNE_CACHE", None)
+    r = subprocess.run([sys.executable, "-c", _FUSION_SWEEP], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SWEEP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_embed_random_boxes_odd_frame():
+    """Crop + resize + ReID embedding on a frame whose byte size is not a multiple of 4 (271 x 523), for seeded boxes that include the
+    frame's corners (its very last pixel), slivers, boxes hanging over every edge and boxes larger than the frame: the fp32 engine
+    against the oracle's embedder on the reference's crops (atol 3e-5, the bar of test_embed_crops), the network INPUT (resize on float
+    data, /255, Normalize) against the oracle's bit for bit in both precisions, and the bf16 engine's two crop kernels
+    (workgroup-per-crop, thread-per-pixel) bit for bit.  (Found by this sweep: the HIP headers' __fmul_rn / __fadd_rn are plain
+    operators compiled with contraction allowed, and the backend fused the interpolation differently in the two kernels.)"""
+    from oracle import reid as orr
+    from oracle.deepsort import crop_corners
+    rng = np.random.default_rng(11)
+    H, W = 271, 523
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    boxes = [[W - 3.0, H - 3.0, 6.0, 6.0], [2.0, 2.0, 5.0, 5.0], [W - 1.5, 100.0, 3.0, 40.0], [100.0, H - 1.5, 60.0, 3.0],
+             [W / 2, H / 2, 2.0 * W, 2.0 * H], [W / 2, H / 2, W, 2.0], [W - 25.0, H - 25.0, 50.0, 50.0]]
+    for _ in range(41):
+        w, h = rng.uniform(2, 300), rng.uniform(2, 260)
+        boxes.append([rng.uniform(-20, W + 20), rng.uniform(-20, H + 20), w, h])
+    keep = []
+    for b in boxes:
+        x1, y1, x2, y2 = crop_corners(np.asarray(b), W, H)
+        if x2 > x1 and y2 > y1:
+            keep.append(b)
+    boxes = np.asarray(keep)
+    assert len(boxes) >= 40
+    sd = synth_reid(1702)
+    crops = []
+    for b in boxes:
+        x1, y1, x2, y2 = crop_corners(b, W, H)
+        crops.append(img[y1:y2, x1:x2])
+    ref = orr.make_embedder(sd)(crops)
+    import torch
+    x_ref = orr.preprocess_crops(crops).transpose(0, 2, 3, 1)        # the network input: resize on float data, /255, Normalize
+    eng = E.Engine(None, sd, precision="f32", max_crops=64, max_frame_hw=(H, W))
+    np.testing.assert_allclose(eng.embed(img, boxes), ref, rtol=0, atol=3e-5)
+    assert np.array_equal(eng.embed_input(len(boxes)), x_ref)         # bit for bit: every product and sum rounded like the oracle's
+    eng.close()
+    eng = E.Engine(None, sd, precision="bf16", max_crops=64, max_frame_hw=(H, W))
+    a = eng.embed(img, boxes)
+    xa = eng.embed_input(len(boxes))
+    eng.set_option("crop_per_pixel", 1)
+    b = eng.embed(img, boxes)
+    assert np.array_equal(xa, torch.from_numpy(x_ref).to(torch.bfloat16).float().numpy())    # one RNE rounding of the fp32 value
+    assert np.array_equal(xa, eng.embed_input(len(boxes)))
+    assert np.array_equal(a, b)
+    assert (a * ref).sum(1).min() >= 0.999
+    eng.close()

@@ -68,6 +68,7 @@ SIGNATURES = {
     "vc_detect": [_vp, _P(_vp), _pi, _pi, _i, _pf, _pi],
     "vc_detect_debug_shape": [_vp, _pi, _pi, _pi],
     "vc_detect_debug_layer": [_vp, _i, _pf, C.c_size_t, _pi],
+    "vc_embed_debug_input": [_vp, _i, _pf, C.c_size_t, _pi],
     "vc_detect_debug_pred": [_vp, _pf, C.c_size_t],
     "vc_embed": [_vp, _pu8, _i, _i, _pd, _i, _pf],
     "vc_embed_tensor": [_vp, _pf, _i, _pf],

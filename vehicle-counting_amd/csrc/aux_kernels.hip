@@ -486,6 +486,8 @@ int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s)
 
 // ------------------------------------------------------------------------------------------ ReID crop + resize (B3/B4)
 // cv2.resize(im.astype(float32)/255., (50,50)) on float data: horizontal pass then vertical pass in f32,
+// every product and sum rounded separately (this file compiles with fp contract(off); the __fmul_rn / __fadd_rn wrappers of the HIP
+// headers are plain operators compiled with contraction ALLOWED, and the backend fused them differently in the two kernels below),
 // then torchvision Normalize; restated in oracle/imageops.py::resize_linear_f32 + oracle/reid.py::preprocess_crops.
 __device__ __forceinline__ void lin_coef_f(int d, int src, double scale, int& s0, int& s1, float& c0, float& c1, bool horizontal) {
     float f = (float)(((double)d + 0.5) * scale - 0.5);
@@ -529,9 +531,9 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t* __restr
                 for (int c = 0; c < 3; ++c) {
                     const float p00 = (float)r0[sx0 * 3 + c] / 255.f, p01 = (float)r0[sx1 * 3 + c] / 255.f;
                     const float p10 = (float)r1[sx0 * 3 + c] / 255.f, p11 = (float)r1[sx1 * 3 + c] / 255.f;
-                    const float h0 = __fadd_rn(__fmul_rn(p00, a0), __fmul_rn(p01, a1));
-                    const float h1 = __fadd_rn(__fmul_rn(p10, a0), __fmul_rn(p11, a1));
-                    v[c] = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+                    const float h0 = p00 * a0 + p01 * a1;
+                    const float h1 = p10 * a0 + p11 * a1;
+                    v[c] = h0 * b0 + h1 * b1;
                 }
             }
 #pragma unroll
@@ -591,9 +593,9 @@ __global__ __launch_bounds__(256) void crop_resize_wg_kernel(const uint8_t* __re
             for (int c = 0; c < 3; ++c) {
                 const float p00 = div255_exact((float)r0[sx0 * 3 + c]), p01 = div255_exact((float)r0[sx1 * 3 + c]);
                 const float p10 = div255_exact((float)r1[sx0 * 3 + c]), p11 = div255_exact((float)r1[sx1 * 3 + c]);
-                const float h0 = __fadd_rn(__fmul_rn(p00, a0), __fmul_rn(p01, a1));
-                const float h1 = __fadd_rn(__fmul_rn(p10, a0), __fmul_rn(p11, a1));
-                v[c] = __fadd_rn(__fmul_rn(h0, b0), __fmul_rn(h1, b1));
+                const float h0 = p00 * a0 + p01 * a1;
+                const float h1 = p10 * a0 + p11 * a1;
+                v[c] = h0 * b0 + h1 * b1;
             }
         }
         const uint32_t o0 = f32_to_bf16((v[0] - mean[0]) / stdv[0]), o1 = f32_to_bf16((v[1] - mean[1]) / stdv[1]), o2 = f32_to_bf16((v[2] - mean[2]) / stdv[2]);

@@ -1281,6 +1281,13 @@ int vc_detect_debug_pred(vc_engine* e, float* out, size_t cap) {
     return VC_OK;
 }
 
+int vc_embed_debug_input(vc_engine* e, int k, float* out, size_t cap, int dims[4]) {
+    VC_CHECK(e && out && dims, VC_ERR_ARG, "null argument");
+    VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
+    VC_CHECK(k > 0 && k <= e->cfg.max_crops, VC_ERR_ARG, "k must be 1..max_crops");
+    return read_view_f32(e, mkview(e->rbuf["in"], k, VC_REID_SIZE, VC_REID_SIZE, 3, 0), out, cap, dims);
+}
+
 // ---- embed ---------------------------------------------------------------------------------------------
 // deep_sort.py:89-95 _xywh_to_xyxy: int() truncation toward zero, clamp to [0, W-1] / [0, H-1]
 static void crop_corners(const double* b, int W, int H, int out[4]) {

@@ -124,6 +124,13 @@ class Engine:
                                  len(boxes), L.ptr(out, C.c_float)))
         return out
 
+    def embed_input(self, k):
+        """The k x 50 x 50 x 3 network input the last embed() built (diagnostics)."""
+        buf = np.empty((k, 50, 50, 3), np.float32)
+        dims = (C.c_int * 4)()
+        L.check(L.lib().vc_embed_debug_input(self._h, k, L.ptr(buf, C.c_float), buf.size, dims))
+        return buf
+
     def embed_tensor(self, x_nchw):
         x = L.f32(x_nchw)
         out = np.zeros((len(x), L.FEAT_DIM), np.float32)
