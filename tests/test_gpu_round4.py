@@ -240,3 +240,60 @@ def test_embed_random_boxes_odd_frame():
     assert np.array_equal(a, b)
     assert (a * ref).sum(1).min() >= 0.999
     eng.close()
+
+
+def test_letterbox_random_geometries():
+    """letterbox_kernel (AutoShape's letterbox: cv::resize INTER_LINEAR on 8-bit data in 11-bit fixed point, pad 114) against the oracle
+    over a seeded sweep of frame and tensor geometries on noise, bit for bit: up- and down-scaling, extreme aspect ratios, 1-pixel-wide
+    resized images, odd paddings."""
+    from oracle import imageops as oi
+    rng = np.random.default_rng(99)
+    n = int(os.environ.get("VC_SWEEP_N", 16))
+    geoms = [(int(rng.integers(8, 900)), int(rng.integers(8, 1200)), 32 * int(rng.integers(1, 21)), 32 * int(rng.integers(1, 21))) for _ in range(n)]
+    geoms += [(8, 1200, 32, 640), (1200, 8, 640, 32), (641, 639, 640, 640), (31, 33, 640, 640)]
+    for h, w, nh, nw in geoms:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = E.letterbox(img, nh, nw, "f32")
+        ref = oi.letterbox(img, nh, nw).astype(np.float32) / np.float32(255)
+        assert np.array_equal(got, ref), (h, w, nh, nw, float((got == ref).mean()))
+
+
+_LOOP_STREAM_ODD = r"""
+import os, types
+import numpy as np
+import vehicle_counting_amd.engine as E
+from vehicle_counting_amd.pipeline import CountingPipeline, FrameSource
+from vehicle_counting_amd.synth import synth_frames
+from vehicle_counting_amd.weights import synth_reid, synth_yolo
+nc = 8
+sd, rsd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+H, W = 273, 521                                                   # resize 640/521, byte size of a clip not a multiple of 4
+frames = synth_frames(21, H, W, n_obj=5, seed=3)
+zone = os.environ["VC_ZONE"]
+cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+eng = E.Engine(sd, rsd, precision="bf16", num_classes=nc, max_batch=8, max_frame_hw=(H, W), max_crops=512, max_tracks=1024, nn_budget_cap=60)
+pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": track}}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+rows_loop, counts_loop = pipe.run(FrameSource(frames), "cam_04", zone)
+rows_stream, counts_stream = pipe.run_stream(FrameSource(frames), "cam_04", zone, batch=8, asynchronous=True)   # 8 + 8 + 5 frames
+eng.close()
+key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
+assert len(rows_loop) > 10, len(rows_loop)
+assert key(rows_loop) == key(rows_stream)
+assert counts_loop == counts_stream
+print("LOOP_STREAM_OK", len(rows_loop))
+"""
+
+
+def test_per_frame_loop_equals_stream_path_bf16_odd_geometry(golden_dir):
+    """The same comparison on the bf16 engine at a frame geometry that takes front_fused_kernel's resize mode, with a ragged last batch
+    (21 frames in batches of 8).  Own process with VC_AUTOTUNE=0: batch 1 and batch 8 then run the same kernel family per layer (the
+    autotuner chooses per shape, and its halo-staged 3x3 variants differ from the implicit-GEMM form in the last bf16 bit)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC_AUTOTUNE="0", VC_ZONE=os.path.join(golden_dir, "cam_04_halfres.json"), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("VC_TUNE_CACHE", None)
+    r = subprocess.run([sys.executable, "-c", _LOOP_STREAM_ODD], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "LOOP_STREAM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
