@@ -155,3 +155,17 @@ def test_hot_kernel_cost_rows_match_the_oracle(eng, name):
             n_iou += iou_ref.size
     assert n_app > 20 and n_iou > 20 and n_gated > 20, (n_app, n_iou, n_gated)
     eng.tracker_reset(tid)
+
+
+def test_random_scenes_random_parameters_match_the_oracle(eng):
+    """Seeded random scenes (2-70 objects with look-alike appearance twins, births and deaths, missed detections, clutter, an empty
+    frame, shuffled detection order) under random tracker parameters (max_dist, max_iou_distance, max_age 1-40, n_init 1-4, budget
+    1-60): ids, FSM counters, states, gallery sizes identical to the oracle's TrackerState after every frame, means to 1e-9
+    (tools/experiments/tracker_soak.py; 100 scenes were run once, 14 stay in the suite)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tracker_soak", os.path.join(root, "tools", "experiments", "tracker_soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    bad = [s for s in range(200, 214) if not soak.run(eng, s)]
+    assert not bad, bad
