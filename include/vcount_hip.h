@@ -129,6 +129,9 @@ typedef struct vc_tracker_params {
 
 int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* tracker_id);
 int vc_tracker_reset(vc_engine* e, int tracker_id);
+/* Gives the tracker's tracks and its id back (the next vc_tracker_create may return the same id).  The reference drops its VideoTracker
+ * after every video (modules/__init__.py:32-36); the drop-in's DeepSort calls this when it is closed or collected. */
+int vc_tracker_destroy(vc_engine* e, int tracker_id);
 /* Tracker.predict() + Tracker.update(detections) for detections already filtered/NMS'ed by the caller.
  * tlwh: k x 4 f64, conf: k f64, feat: k x 512 f32 (host). */
 int vc_tracker_step(vc_engine* e, int tracker_id, const double* tlwh, const double* conf, const float* feat, int k);

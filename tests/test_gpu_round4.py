@@ -317,3 +317,74 @@ def test_autotuned_tile_configurations_random_geometries(tmp_path):
     assert r.returncode == 0 and "BAD" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     worst = float(r.stdout.strip().splitlines()[-1].split()[-1])
     assert worst <= 2e-2, worst
+
+
+def test_stream_path_is_deterministic_run_to_run(tmp_path):
+    """The asynchronous three-stream path on the benchmarked configuration (YOLOv5s 640 x 640, 80 classes, bf16, autotuned tiles, B = 32
+    so that the sparse head's atomic gather, the NMS and the tracker walk all see many rows) run five times on one engine and once
+    more on a fresh engine: every CSV row and every count identical.  Workgroup scheduling, the order in which the head's atomics
+    append pixels and the overlap of batch i's tracker with batch i + 1's detector must not reach the result."""
+    nc = 80
+    sd, rsd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=1.0), synth_reid(1702)
+    frames = synth_frames(96, 640, 640, n_obj=12, seed=1702)
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cam_04_halfres.json")) as f:
+        z = json.load(f)
+    for sh in z["shapes"]:                                            # the whole frame is the zone: every tracked row reaches the CSV
+        if sh["label"] == "zone":
+            sh["points"] = [[0.0, 0.0], [640.0, 0.0], [640.0, 640.0], [0.0, 640.0]]
+    zone = str(tmp_path / "cam_04.json")
+    with open(zone, "w") as f:
+        json.dump(z, f)
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+    track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"]), r["fframe"], r["lframe"]) for r in rows]
+    runs = []
+    for fresh in (False, True):
+        eng = E.Engine(sd, rsd, precision="bf16", num_classes=nc, max_batch=32, max_frame_hw=(640, 640), max_crops=32 * 64, max_tracks=4096, nn_budget_cap=60)
+        pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": track}}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+        for _ in range(1 if fresh else 5):
+            rows, counts = pipe.run_stream(FrameSource(frames), "cam_04", zone, batch=32, asynchronous=True)
+            runs.append((key(rows), counts))
+        eng.close()
+    assert len(runs[0][0]) > 100
+    for k, c in runs[1:]:
+        assert k == runs[0][0] and c == runs[0][1]
+
+
+def test_tracker_ids_are_given_back():
+    """vc_tracker_destroy: the reference builds a new VideoTracker per video and drops the old one (modules/__init__.py:32-36); the
+    drop-in's DeepSort gives its engine-side tracker back when it is closed or collected, so a process that walks a folder of videos
+    with 80 classes does not hit max_trackers (256) on the fourth video (found by the determinism test above)."""
+    from vehicle_counting_amd.track import VideoTracker
+    eng = E.Engine(None, synth_reid(1702), precision="f32", max_crops=16, max_frame_hw=(360, 640), max_tracks=64, nn_budget_cap=10, max_trackers=4)
+    ids = [eng.tracker_create(nn_budget=5) for _ in range(4)]
+    with pytest.raises(L.VcError, match="max_trackers"):
+        eng.tracker_create(nn_budget=5)
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((3, 512)).astype(np.float32)
+    tlwh = np.array([[10, 10, 40, 60], [200, 100, 50, 50], [400, 200, 30, 80]], np.float64)
+    for _ in range(3):
+        eng.tracker_step(ids[1], tlwh, np.full(3, 0.9), f)
+    assert len(eng.tracker_state(ids[1])["ids"]) == 3
+    eng.tracker_destroy(ids[1])
+    with pytest.raises(L.VcError, match="bad tracker id"):
+        eng.tracker_step(ids[1], tlwh, np.full(3, 0.9), f)
+    with pytest.raises(L.VcError, match="bad tracker id"):
+        eng.tracker_destroy(ids[1])
+    again = eng.tracker_create(nn_budget=7, max_age=5)
+    assert again == ids[1]
+    assert len(eng.tracker_state(again)["ids"]) == 0            # a fresh tracker: no tracks, ids from 1
+    eng.tracker_step(again, tlwh, np.full(3, 0.9), f)
+    assert eng.tracker_state(again)["ids"].tolist() == [1, 2, 3]
+    for t in ids:
+        eng.tracker_destroy(t)
+    cam = {"tracking_config": dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=10)}
+    for _ in range(5):                                            # five "videos" of four classes on four tracker ids
+        vt = VideoTracker(4, cam, None, engine=eng)
+        assert sorted(vt.tracker_ids) == [0, 1, 2, 3]
+        del vt
+    vt = VideoTracker(4, cam, None, engine=eng)
+    vt.close(); vt.close()                                        # idempotent
+    eng.close()

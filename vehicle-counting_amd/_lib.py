@@ -74,6 +74,7 @@ SIGNATURES = {
     "vc_embed_tensor": [_vp, _pf, _i, _pf],
     "vc_tracker_create": [_vp, _P(TrackerParams), _pi],
     "vc_tracker_reset": [_vp, _i],
+    "vc_tracker_destroy": [_vp, _i],
     "vc_tracker_step": [_vp, _i, _pd, _pd, _pf, _i],
     "vc_tracker_count": [_vp, _i, _pi],
     "vc_tracker_state": [_vp, _i, _i, _pl, _pi, _pi, _pi, _pi, _pd, _pd, _pi],

@@ -75,7 +75,9 @@ struct Tracker {
     vc_tracker_params p;
     int known_tracks = 0;            // live tracks reported by the last completed batch
     int pending_dets = 0;            // detections of batches still in flight (each may start a track)
+    bool released = false;           // vc_tracker_destroy: the id is free for the next vc_tracker_create
 };
+inline bool tracker_ok(const std::vector<std::unique_ptr<Tracker>>& v, int id) { return id >= 0 && id < (int)v.size() && !v[id]->released; }
 
 // one (frame, class) step of a batch as the host sees it
 struct TrackTaskHost { int tracker, label, frame, det_off, det_n; };

@@ -256,7 +256,7 @@ static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const in
         for (int c = 0; c < num_classes; ++c) {
             std::vector<int>& g = by_class[c];
             if (g.empty()) continue;
-            VC_CHECK(trackers[c] >= 0 && trackers[c] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            VC_CHECK(tracker_ok(e->trackers, trackers[c]), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
             std::vector<double> bx(g.size() * 4), cf(g.size());
             std::vector<int> rows(g.size());
             for (size_t i = 0; i < g.size(); ++i) {
@@ -412,7 +412,7 @@ int vc_videotracker_run_features(vc_engine* e, const int* trackers, int num_clas
         for (int c = 0; c < num_classes; ++c) {                                        // modules/track.py:50-59
             std::vector<int>& g = by_class[c];
             if (g.empty()) continue;
-            VC_CHECK(trackers[c] >= 0 && trackers[c] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            VC_CHECK(tracker_ok(e->trackers, trackers[c]), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
             std::vector<double> bx(g.size() * 4), cf(g.size());
             for (size_t k = 0; k < g.size(); ++k) {
                 memcpy(&bx[k * 4], rows7 + (size_t)g[k] * 7 + 1, 4 * sizeof(double));

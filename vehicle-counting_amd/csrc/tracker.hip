@@ -164,7 +164,7 @@ int track_enqueue(vc_engine* e, int st, const std::vector<std::vector<FrameClass
     std::vector<const FrameClassDets*> src;
     for (size_t f = 0; f < frames.size(); ++f)
         for (const FrameClassDets& g : frames[f]) {
-            VC_CHECK(g.tracker >= 0 && g.tracker < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", g.tracker);
+            VC_CHECK(tracker_ok(e->trackers, g.tracker), VC_ERR_NOTFOUND, "bad tracker id %d", g.tracker);
             s.tasks.push_back(TrackTaskHost{g.tracker, g.label, (int)f, 0, (int)g.dets.conf.size()});
             src.push_back(&g);
         }
@@ -445,7 +445,7 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
             cf[i] = conf[g[i]];
             rows[i] = g[i];
         }
-        VC_CHECK(tracker_ids[j] >= 0 && tracker_ids[j] < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
+        VC_CHECK(tracker_ok(e->trackers, tracker_ids[j]), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
         FrameClassDets fc{labels[j], tracker_ids[j], {}};
         prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, fc.dets);
         total_tracks += e->trackers[tracker_ids[j]]->known_tracks + (int)fc.dets.conf.size();
@@ -514,20 +514,32 @@ int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
     VC_CHECK(p->nn_budget >= 1 && p->nn_budget <= e->cfg.nn_budget_cap, VC_ERR_CAPACITY,
              "nn_budget %d outside [1, nn_budget_cap=%d] (an unbounded budget is not supported)", p->nn_budget, e->cfg.nn_budget_cap);
     VC_CHECK(p->max_age >= 1 && p->n_init >= 1, VC_ERR_ARG, "max_age and n_init must be >= 1");
-    VC_CHECK((int)e->trackers.size() < e->max_trackers, VC_ERR_CAPACITY, "more than max_trackers (%d) trackers", e->max_trackers);
+    int slot = -1;                       // an id given back by vc_tracker_destroy is used again before the table grows
+    for (int i = 0; i < (int)e->trackers.size() && slot < 0; ++i) if (e->trackers[i]->released) slot = i;
+    VC_CHECK(slot >= 0 || (int)e->trackers.size() < e->max_trackers, VC_ERR_CAPACITY,
+             "more than max_trackers (%d) trackers (vc_tracker_destroy gives an id back)", e->max_trackers);
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));           // batches in flight index e->trackers
-    std::unique_ptr<Tracker> t(new Tracker());
-    t->p = *p;
     const TrackerHdr h = make_hdr(*p);
-    VC_HIP(hipMemcpy(e->d_hdrs + e->trackers.size(), &h, sizeof(h), hipMemcpyHostToDevice));
-    e->trackers.push_back(std::move(t));
-    *id = (int)e->trackers.size() - 1;
+    if (slot < 0) { slot = (int)e->trackers.size(); e->trackers.push_back(std::unique_ptr<Tracker>(new Tracker())); }
+    VC_HIP(hipMemcpy(e->d_hdrs + slot, &h, sizeof(h), hipMemcpyHostToDevice));
+    Tracker& t = *e->trackers[slot];
+    t.p = *p; t.known_tracks = 0; t.pending_dets = 0; t.released = false;
+    *id = slot;
+    return VC_OK;
+}
+
+// The reference builds a new VideoTracker (one DeepSort per class) for every video (modules/__init__.py:32-36) and drops the old one:
+// the drop-in's DeepSort gives its tracker back here, so that a process that walks a folder of videos does not run out of ids.
+int vc_tracker_destroy(vc_engine* e, int id) {
+    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_TRY(vc_tracker_reset(e, id));     // waits for the batches in flight, returns the track slots to the pool
+    e->trackers[id]->released = true;
     return VC_OK;
 }
 
 int vc_tracker_reset(vc_engine* e, int id) {
-    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -541,7 +553,7 @@ int vc_tracker_reset(vc_engine* e, int id) {
 }
 
 int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf, const float* feat, int k) {
-    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_CHECK(k == 0 || (tlwh && conf && feat), VC_ERR_ARG, "null argument");
     VC_CHECK(k >= 0 && k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
     VC_HIP(hipSetDevice(e->cfg.device));
@@ -562,7 +574,7 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
 }
 
 int vc_tracker_count(vc_engine* e, int id, int* n) {
-    VC_CHECK(e && n && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && n && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -573,7 +585,7 @@ int vc_tracker_count(vc_engine* e, int id, int* n) {
 
 int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
                      double* cov64, int* gallery_count) {
-    VC_CHECK(e && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -628,7 +640,7 @@ const char kSnapMagic[8] = {'V', 'C', 'T', 'R', 'K', '0', '1', 0};
 }  // namespace
 
 int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* size) {
-    VC_CHECK(e && size && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && size && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -663,7 +675,7 @@ int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* siz
 }
 
 int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
-    VC_CHECK(e && buf && id >= 0 && id < (int)e->trackers.size(), VC_ERR_NOTFOUND, "bad tracker id");
+    VC_CHECK(e && buf && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
     VC_CHECK(size >= sizeof(SnapHeader), VC_ERR_ARG, "snapshot truncated");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
@@ -720,7 +732,7 @@ int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
 
 int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy, const double* conf, int k,
                        int64_t* out_rows7, int cap_rows, int* out_m) {
-    VC_CHECK(e && bgr && out_m && id >= 0 && id < (int)e->trackers.size(), VC_ERR_ARG, "bad argument");
+    VC_CHECK(e && bgr && out_m && tracker_ok(e->trackers, id), VC_ERR_ARG, "bad argument");
     VC_CHECK(k >= 1 && bbox_xyxy && conf, VC_ERR_ARG, "DeepSort.update needs at least one box (the reference only calls it then)");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));

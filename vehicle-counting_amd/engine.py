@@ -152,6 +152,10 @@ class Engine:
         L.check(L.lib().vc_tracker_create(self._h, C.byref(p), C.byref(tid)))
         return tid.value
 
+    def tracker_destroy(self, tid):
+        if self._h:
+            L.check(L.lib().vc_tracker_destroy(self._h, tid))
+
     def tracker_reset(self, tid):
         L.check(L.lib().vc_tracker_reset(self._h, tid))
 

@@ -80,6 +80,7 @@ class CountingPipeline:
                     obj["tracks"].append(res["tracks"][j])
                     obj["labels"].append(res["labels"][j])
                     obj["boxes"].append(res["boxes"][j])
+        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
         return self._finish(counter, obj, cam_name)
 
     def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False, host_frames=False):
@@ -128,6 +129,7 @@ class CountingPipeline:
             ptr.pop(n - 1, None)
         if asynchronous and starts:
             record(starts[-1], *self.engine.stream_collect()[:2])
+        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
         return self._finish(counter, obj, cam_name)
 
     def run_streams(self, sources, cam_names, zone_paths, batch=16):
@@ -178,6 +180,8 @@ class CountingPipeline:
                 record(starts[n - 1], *self.engine.stream_collect()[:2])
         if starts:
             record(starts[-1], *self.engine.stream_collect()[:2])
+        for st in stages:
+            st[0].close()
         return [self._finish(st[1], o, n) for st, o, n in zip(stages, objs, cam_names)]
 
     def run_frame_sharded(self, source, cam_name, zone_path, chunk=8, device=None):
@@ -222,4 +226,5 @@ class CountingPipeline:
                 obj["boxes"].extend(list(rows[:, :4].copy()))
         if rank != 0:
             return None, None
+        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
         return self._finish(counter, obj, cam_name)

@@ -19,6 +19,19 @@ class DeepSort:
         self.tracker_id = engine.tracker_create(max_dist=max_dist, min_confidence=min_confidence, nms_max_overlap=nms_max_overlap,
                                                 max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, nn_budget=nn_budget)
 
+    def close(self):
+        """Gives the tracker (its tracks, galleries and its id) back to the engine.  The reference simply drops its DeepSort objects when
+        CountingPipeline builds the next video's VideoTracker (modules/__init__.py:32-36); here that is `__del__`, or an explicit close()."""
+        tid, self.tracker_id = self.tracker_id, None
+        if tid is not None and getattr(self.engine, "_h", None):
+            self.engine.tracker_destroy(tid)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown, engine already destroyed
+            pass
+
     def update(self, bbox_xyxy, confidences, ori_img):
         rows = self.engine.deepsort_update(self.tracker_id, bbox_xyxy, confidences, ori_img)
         return rows if len(rows) > 0 else []          # deep_sort.py:57-59
@@ -65,6 +78,10 @@ class VideoTracker:
                                   max_age=cfg["MAX_AGE"], n_init=cfg["N_INIT"], nn_budget=cfg["NN_BUDGET"], use_cuda=1,
                                   engine=engine) for _ in range(num_classes)]
         self.tracker_ids = [d.tracker_id for d in self.deepsort]
+
+    def close(self):
+        for d in self.deepsort:
+            d.close()
 
     def run(self, image, boxes, labels, scores):
         rows = self.engine.videotracker_run(self.tracker_ids, image, boxes, labels, scores)
