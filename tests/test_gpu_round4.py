@@ -388,3 +388,64 @@ def test_tracker_ids_are_given_back():
     vt = VideoTracker(4, cam, None, engine=eng)
     vt.close(); vt.close()                                        # idempotent
     eng.close()
+
+
+def test_folder_of_videos_on_one_pipeline(golden_dir):
+    """The reference's driver walks a folder: one CountingPipeline, `run` per video, a new VideoTracker each time
+    (modules/__init__.py:28-36).  Three videos of different geometry, length and batch raggedness through ONE drop-in pipeline / engine,
+    the first one again at the end: its rows and counts are what they were the first time (no state of an earlier video -- tracks,
+    galleries, ids, cached plans of another geometry, frames in flight -- reaches a later one), and track ids start from 1 per video."""
+    nc = 8
+    sd, rsd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0), synth_reid(1702)
+    zone = os.path.join(golden_dir, "cam_04_halfres.json")
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+    track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    eng = E.Engine(sd, rsd, precision="bf16", num_classes=nc, max_batch=8, max_frame_hw=(480, 640), max_crops=8 * 300, max_tracks=4096, nn_budget_cap=60,
+                   max_trackers=2 * nc)
+    pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": track}}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+    videos = [synth_frames(20, 360, 640, n_obj=6, seed=3), synth_frames(13, 273, 521, n_obj=5, seed=4), synth_frames(9, 480, 352, n_obj=4, seed=5)]
+    key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
+    out = []
+    for v in videos + [videos[0]]:
+        rows, counts = pipe.run_stream(FrameSource(v), "cam_04", zone, batch=8, asynchronous=True)
+        out.append((key(rows), counts))
+    assert len(out[0][0]) > 10 and len(out[1][0]) > 0
+    assert out[3] == out[0]
+    assert min(k[1] for k in out[1][0]) <= 3                      # ids restart per video (a leftover tracker would continue from ~20)
+    rows_loop, counts_loop = pipe.run(FrameSource(videos[1]), "cam_04", zone)      # and the per-frame loop afterwards, same engine
+    assert len(rows_loop) > 0
+    eng.close()
+
+
+def test_a_failed_video_does_not_poison_the_next_one(golden_dir):
+    """A video that exceeds a configured capacity (here: more boxes in a batch than max_crops) raises out of run_stream with batches
+    still in flight.  The pipeline abandons them (vc_stream_reset) and gives the video's trackers back, so the next video on the same
+    pipeline gives exactly what it gives on an engine that never saw the failure."""
+    nc = 8
+    quiet, busy = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=0.0), None
+    rsd = synth_reid(1702)
+    zone = os.path.join(golden_dir, "cam_04_halfres.json")
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+    track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    good = synth_frames(20, 360, 640, n_obj=6, seed=3)
+    crowded = synth_frames(24, 273, 521, n_obj=5, seed=4)          # three batches: the failure leaves submissions in flight
+    key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
+    res = []
+    for fail_first in (True, False):
+        eng = E.Engine(quiet, rsd, precision="f32", num_classes=nc, max_batch=8, max_frame_hw=(360, 640), max_crops=512, max_tracks=1024, nn_budget_cap=60,
+                       max_trackers=nc)
+        pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": track}}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+        if fail_first:
+            rng = np.random.default_rng(1)                      # 8 x 70 injected boxes per batch > max_crops = 512
+            xy = rng.uniform(10, 200, (8, 70, 2)); wh = rng.uniform(20, 60, (8, 70, 2))
+            det6 = np.concatenate([xy, xy + wh, np.full((8, 70, 1), 0.9), rng.integers(0, nc, (8, 70, 1))], 2).astype(np.float32)
+            eng.stream_inject(det6, np.full(8, 70, np.int32))
+            with pytest.raises(L.VcError, match="max_crops"):
+                pipe.run_stream(FrameSource(crowded), "cam_04", zone, batch=8, asynchronous=True)
+            eng.stream_inject()
+        rows, counts = pipe.run_stream(FrameSource(good), "cam_04", zone, batch=8, asynchronous=True)   # max_trackers = nc: the failed video's ids are free again
+        res.append((key(rows), counts))
+        eng.close()
+    assert len(res[0][0]) > 10 and res[0] == res[1]

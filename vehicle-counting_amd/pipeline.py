@@ -12,6 +12,7 @@ Drivers with identical results:
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import numpy as np
@@ -55,6 +56,24 @@ class CountingPipeline:
         counter = VideoCounting(class_names=self.class_names, zone_path=zone_path)
         return tracker, counter
 
+    @contextlib.contextmanager
+    def _video(self, *trackers):
+        """One video's stage objects: whatever happens inside, the engine-side trackers are given back (the reference drops the video's
+        VideoTracker, modules/__init__.py:32-36), and after an exception the submissions still in flight are abandoned so that the
+        next video starts on an idle engine."""
+        try:
+            yield
+        except BaseException:
+            try:
+                self.engine.stream_reset()
+            except Exception:
+                pass
+            raise
+        finally:
+            for t in trackers:
+                if t is not None:
+                    t.close()
+
     def _finish(self, counter, obj, cam_name):
         out = os.path.join(self.saved_path, cam_name + ".csv") if self.saved_path else None
         td = counter.run(frames=obj["frames"], tracks=obj["tracks"], labels=obj["labels"], boxes=obj["boxes"], output_path=out)
@@ -66,21 +85,21 @@ class CountingPipeline:
         """modules/__init__.py:28-100 for one video."""
         tracker, counter = self._stages(cam_name, source.video_info, zone_path)
         obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
-        for batch in source:
-            if batch is None:
-                continue
-            preds = self.detector.run(batch)
-            for i in range(len(batch["ori_imgs"])):
-                boxes, labels, scores = preds["boxes"][i], preds["labels"][i], preds["scores"][i]
-                if len(boxes) == 0:                         # :68-69 (Q1)
+        with self._video(tracker):
+            for batch in source:
+                if batch is None:
                     continue
-                res = tracker.run(batch["ori_imgs"][i], boxes, labels, scores)
-                for j in range(len(res["boxes"])):
-                    obj["frames"].append(batch["frames"][i])
-                    obj["tracks"].append(res["tracks"][j])
-                    obj["labels"].append(res["labels"][j])
-                    obj["boxes"].append(res["boxes"][j])
-        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
+                preds = self.detector.run(batch)
+                for i in range(len(batch["ori_imgs"])):
+                    boxes, labels, scores = preds["boxes"][i], preds["labels"][i], preds["scores"][i]
+                    if len(boxes) == 0:                         # :68-69 (Q1)
+                        continue
+                    res = tracker.run(batch["ori_imgs"][i], boxes, labels, scores)
+                    for j in range(len(res["boxes"])):
+                        obj["frames"].append(batch["frames"][i])
+                        obj["tracks"].append(res["tracks"][j])
+                        obj["labels"].append(res["labels"][j])
+                        obj["boxes"].append(res["boxes"][j])
         return self._finish(counter, obj, cam_name)
 
     def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False, host_frames=False):
@@ -110,26 +129,26 @@ class CountingPipeline:
             obj["labels"].extend(rows[:, 5].tolist())
             obj["boxes"].extend(list(rows[:, :4].copy()))
 
-        for n in range(min(2, len(starts))):            # staging order = batch order (the engine hands its four host slots out round-robin)
-            stage(n)
-        if starts:
-            self.engine.stream_submit(ptr[0], size(0), h, w)
-        for n, f0 in enumerate(starts):
-            b = size(n)
-            if n + 2 < len(starts):                     # copy batch n+2 (host frames) under the detector of batch n+1
-                stage(n + 2)
-            if n + 1 < len(starts):                     # detect the next batch while this one is tracked
-                self.engine.stream_submit(ptr[n + 1], size(n + 1), h, w)
-            if asynchronous:
-                self.engine.stream_run_async(tracker.tracker_ids, ptr[n], b, h, w)
-                if n > 0:
-                    record(starts[n - 1], *self.engine.stream_collect()[:2])
-            else:
-                record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, ptr[n], b, h, w)[:2])
-            ptr.pop(n - 1, None)
-        if asynchronous and starts:
-            record(starts[-1], *self.engine.stream_collect()[:2])
-        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
+        with self._video(tracker):
+            for n in range(min(2, len(starts))):            # staging order = batch order (the engine hands its four host slots out round-robin)
+                stage(n)
+            if starts:
+                self.engine.stream_submit(ptr[0], size(0), h, w)
+            for n, f0 in enumerate(starts):
+                b = size(n)
+                if n + 2 < len(starts):                     # copy batch n+2 (host frames) under the detector of batch n+1
+                    stage(n + 2)
+                if n + 1 < len(starts):                     # detect the next batch while this one is tracked
+                    self.engine.stream_submit(ptr[n + 1], size(n + 1), h, w)
+                if asynchronous:
+                    self.engine.stream_run_async(tracker.tracker_ids, ptr[n], b, h, w)
+                    if n > 0:
+                        record(starts[n - 1], *self.engine.stream_collect()[:2])
+                else:
+                    record(f0, *self.engine.stream_run_packed(tracker.tracker_ids, ptr[n], b, h, w)[:2])
+                ptr.pop(n - 1, None)
+            if asynchronous and starts:
+                record(starts[-1], *self.engine.stream_collect()[:2])
         return self._finish(counter, obj, cam_name)
 
     def run_streams(self, sources, cam_names, zone_paths, batch=16):
@@ -168,20 +187,19 @@ class CountingPipeline:
             f0 = starts[n]
             return f0, min(batch, len(order) - f0)
 
-        f0, b = span(0)
-        self.engine.stream_submit(dev[f0:f0 + b].data_ptr(), b, h, w)
-        for n in range(len(starts)):
-            f0, b = span(n)
-            if n + 1 < len(starts):
-                g0, gb = span(n + 1)
-                self.engine.stream_submit(dev[g0:g0 + gb].data_ptr(), gb, h, w)
-            self.engine.stream_run_async_multi(tids, cams[f0:f0 + b], dev[f0:f0 + b].data_ptr(), b, h, w)
-            if n > 0:
-                record(starts[n - 1], *self.engine.stream_collect()[:2])
-        if starts:
-            record(starts[-1], *self.engine.stream_collect()[:2])
-        for st in stages:
-            st[0].close()
+        with self._video(*[st[0] for st in stages]):
+            f0, b = span(0)
+            self.engine.stream_submit(dev[f0:f0 + b].data_ptr(), b, h, w)
+            for n in range(len(starts)):
+                f0, b = span(n)
+                if n + 1 < len(starts):
+                    g0, gb = span(n + 1)
+                    self.engine.stream_submit(dev[g0:g0 + gb].data_ptr(), gb, h, w)
+                self.engine.stream_run_async_multi(tids, cams[f0:f0 + b], dev[f0:f0 + b].data_ptr(), b, h, w)
+                if n > 0:
+                    record(starts[n - 1], *self.engine.stream_collect()[:2])
+            if starts:
+                record(starts[-1], *self.engine.stream_collect()[:2])
         return [self._finish(st[1], o, n) for st, o, n in zip(stages, objs, cam_names)]
 
     def run_frame_sharded(self, source, cam_name, zone_path, chunk=8, device=None):
@@ -206,25 +224,25 @@ class CountingPipeline:
         tracker, counter = self._stages(cam_name, source.video_info, zone_path) if rank == 0 else (None, None)
         obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
         devs = [torch.from_numpy(frames[a:b]).to(f"cuda:{self.engine.cfg.device}") for a, b in mine]     # only this rank's chunks
-        if mine:
-            self.engine.stream_submit(devs[0].data_ptr(), len(devs[0]), h, w)
-        for r in range(n_rounds):
-            if r + 1 < len(mine):                                                # detector of the next chunk runs behind this round's ReID / gather
-                self.engine.stream_submit(devs[r + 1].data_ptr(), len(devs[r + 1]), h, w)
-            if r < len(mine):
-                rows7, feat = self.engine.stream_embed(devs[r].data_ptr(), len(devs[r]), h, w)
-                rows7[:, 0] += mine[r][0] + 1                                     # 1-based global frame id (modules/datasets.py:61)
-            else:
-                rows7, feat = np.zeros((0, 7)), 0
-            all_rows, all_feat, _ = self.engine.allgather_rows(rows7, feat, world)   # rank-major = frame order within a round
-            if rank != 0:
-                continue
-            for fid, rows in self.engine.videotracker_run_features(tracker.tracker_ids, all_rows, all_feat, h, w):
-                obj["frames"].extend([fid] * len(rows))
-                obj["tracks"].extend(rows[:, 4].tolist())
-                obj["labels"].extend(rows[:, 5].tolist())
-                obj["boxes"].extend(list(rows[:, :4].copy()))
+        with self._video(tracker):
+            if mine:
+                self.engine.stream_submit(devs[0].data_ptr(), len(devs[0]), h, w)
+            for r in range(n_rounds):
+                if r + 1 < len(mine):                                                # detector of the next chunk runs behind this round's ReID / gather
+                    self.engine.stream_submit(devs[r + 1].data_ptr(), len(devs[r + 1]), h, w)
+                if r < len(mine):
+                    rows7, feat = self.engine.stream_embed(devs[r].data_ptr(), len(devs[r]), h, w)
+                    rows7[:, 0] += mine[r][0] + 1                                     # 1-based global frame id (modules/datasets.py:61)
+                else:
+                    rows7, feat = np.zeros((0, 7)), 0
+                all_rows, all_feat, _ = self.engine.allgather_rows(rows7, feat, world)   # rank-major = frame order within a round
+                if rank != 0:
+                    continue
+                for fid, rows in self.engine.videotracker_run_features(tracker.tracker_ids, all_rows, all_feat, h, w):
+                    obj["frames"].extend([fid] * len(rows))
+                    obj["tracks"].extend(rows[:, 4].tolist())
+                    obj["labels"].extend(rows[:, 5].tolist())
+                    obj["boxes"].extend(list(rows[:, :4].copy()))
         if rank != 0:
             return None, None
-        tracker.close()                                 # the reference drops the video's VideoTracker here (modules/__init__.py:32-36)
         return self._finish(counter, obj, cam_name)
