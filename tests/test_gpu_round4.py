@@ -449,3 +449,21 @@ def test_a_failed_video_does_not_poison_the_next_one(golden_dir):
         res.append((key(rows), counts))
         eng.close()
     assert len(res[0][0]) > 10 and res[0] == res[1]
+
+
+def test_edge_arguments_end_in_a_result_or_an_error():
+    """tools/experiments/edge_args.py: 33 calls with empty inputs, 1-pixel and 8 x 640 frames, boxes outside the frame, NaN boxes, zero-sized
+    batches, calls out of order, zero-frame videos -- each ends in a result or a VcError with the argument named; none crashes the process
+    (own process: a fault would otherwise take pytest down)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "edge_args.py")], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "EDGE_DONE" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    out = r.stdout
+    assert "pyerr" not in out, out
+    for needle in ("error detect([]) -> libvcount_hip status 1", "error stream_submit(h=0) -> libvcount_hip status 1: frame size 0 x 640",
+                   "error embed(box outside) -> libvcount_hip status 1: box 0 gives an empty crop", "ok    run_stream(0 frames)",
+                   "error stream_collect with nothing in flight -> libvcount_hip status 3"):
+        assert needle in out, (needle, out)

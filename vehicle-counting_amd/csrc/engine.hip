@@ -763,7 +763,9 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
 
 int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w, bool swap_rb) {
     VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "detector not finalized");
-    VC_CHECK(B >= 1 && B <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    VC_CHECK(B >= 1, VC_ERR_ARG, "a batch needs at least one frame (got %d)", B);
+    VC_CHECK(B <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+    VC_CHECK(h >= 1 && w >= 1, VC_ERR_ARG, "frame size %d x %d", h, w);
     int nh, nw;
     autoshape_net_size(&h, &w, 1, e->cfg.img_size, nh, nw);
     const LetterboxGeom g = letterbox_geom(h, w, nh, nw, swap_rb);
@@ -1187,7 +1189,9 @@ int vc_engine_sync(vc_engine* e) {
 int vc_detect(vc_engine* e, const uint8_t* const* rgb, const int* h, const int* w, int n, float* out_det, int* out_count) {
     VC_CHECK(e && rgb && h && w && out_det && out_count, VC_ERR_ARG, "null argument");
     VC_CHECK(e->finalized && e->cfg.with_detector, VC_ERR_STATE, "detector not finalized");
-    VC_CHECK(n >= 1 && n <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, e->cfg.max_batch);
+    VC_CHECK(n >= 1, VC_ERR_ARG, "a batch needs at least one image (got %d)", n);
+    VC_CHECK(n <= e->cfg.max_batch, VC_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, e->cfg.max_batch);
+    for (int i = 0; i < n; ++i) VC_CHECK(rgb[i] && h[i] >= 1 && w[i] >= 1, VC_ERR_ARG, "image %d: null pointer or size %d x %d", i, h[i], w[i]);
     VC_HIP(hipSetDevice(e->cfg.device));
     int nh, nw;
     autoshape_net_size(h, w, n, e->cfg.img_size, nh, nw);
@@ -1324,7 +1328,8 @@ int vc_embed(vc_engine* e, const uint8_t* bgr, int h, int w, const double* boxes
 int vc_embed_tensor(vc_engine* e, const float* x, int k, float* out_feat) {
     VC_CHECK(e && x && out_feat, VC_ERR_ARG, "null argument");
     VC_CHECK(e->finalized && e->cfg.with_reid, VC_ERR_STATE, "ReID net not finalized");
-    VC_CHECK(k >= 1 && k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
+    VC_CHECK(k >= 1, VC_ERR_ARG, "at least one crop is needed (got %d)", k);
+    VC_CHECK(k <= e->cfg.max_crops, VC_ERR_CAPACITY, "%d crops exceed max_crops %d", k, e->cfg.max_crops);
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_HIP(hipMemcpyAsync(e->d_reid_in_nchw, x, (size_t)k * 3 * 2500 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     VC_HIP(hipStreamSynchronize(e->rstream));

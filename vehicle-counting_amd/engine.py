@@ -270,6 +270,8 @@ class Engine:
 
     def stream_collect(self):
         """Rows of the oldest asynchronous batch, packed like `stream_run_packed` (blocks until its tracker loop is done)."""
+        if not getattr(self, "_async_shapes", None):
+            raise L.VcError(3, "stream_collect: no asynchronous batch is in flight (stream_run_async first)")
         b, cap_rows = self._async_shapes.pop(0)
         rows, m, nd = np.empty((b, cap_rows, 6), np.int64), np.zeros(b, np.int32), np.zeros(b, np.int32)
         L.check(L.lib().vc_stream_collect(self._h, L.ptr(rows, C.c_int64), cap_rows, L.ptr(m, C.c_int), L.ptr(nd, C.c_int), b))
