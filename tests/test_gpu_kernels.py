@@ -140,6 +140,30 @@ def test_conv1x1_direct_configs(cfg, ci, slots, monkeypatch):
                 np.testing.assert_array_equal(y, y_igemm)
 
 
+@pytest.mark.parametrize("slots", [0, 8])
+@pytest.mark.parametrize("cfg,ci,co", [(50, 128, 128), (51, 256, 256), (52, 256, 128), (53, 128, 256), (54, 128, 128)])
+def test_conv1x1_stream_configs(cfg, ci, co, slots, monkeypatch):
+    """Weights-in-LDS streaming 1x1 variants (conv1x1_stream_kernel: a wave owns every output channel of its pixels, the pixel operand
+    comes straight from global memory): ragged pixel tails, fewer blocks than waves, SiLU and no activation, a short persistent grid;
+    against the torch reference and bit for bit against the implicit-GEMM kernel."""
+    for (B, H, W) in ((3, 7, 9), (2, 40, 41), (1, 3, 5)):
+        for act in (1, 0):
+            rng = np.random.default_rng(cfg * 131 + co + H)
+            x = rng.standard_normal((B, H, W, ci), dtype=np.float32)
+            w = (rng.standard_normal((co, ci, 1, 1), dtype=np.float32) / np.sqrt(ci)).astype(np.float32)
+            b = rng.standard_normal(co, dtype=np.float32) * 0.1
+            monkeypatch.setenv("VC_CONV_CFG", str(cfg))
+            if slots:
+                monkeypatch.setenv("VC_CONV_SLOTS", str(slots))
+            y = E.conv2d(x, w, b, stride=1, pad=0, act=act, precision="bf16")
+            monkeypatch.delenv("VC_CONV_SLOTS", raising=False)
+            monkeypatch.setenv("VC_CONV_CFG", "3")
+            y_igemm = E.conv2d(x, w, b, stride=1, pad=0, act=act, precision="bf16")
+            ref = torch_conv(x, w, b, 1, 0, act, None, 0, "bf16")
+            np.testing.assert_allclose(y, ref, rtol=2 ** -7, atol=2e-3)
+            np.testing.assert_array_equal(y, y_igemm)
+
+
 @pytest.mark.parametrize("hw", [(720, 1280, 384, 640), (333, 500, 448, 640), (640, 640, 640, 640), (100, 60, 640, 384)])
 def test_letterbox(hw):
     h, w, nh, nw = hw

@@ -157,7 +157,8 @@ def test_hot_kernel_cost_rows_match_the_oracle(eng, name):
     eng.tracker_reset(tid)
 
 
-def test_random_scenes_random_parameters_match_the_oracle(eng):
+@pytest.mark.parametrize("arena_mb", [None, 0])
+def test_random_scenes_random_parameters_match_the_oracle(arena_mb):
     """Seeded random scenes (2-70 objects with look-alike appearance twins, births and deaths, missed detections, clutter, an empty
     frame, shuffled detection order) under random tracker parameters (max_dist, max_iou_distance, max_age 1-40, n_init 1-4, budget
     1-60): ids, FSM counters, states, gallery sizes identical to the oracle's TrackerState after every frame, means to 1e-9
@@ -167,5 +168,9 @@ def test_random_scenes_random_parameters_match_the_oracle(eng):
     spec = importlib.util.spec_from_file_location("tracker_soak", os.path.join(root, "tools", "experiments", "tracker_soak.py"))
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
+    eng = E.Engine(None, synth_reid(1702), precision="f32", max_crops=128, max_frame_hw=(720, 1280), max_tracks=512, nn_budget_cap=60)   # own engine: the
+    if arena_mb is not None:                                      # module's shared one carries the tracks of the tests before this one
+        eng.set_option("dot_arena_mb", arena_mb)                  # 0: every batch on the in-walk instance (see the `eng` fixture)
     bad = [s for s in range(200, 214) if not soak.run(eng, s)]
+    eng.close()
     assert not bad, bad

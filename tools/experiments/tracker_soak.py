@@ -52,8 +52,8 @@ def run(eng, seed):
         if ok and len(ids): ok = np.allclose(s["mean"], np.array([k.mean for k in ref.tracks]), rtol=1e-9, atol=1e-9)
         if ok: ok = np.array_equal(s["gallery"], [len(ref.gallery.get(k.tid, [])) for k in ref.tracks])
         if not ok:
-            print("DIVERGED seed", seed, "frame", t, p, "tracks", len(ids), "dets", len(dets)); return False
-    eng.tracker_reset(tid)
+            print("DIVERGED seed", seed, "frame", t, p, "tracks", len(ids), "dets", len(dets)); eng.tracker_destroy(tid); return False
+    eng.tracker_destroy(tid)
     return True
 
 

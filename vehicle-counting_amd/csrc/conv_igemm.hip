@@ -1200,6 +1200,119 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_direct_kernel(const ConvP p)
     }
 }
 
+// ---- 1x1 / stride 1, streaming form: weights in LDS, a wave owns ALL output channels of its pixels (bf16) -----------------------
+// The wide-map pointwise layers (K, N <= 256 at 80^2 / 40^2) move 2 - 7 times the bytes their MFMAs are worth in time, and both forms
+// above leave them at ~3.3 TB/s: the implicit GEMM pays a DMA issue, a counted wait and a workgroup barrier per K tile around a dozen
+// MFMAs, and the register-weight kernel reads every pixel NG times with 32 KB of unique bytes in flight per CU.  tools/ubench/stream_bw
+// puts the ceiling for THIS access shape (fragment loads, epilogue-shaped stores) at 4.5 - 5.0 TB/s.  Here the whole weight matrix sits
+// in LDS as ready-made MFMA fragments (CT x KS KB, up to 128 KB: one workgroup of eight waves per CU), a wave takes PT x 16 pixels,
+// reads their channel runs straight from global memory into the MFMA "B" operand and keeps all CT x 16 outputs of those pixels in
+// its accumulators: every input byte is read once, nothing is staged, no barrier after the prologue.  The pixel fragments of K step
+// ks are re-requested for the wave's NEXT block as soon as the step's MFMAs have consumed them, so a block's loads fly under the rest
+// of the K loop and the whole epilogue of the block before (8 waves x 16 KB in flight per CU).  K order, operand order and epilogue
+// are those of conv_igemm_kernel: bit-identical results.
+// Measured (128 frames, isolated, autotuner's timing): 256 -> 256 at 40^2 0.054 - 0.056 ms against 0.060 - 0.062 for the best staged tile,
+// 256 -> 128 at 80^2 0.149 - 0.158 against 0.159 - 0.166, 128 -> 128 at 80^2 0.112 - 0.116 (NP = 1, PT = 2) against 0.120 - 0.125; a tie on the
+// smaller maps -- 5 - 9 %, not the 30 % the access-shape ceiling would allow.  Neither a second fragment set (a block's loads in flight for
+// two block times) nor counting the epilogue's stores as allowed-outstanding (loads and stores do retire in issue order here:
+// tools/ubench/vmcnt_order, 0 of 3e9) moved it, so what is left is not staging, load latency or store acknowledgement; both removed.
+// END TO END the kernel LOSES: one workgroup with up to 132 KB of LDS per CU keeps the ReID queue's workgroups off the CUs it runs on --
+// 17.96 / 18.27 k frames/s with it against 18.55 / 18.81 k without (alternating 60-step runs, one box) although the conv stage sum drops
+// from 6.40 to 6.35 ms.  The autotuner therefore offers it only under VC_CONV_STREAM=1 (conv_stream_cfg); it stays for the tests and as the
+// measured answer to "would reading every byte once with nothing staged reach the copy rate".
+template <int CT, int KS, int PT, int NP, int ACT>
+__global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(const ConvP p) {
+    constexpr uint32_t OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint4 wl[CT * KS * 64 + CT * 4];      // weight fragments [ct][ks][lane], then the bias
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fch = lane >> 4;
+    for (int f = wave; f < CT * KS; f += 8) {                 // LDS order [ks][ct]: a K step's fragments are one ds_read offset apart
+        const int ks = f / CT, ct = f - ks * CT;
+        wl[f * 64 + lane] = *(const uint4*)((const char*)p.w + ((size_t)(ct * 16 + frow) * p.Kw + ks * 32 + fch * 8) * 2);
+    }
+    float* bl = (float*)(wl + CT * KS * 64);
+    for (int i = threadIdx.x; i < CT * 16; i += 512) bl[i] = p.bias[i];
+    __syncthreads();
+    const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    const uint32_t wl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)wl + lane * 16;
+    // The pixel fragments are loaded by hand too (global_load_dwordx4 + counted s_waitcnt): with loads and stores both pending, hipcc's
+    // wait insertion falls back to vmcnt(0) in front of the first MFMA of every block, which drains the next block's loads AND this
+    // block's stores once per iteration.  Loads return in order: when step ks of a block's first pass starts, the loads younger than its
+    // fragments are the (KS - 1 - ks) * PT of the later K steps (requested during the previous block's last pass), so
+    // "vmcnt <= (KS - 1 - ks) * PT" means they have landed; the epilogue's stores also sit on the counter and can only make the wait longer.
+    // Rows past M are clamped to the last row (read, multiplied, dropped by the epilogue's m < M).
+    u32x4v x[PT][KS];
+    const char* inb = (const char*)p.in + (size_t)p.in_co * 2 + fch * 16;
+    const char* ra[PT];
+    auto rows_of = [&](int blk) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) ra[pt] = inb + (size_t)min((blk * PT + pt) * 16 + frow, p.M - 1) * p.in_cs * 2;
+    };
+#define VC_XLOAD(pt, ks) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(x[pt][ks]) : "v"(ra[pt]), "n"((ks) * 64))
+    rows_of(gw);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) VC_XLOAD(pt, ks);
+    constexpr int CTP = CT / NP;                          // channel tiles per pass: the accumulators of one pass are CTP x PT x 4 registers
+    for (int blk = gw; blk < nblk; blk += nw) {
+        rows_of(blk + nw);                            // the next block of this wave (past the end: the last row again)
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            f32x4 acc[CTP][PT];
+#pragma unroll
+            for (int a = 0; a < CTP; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // The weight fragments are read by hand, one ahead of the MFMAs that use them: left to the compiler, the loop-invariant LDS
+            // reads are hoisted out of the block loop (CT x KS x 4 registers: 170 - 550 spills).  lgkmcnt(1) = everything but the newest
+            // LDS operation has landed, whatever else the compiler has in flight (LDS returns in order): the wait can only be too strict.
+            uint32_t wa = wl_addr + np * CTP * 1024;
+            asm volatile("" : "+v"(wa));
+            u32x4v wcur, wnext;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wcur) : "v"(wa));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (np == 0) {                        // first pass over this block: its fragments of step ks must have landed
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((KS - 1 - ks) * PT));
+#pragma unroll
+                    for (int b = 0; b < PT; ++b) asm volatile("" : "+v"(x[b][ks]));
+                }
+#pragma unroll
+                for (int a = 0; a < CTP; ++a) {
+                    if (a + 1 < CTP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wnext) : "v"(wa), "n"((a + 1) * 1024));
+                    else if (ks + 1 < KS) { wa += CT * 1024; asm volatile("ds_read_b128 %0, %1" : "=v"(wnext) : "v"(wa)); }
+                    if (a + 1 < CTP || ks + 1 < KS) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wcur));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur));
+                    Chunk wf;
+                    wf.u = wcur;
+#pragma unroll
+                    for (int b = 0; b < PT; ++b) {
+                        Chunk xa;
+                        xa.u = x[b][ks];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.h, xa.h, acc[a][b], 0, 0, 0);
+                    }
+                    wcur = wnext;
+                }
+                if (np == NP - 1) {                   // last pass: this K step's fragments are dead, request the next block's
+#pragma unroll
+                    for (int b = 0; b < PT; ++b) VC_XLOAD(b, ks);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < CTP; ++a) {
+                const float4 b1[1] = {*(const float4*)(bl + (np * CTP + a) * 16 + fch * 4)};
+                conv_epilogue_bf16<PT, 1, ACT, RES_NONE>(p, reinterpret_cast<f32x4(&)[1][PT]>(acc[a]), b1, blk * PT * 16, (np * CTP + a) * 16 + fch * 4, frow);
+            }
+        }
+    }
+}
+#undef VC_XLOAD
+
+bool conv_stream_cfg(int cfg) { return cfg >= 50 && cfg <= 54; }
+
 int conv_k_tile(int prec) { return prec == PREC_F32 ? 32 : prec == PREC_FP8 ? 128 : 64; }    // weights are padded to the widest K tile (KC = 8)
 
 double conv_flops(const ConvP& p) { return 2.0 * (double)p.M * (double)p.Cout * (double)p.K; }
@@ -1238,9 +1351,22 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #undef VC_X
 // weights-in-registers 1x1 (bf16): Z(index, CT, KS, PT, OCC)
 #define VC_DIRECT_CFGS(Z) Z(32, 2, 1, 4, 4) Z(33, 4, 2, 4, 2) Z(34, 4, 2, 2, 3) Z(35, 4, 4, 2, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43) and the halo-staged 3x3/s2 (44-49)
+// weights-in-LDS streaming 1x1 (bf16): S(index, CT, KS, PT, NP): 128 -> 128, 256 -> 256, 256 -> 128, 128 -> 256 channels; NP passes over the
+// block's fragments, each for CT / NP channel tiles, keep accumulators + fragments + epilogue inside 256 registers at two waves per SIMD
+#define VC_STREAM_CFGS(S) S(50, 8, 4, 4, 2) S(51, 16, 8, 2, 2) S(52, 8, 8, 2, 1) S(53, 16, 4, 2, 2) S(54, 8, 4, 2, 1)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43) and the halo-staged 3x3/s2 (44-49)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    return n;
+}
+
 template <class K>
 static int resident_workgroups(K kernel, int threads = 256) {
     int per_cu = 0, dev = 0, cus = 256;
@@ -1391,6 +1517,19 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
 }
 
 
+template <int CT, int KS, int PT, int NP>
+static int launch_stream1x1(ConvP p, hipStream_t s) {
+    if (!direct1x1_applicable(p, CT, KS) || p.Cout != CT * 16) return VC_ERR_ARG;                     // quietly, like launch_halo
+    p.Kw = p.Kp;
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    p.ntiles = nblk;
+    const int grid = std::max(1, std::min((nblk + 7) / 8, p.slots > 0 ? std::max(1, p.slots / 8) : device_cus()));   // persistent, one workgroup per CU
+    if (p.act == ACT_SILU) launch_timed(p, conv1x1_stream_kernel<CT, KS, PT, NP, ACT_SILU>, dim3(grid), dim3(512), 0, s, p);
+    else launch_timed(p, conv1x1_stream_kernel<CT, KS, PT, NP, ACT_NONE>, dim3(grid), dim3(512), 0, s, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
     if (cfg < 0 || cfg >= conv_num_cfgs()) cfg = conv_heuristic(p);
     switch (cfg) {
@@ -1403,6 +1542,9 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #define VC_Z(i, ct, ks, pt, occ) case i: return launch_direct1x1<ct, ks, pt, occ>(p, s);
         VC_DIRECT_CFGS(VC_Z)
 #undef VC_Z
+#define VC_S(i, ct, ks, pt, np) case i: return launch_stream1x1<ct, ks, pt, np>(p, s);
+        VC_STREAM_CFGS(VC_S)
+#undef VC_S
 #define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
         VC_CONV_CFGS(VC_X)
         VC_CONV_BIG_CFGS(VC_X)

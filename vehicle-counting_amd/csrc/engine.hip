@@ -470,7 +470,9 @@ static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
     }
     int best = -1;
     float best_ms = 1e30f;
+    static const bool stream_on = getenv("VC_CONV_STREAM") && atoi(getenv("VC_CONV_STREAM")) != 0;   // conv1x1_stream_kernel: wins alone, loses beside the ReID queue (conv_igemm.hip)
     for (int cfg = 0; cfg < conv_num_cfgs(); ++cfg) {
+        if (conv_stream_cfg(cfg) && !stream_on) continue;
         if (launch_conv_cfg(c, cfg, s) != VC_OK) continue;          // warm-up (instruction cache, L2)
         float tmin = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
@@ -482,6 +484,8 @@ static int tuned_cfg(vc_engine* e, const ConvP& c, hipStream_t s) {
             hipEventElapsedTime(&ms, e->ev0, e->ev1);
             tmin = std::min(tmin, ms);
         }
+        static const bool tlog = getenv("VC_TUNE_LOG") != nullptr;      // diagnostics: every candidate's time
+        if (tlog) fprintf(stderr, "[vc tune] %s cfg %d %.4f ms\n", key.c_str(), cfg, tmin);
         if (tmin < best_ms) { best_ms = tmin; best = cfg; }
     }
     e->tuned[key] = best;
