@@ -467,3 +467,44 @@ def test_edge_arguments_end_in_a_result_or_an_error():
                    "error embed(box outside) -> libvcount_hip status 1: box 0 gives an empty crop", "ok    run_stream(0 frames)",
                    "error stream_collect with nothing in flight -> libvcount_hip status 3"):
         assert needle in out, (needle, out)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_multi_camera_random_layouts_equal_separate_runs(golden_dir, tmp_path, seed):
+    """run_streams (S cameras interleaved in every batch, vc_stream_run_async_multi) against separate single-camera runs for seeded random
+    layouts: 2 - 7 cameras, clip lengths 1 - 25 (cameras drop out of the round-robin at different times, one-frame clips included), batch
+    sizes that do and do not divide the interleaved length, on one engine that has already served other layouts (fp32: conv numerics do
+    not depend on the tile configuration a batch size selects)."""
+    import json
+    rng = np.random.default_rng(seed)
+    nc, H, W = 6, 273, 521
+    ysd, rsd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=8.0, obj_shift=1.0), synth_reid(1702)
+    with open(os.path.join(golden_dir, "cam_04_halfres.json")) as f:
+        z = json.load(f)
+    for sh in z["shapes"]:                                            # the whole frame is the zone: every tracked row reaches the CSV
+        if sh["label"] == "zone":
+            sh["points"] = [[0.0, 0.0], [float(W), 0.0], [float(W), float(H)], [0.0, float(H)]]
+    zone = str(tmp_path / "zone.json")
+    with open(zone, "w") as f:
+        json.dump(z, f)
+    cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=None)
+    track = dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=60)
+    eng = E.Engine(ysd, rsd, precision="f32", num_classes=nc, max_batch=8, max_frame_hw=(H, W), max_crops=8 * 300, max_tracks=4096, nn_budget_cap=60,
+                   max_trackers=8 * nc)
+    key = lambda rows: [(r["label"], r["track_id"], r["frame_id"], r["direction"], tuple(r["box"])) for r in rows]
+    total = 0
+    for _ in range(2):
+        S = int(rng.integers(2, 8))
+        lens = [int(rng.integers(1, 26)) for _ in range(S)]
+        clips = [synth_frames(n, H, W, n_obj=3 + c % 4, seed=100 * seed + c) for c, n in enumerate(lens)]
+        names = [f"cam_{c:02d}" for c in range(S)]
+        pipe = CountingPipeline(args, cfg, {"cam": {n: {"tracking_config": track} for n in names}}, engine=eng, class_names=[f"c{i}" for i in range(nc)])
+        multi = pipe.run_streams([FrameSource(c) for c in clips], names, [zone] * S, batch=int(rng.integers(1, 9)))
+        for c in range(S):
+            rows, counts = pipe.run_stream(FrameSource(clips[c]), names[c], zone, batch=int(rng.integers(1, 9)), asynchronous=bool(rng.integers(0, 2)))
+            assert key(multi[c][0]) == key(rows), (S, lens, c)
+            assert multi[c][1] == counts, (S, lens, c)
+            total += len(rows)
+    assert total >= 5, total                                      # (clips shorter than N_INIT frames contribute no rows)
+    eng.close()
