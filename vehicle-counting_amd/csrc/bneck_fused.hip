@@ -352,6 +352,16 @@ bool bneck_cv3_fused_applicable(const ConvP& pm1, const ConvP& pm2, const ConvP&
     return p3.out_cs % 8 == 0 && p3.out_co % 8 == 0 && p3.Kp >= 128;
 }
 
+// Persistent grid of the Bottleneck kernels: one workgroup holds 128 KB of a CU's LDS, so a grid on all 256 CUs shuts the other conv queue's
+// workgroups out of the whole chip for the length of the launch (three launches of 0.1 - 0.19 ms per 128-frame step).  An eighth of the CUs
+// is left free: the kernel alone is ~14 % slower (28.6 instead of 25 tile rounds at 80^2), the step is 2.5 - 3.5 % faster (60-step runs on
+// one box, alternating: 18.36 / 18.42 / 18.47 k frames/s with 256 workgroups, 18.90 / 19.10 k with 224, 18.91 k with 192, 18.66 k with 240).
+// The same cap on front_fused_kernel (150 KB) and reid_block_fused_kernel (152 KB) stayed inside the run-to-run spread.
+static int bneck_grid_cap(int cus) {
+    static const int forced = getenv("VC_BN_GRID") ? atoi(getenv("VC_BN_GRID")) : 0;      // A/B switch
+    return forced > 0 ? forced : cus - cus / 8;
+}
+
 int launch_bneck_cv3_fused(const ConvP& pm1, const ConvP& pm2, const ConvP& p3, hipStream_t s) {
     if (!bneck_cv3_fused_applicable(pm1, pm2, p3)) return VC_ERR_ARG;
     BnArgs a{};
@@ -369,7 +379,7 @@ int launch_bneck_cv3_fused(const ConvP& pm1, const ConvP& pm2, const ConvP& p3, 
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     a.res = pm2.res_mode == RES_AFTER_ACT ? 1 : 0;
-    launch_timed(pm1, bneck_fused_kernel<true>, dim3(std::min(ntiles, cus)), dim3(BN_NW * 64), 0, s, a);
+    launch_timed(pm1, bneck_fused_kernel<true>, dim3(std::min(ntiles, bneck_grid_cap(cus))), dim3(BN_NW * 64), 0, s, a);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
@@ -390,7 +400,7 @@ int launch_bneck_fused(const ConvP& pm1, const ConvP& pm2, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         return n;
     }();
-    const int grid = std::min(ntiles, cus);                // persistent, one workgroup per CU (128 KB of LDS)
+    const int grid = std::min(ntiles, bneck_grid_cap(cus));                // persistent, one workgroup per CU (128 KB of LDS)
     a.res = pm2.res_mode == RES_AFTER_ACT ? 1 : 0;
     launch_timed(pm1, bneck_fused_kernel<false>, dim3(grid), dim3(BN_NW * 64), 0, s, a);
     VC_HIP(hipGetLastError());
