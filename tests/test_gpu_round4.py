@@ -508,3 +508,29 @@ def test_multi_camera_random_layouts_equal_separate_runs(golden_dir, tmp_path, s
             total += len(rows)
     assert total >= 5, total                                      # (clips shorter than N_INIT frames contribute no rows)
     eng.close()
+
+
+def test_head_side_stream_gives_the_same_detections():
+    """The P3 / P4 Detect-head ops run on the engine's head stream beside the neck layers that follow them (Op::side, joined before the
+    decode): detections and the head's gathered logits are what the single-stream order gives, for several batch sizes on one engine
+    (cached plans) and back and forth between the two modes."""
+    nc = 80
+    sd = synth_yolo("yolov5s", nc=nc, seed=1702, det_scale=4.0, obj_shift=1.0)
+    frames = synth_frames(6, 640, 640, n_obj=12, seed=1702)         # bench.py's workload: ~15 boxes per frame from the random head
+    eng = E.Engine(sd, None, precision="bf16", num_classes=nc, max_batch=6, max_frame_hw=(640, 640))
+    imgs = [f[:, :, ::-1] for f in frames]
+    ref = {}
+    for mode in (1, 0, 1, 0):
+        eng.set_option("head_side", mode)
+        for b in (6, 1, 3):
+            d = eng.detect(imgs[:b])
+            l23 = eng.debug_layer(23, batch=b)
+            if b not in ref:
+                ref[b] = (d, l23)
+                assert sum(len(x) for x in d) > 0
+            else:
+                assert len(d) == len(ref[b][0])
+                for x, y in zip(d, ref[b][0]):
+                    np.testing.assert_array_equal(x, y)
+                np.testing.assert_array_equal(l23, ref[b][1])
+    eng.close()

@@ -44,6 +44,7 @@ struct Op {
     int cout_logical = 0;            // > 0: the launch covers zero-padded output channels, FLOPs count this many
     int param = -1;                  // index into Net::params for CONV
     int tuned = -2;                  // CONV: tile configuration resolved at the first launch of this (cached) op; -2 = not yet
+    int side = 0;                    // 1: off the detector's critical path -- launched on the engine's head stream, joined before the decode
 };
 
 // The op list of one network pass is a pure function of its shape: built once per (batch, tensor size, head variant) / (crop count)
@@ -108,12 +109,15 @@ struct vc_engine {
     hipStream_t stream = nullptr;    // ReID + tracker
     hipStream_t dstream = nullptr;   // detector (runs ahead of the tracker on the next batch)
     hipStream_t rstream = nullptr;   // ReID of the next batch (stream path), concurrent with detector and tracker
+    hipStream_t hstream = nullptr;   // Detect-head ops of the P3 / P4 levels, beside the neck layers that follow them (Op::side)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_used = false;          // the last run_ops put ops on the head stream
     hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;
     // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
     // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv per launch
-    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1; } opt;
+    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1, head_side = 1; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 

@@ -366,30 +366,25 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     lv[14] = x = pb.conv("model.14.conv", x, mkview(cat19, B, Hn / 16, Wn / 16, c[2], c[2]), 1, 1, 0, ACT_SILU);
     { Op op{}; op.kind = Op::UPSAMPLE; op.a = x; op.b = mkview(cat16, B, Hn / 8, Wn / 8, c[2], 0); ops.push_back(op); lv[15] = op.b; }
     lv[16] = cat16;
-    View p3 = lv[17] = yolo_c3(pb, e, 17, cat16, full("l17", 8, c[2]), c[2], e->rep[0], false);
-    lv[18] = pb.conv("model.18.conv", p3, mkview(cat19, B, Hn / 16, Wn / 16, c[2], 0), 3, 2, 1, ACT_SILU);
-    lv[19] = cat19;
-    View p4 = lv[20] = yolo_c3(pb, e, 20, cat19, full("l20", 16, c[3]), c[3], e->rep[0], false);
-    lv[21] = pb.conv("model.21.conv", p4, mkview(cat22, B, Hn / 32, Wn / 32, c[3], 0), 3, 2, 1, ACT_SILU);
-    lv[22] = cat22;
-    View p5 = lv[23] = yolo_c3(pb, e, 23, cat22, full("l23", 32, c[4]), c[4], e->rep[0], false);
     // Detect.m[i]: 1x1 conv + bias (models/yolo.py::Detect).  fp32 mode: fp32 logits.  bf16 mode: bf16 logits like every other
     // activation, and the launch covers round_up(no, 8) output channels (the packed weight / bias rows past `no` are zero) so
     // that the 255-channel head takes the 16-byte-store epilogue; FLOPs are still counted for `no` channels (Op::cout_logical).
     const int no = 3 * (e->cfg.num_classes + 5), lcs = round_up(no, 8);
-    const View heads[3] = {p3, p4, p5};
     e->sparse_pass = e->prec == PREC_BF16 && e->opt.sparse_head && !e->want_pred_debug && e->d_hc_count;
-    for (int i = 0; i < 3 && e->sparse_pass; ++i) {
-        // sparse Detect head (detect_post.hip): objectness conv over every pixel -> gather the pixels that can pass conf_thres -> the
-        // full head on the gathered rows (row count on the device).  The work reported is what RUNS (the gathered rows); the dense
-        // head's figures travel beside it as dense_* (round 3 credited the launch with the dense head's work: a 6 us launch showed
-        // 3.4 x the chip's peak in the per-layer table).
+    // sparse Detect head (detect_post.hip): objectness conv over every pixel -> gather the pixels that can pass conf_thres -> the
+    // full head on the gathered rows (row count on the device).  The work reported is what RUNS (the gathered rows); the dense
+    // head's figures travel beside it as dense_* (round 3 credited the launch with the dense head's work: a 6 us launch showed
+    // 3.4 x the chip's peak in the per-layer table).  The ops of level i follow the layer that produces its map: P3's and P4's are
+    // marked Op::side and run on the head stream beside layers 18 - 23 (three short dependent launches per level, 0.11 ms of
+    // objectness conv alone at 80^2, that used to sit at the END of the detector's chain of ~63 dependent launches).
+    auto sparse_head = [&](int i, const View& x) {
+        if (!e->sparse_pass || pb.status != VC_OK) return;
+        const size_t first = ops.size();
         const std::string hp = "model.24.m." + std::to_string(i);
-        const View& x = heads[i];
         const double es = 2.0, Mh = (double)x.B * x.H * x.W;
         View ov{}; ov.ptr = e->d_obj[i]; ov.cs = 8; ov.co = 0;
         pb.conv(hp + ".obj", x, ov, 1, 1, 0, ACT_NONE);
-        if (pb.status != VC_OK) break;
+        if (pb.status != VC_OK) return;
         ops.back().flops_override = 2.0 * Mh * 3 * x.C;                                    // the three objectness rows (the launch covers 8 zero-padded channels)
         ops.back().bytes_override = (Mh * x.C + 8.0 * x.C) * es + Mh * 8 * es;
         ops.back().dense_flops = 0; ops.back().dense_bytes = 0;                            // the dense head has no such launch: its work is on the head conv below
@@ -397,7 +392,7 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
         View gx{}; gx.ptr = e->d_hc_x[i]; gx.B = 1; gx.H = 1; gx.W = e->hc_cap[i]; gx.C = x.C; gx.cs = x.C; gx.co = 0;
         View go{}; go.ptr = e->d_hc_logits[i]; go.cs = lcs; go.co = 0;
         pb.conv(hp, gx, go, 1, 1, 0, ACT_NONE);
-        if (pb.status != VC_OK) break;
+        if (pb.status != VC_OK) return;
         Op& hop = ops.back();
         hop.cout_logical = hop.conv.Cout; hop.conv.Cout = lcs;
         hop.conv.m_dev = e->d_hc_count + i;
@@ -407,7 +402,19 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
         hop.flops_per_row = 2.0 * no * x.C; hop.bytes_per_row = (x.C + (double)lcs) * es;  // one gathered feature row in, one logit row out
         hop.dense_flops = 2.0 * Mh * no * x.C;
         hop.dense_bytes = (Mh * x.C + (double)no * x.C) * es + Mh * lcs * es;              // the dense head's in + weights + out
-    }
+        if (i < 2) for (size_t j = first; j < ops.size(); ++j) ops[j].side = 1;
+    };
+    View p3 = lv[17] = yolo_c3(pb, e, 17, cat16, full("l17", 8, c[2]), c[2], e->rep[0], false);
+    sparse_head(0, p3);
+    lv[18] = pb.conv("model.18.conv", p3, mkview(cat19, B, Hn / 16, Wn / 16, c[2], 0), 3, 2, 1, ACT_SILU);
+    lv[19] = cat19;
+    View p4 = lv[20] = yolo_c3(pb, e, 20, cat19, full("l20", 16, c[3]), c[3], e->rep[0], false);
+    sparse_head(1, p4);
+    lv[21] = pb.conv("model.21.conv", p4, mkview(cat22, B, Hn / 32, Wn / 32, c[3], 0), 3, 2, 1, ACT_SILU);
+    lv[22] = cat22;
+    View p5 = lv[23] = yolo_c3(pb, e, 23, cat22, full("l23", 32, c[4]), c[4], e->rep[0], false);
+    sparse_head(2, p5);
+    const View heads[3] = {p3, p4, p5};
     for (int i = 0; i < 3 && !e->sparse_pass; ++i) {
         View o{}; o.ptr = e->d_logits[i]; o.cs = lcs; o.co = 0;
         const bool wide = e->prec == PREC_F32;
@@ -509,9 +516,22 @@ static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes, 
     cp.ev_start = pp.a; cp.ev_stop = pp.b;
 }
 
-static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s) {
+static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s_main) {
+    // Op::side ops go to the head stream (detector passes only; not while every launch is bracketed by blocking events): the first of a run
+    // of them waits for everything the main stream has been given so far, the caller joins the head stream before it reads their results
+    const bool side_ok = s_main == e->dstream && e->hstream && e->opt.head_side && !e->profiling;
+    bool prev_side = false;
+    e->side_used = false;
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         Op& op = ops[oi];
+        const bool on_side = side_ok && op.side;
+        if (on_side && !prev_side) {
+            VC_HIP(hipEventRecord(e->ev_fork, s_main));
+            VC_HIP(hipStreamWaitEvent(e->hstream, e->ev_fork, 0));
+            e->side_used = true;
+        }
+        prev_side = on_side;
+        hipStream_t s = on_side ? e->hstream : s_main;
         switch (op.kind) {
             case Op::CONV: {
                 const double es = elem_size(op.conv.prec);
@@ -729,6 +749,10 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
         VC_HIP(hipMemsetAsync(e->post.cand_count, 0, sizeof(int) * B, ds));
     }
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
+    if (e->side_used) {                                      // the P3 / P4 head ops ran on the head stream: the decode reads their rows
+        VC_HIP(hipEventRecord(e->ev_join, e->hstream));
+        VC_HIP(hipStreamWaitEvent(ds, e->ev_join, 0));
+    }
     if (e->sparse_pass && e->prof_async && e->h_hc_ring)     // executed-work accounting: this pass's gathered-row counts, next to the event pairs
         VC_HIP(hipMemcpyAsync(e->h_hc_ring + (size_t)e->hc_ring_cur * 4, e->d_hc_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ds));
     // decode + NMS
@@ -960,7 +984,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
-        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1);
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -995,6 +1019,8 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
             hipEventCreateWithFlags(&e->ev_reid[2], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&e->ev_det[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_det[1], hipEventDisableTiming) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
+        if (hipStreamCreateWithPriority(&e->hstream, hipStreamNonBlocking, plo) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("head stream create failed"); st = VC_ERR_HIP; break; }
         if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) { set_error("event create failed"); st = VC_ERR_HIP; break; }
         tune_cache_load(e);
         if (cfg->with_detector) yolo_define(e);
@@ -1023,6 +1049,9 @@ int vc_engine_destroy(vc_engine* e) {
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->dstream) hipStreamDestroy(e->dstream);
     if (e->rstream) hipStreamDestroy(e->rstream);
+    if (e->hstream) hipStreamDestroy(e->hstream);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     for (hipEvent_t ev : e->ev_det) if (ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_reid) if (ev) hipEventDestroy(ev);
     for (vc::TrackStage& ts : e->tstage) if (ts.done) hipEventDestroy(ts.done);
@@ -1143,6 +1172,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "crop_per_pixel") e->opt.crop_per_pixel = value;
     else if (n == "sparse_head") e->opt.sparse_head = value;
     else if (n == "reid_block_fused") e->opt.reid_block_fused = value;
+    else if (n == "head_side") e->opt.head_side = value;
     else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
