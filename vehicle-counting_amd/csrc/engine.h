@@ -112,6 +112,7 @@ struct vc_engine {
     hipStream_t hstream = nullptr;   // Detect-head ops of the P3 / P4 levels, beside the neck layers that follow them (Op::side)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_used = false;          // the last run_ops put ops on the head stream
+    void* d_zero = nullptr; size_t zero_bytes = 0; bool want_hc_count = false;   // per-pass counters cleared by one memset (engine.hip)
     hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};
     bool finalized = false;

@@ -277,7 +277,7 @@ static int yolo_alloc(vc_engine* e) {
             VC_TRY(dev_alloc(e, &e->d_hc_x[i], (size_t)e->hc_cap[i] * c[2 + i] * 2));
             VC_TRY(dev_alloc(e, &e->d_hc_logits[i], (size_t)e->hc_cap[i] * lcs * 2));
         }
-        VC_TRY(dev_alloc(e, (void**)&e->d_hc_count, 64));
+        e->want_hc_count = true;                            // carved out of the zero block below (one memset per pass clears all three)
         VC_TRY(host_alloc(e, (void**)&e->h_hc_ring, (size_t)vc_engine::HC_RING * 4 * sizeof(int)));
         memset(e->h_hc_ring, 0, (size_t)vc_engine::HC_RING * 4 * sizeof(int));
     }
@@ -288,14 +288,19 @@ static int yolo_alloc(vc_engine* e) {
     VC_TRY(dev_alloc(e, (void**)&pb.cand_conf, B * mc * sizeof(float)));
     VC_TRY(dev_alloc(e, (void**)&pb.cand_cls, B * mc * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&pb.cand_idx, B * mc * sizeof(int)));
-    VC_TRY(dev_alloc(e, (void**)&pb.cand_count, B * sizeof(int)));
+    // per-pass counters in ONE block: [sparse-head row counts, 64 B][cand_count][overflow] -- a single memset at the head of the detector's
+    // chain of dependent launches instead of three
+    e->zero_bytes = 64 + 2 * B * sizeof(int);
+    VC_TRY(dev_alloc(e, (void**)&e->d_zero, e->zero_bytes));
+    if (e->want_hc_count) e->d_hc_count = (int*)e->d_zero;
+    pb.cand_count = (int*)((char*)e->d_zero + 64);
     VC_TRY(dev_alloc(e, (void**)&pb.sort_box, B * mc * 4 * sizeof(float)));
     VC_TRY(dev_alloc(e, (void**)&pb.sort_conf, B * mc * sizeof(float)));
     VC_TRY(dev_alloc(e, (void**)&pb.sort_cls, B * mc * sizeof(int)));
     VC_TRY(dev_alloc(e, (void**)&pb.mask, B * mc * (mc / 64) * sizeof(unsigned long long)));
     VC_TRY(dev_alloc(e, (void**)&pb.det, B * md * 6 * sizeof(float)));
     VC_TRY(dev_alloc(e, (void**)&pb.det_count, B * sizeof(int)));
-    VC_TRY(dev_alloc(e, (void**)&pb.overflow, B * sizeof(int)));
+    pb.overflow = pb.cand_count + B;
     VC_TRY(dev_alloc(e, (void**)&e->d_geom, B * 5 * sizeof(float)));
     VC_TRY(host_alloc(e, (void**)&e->h_geom, 2 * B * 5 * sizeof(float)));
     for (int k = 0; k < 2; ++k) {
@@ -744,9 +749,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     e->l0_stale = false;
     if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
         e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
-        VC_HIP(hipMemsetAsync(e->d_hc_count, 0, 64, ds));
-        VC_HIP(hipMemsetAsync(e->post.overflow, 0, sizeof(int) * B, ds));
-        VC_HIP(hipMemsetAsync(e->post.cand_count, 0, sizeof(int) * B, ds));
+        VC_HIP(hipMemsetAsync(e->d_zero, 0, e->zero_bytes, ds));
     }
     VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
     if (e->side_used) {                                      // the P3 / P4 head ops ran on the head stream: the decode reads their rows
