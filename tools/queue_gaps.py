@@ -21,3 +21,10 @@ print(f"queue {q}: {len(s)} kernels over {span/1e3:.2f} ms ({steps} passes); idl
       f"> 20 us: {int((g > 20).sum())} totalling {g[g > 20].sum()/steps:.0f} us per pass, <= 20 us: {g[(g > 0) & (g <= 20)].sum()/steps:.0f} us per pass")
 for d, a, b in sorted(gaps, key=lambda x: -x[0])[:12]:
     print(f"  {d/1e3:8.1f} us  after {a}  before {b}")
+if len(sys.argv) > 3:                                   # one whole pass, in order: start offset, duration, gap before, kernel
+    starts = [i for i, r in enumerate(s) if key in r[2]]
+    a, b = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+    t0 = s[a][0]
+    print(f"one pass ({b - a} kernels, {(s[b][0] - t0)/1e3:.0f} us from its first kernel to the next pass's first):")
+    for i in range(a, b):
+        print(f"  +{(s[i][0]-t0)/1e3:8.1f} us  dur {(s[i][1]-s[i][0])/1e3:7.1f}  gap {((s[i][0]-s[i-1][1])/1e3 if i > a else 0):6.1f}  {s[i][2][:90]}")
