@@ -27,3 +27,4 @@ for l in lines:
 print("total conv ms", tot, "launches", len(lines), "B", B, "conv ms per frame", tot / B)
 import vehicle_counting_amd._lib as L
 print({k: eng.profile_read(c) for k, c in (("conv", 0), ("detect_aux", 1), ("reid_aux", 2), ("track", 3))})
+eng.close()
