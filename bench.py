@@ -331,11 +331,6 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
     eng = st.eng
     st.run_steps(first, warmup, False)
     st.sync(world)
-    if os.environ.get("VC_TUNE_LOAD"):            # experiment: tile choices re-timed beside a ReID forward pass (vc_tune_under_load)
-        t0 = time.perf_counter()
-        n = eng.tune_under_load()
-        print(f"bench.py: vc_tune_under_load changed {n} choices in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
-        st.sync(world)
     eng.profile_reset(); eng.profile(2)            # in-flight event pairs around every conv launch of the timed steps (no host waits)
     dt, post_ms, all_counts = st.timed(first + warmup, steps, world)
     if world > 1:

@@ -262,9 +262,6 @@ int vc_gather_offsets(int world, int max_rows, const int* counts, int64_t* src_o
  * disagree on the member of a near-tie (bf16 results are identical across tile configurations of one kernel family only). */
 int vc_tune_export(vc_engine* e, char* buf, size_t cap, size_t* size);   /* buf may be NULL: *size receives the bytes needed (incl. NUL) */
 int vc_tune_import(vc_engine* e, const char* text);
-/* Re-times the tile candidates of the detector's stand-alone convs while one forward pass of the largest cached ReID plan runs on the ReID
- * stream (the neighbour the stream path gives them); needs one completed stream-path step.  *changed = choices that differ from the isolated ones. */
-int vc_tune_under_load(vc_engine* e, int* changed);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 #define VC_PROF_CONV 0       /* all implicit-GEMM conv launches */

@@ -114,7 +114,6 @@ SIGNATURES = {
     "vc_gather_offsets": [_i, _i, _pi, _pl, _pl, _pl],
     "vc_tune_export": [_vp, C.c_char_p, C.c_size_t, _P(C.c_size_t)],
     "vc_tune_import": [_vp, C.c_char_p],
-    "vc_tune_under_load": [_vp, _pi],
     "vc_profile_read": [_vp, _i, _pd, _pl, _pd, _pd],
     "vc_profile_reset": [_vp],
     "vc_profile_ops": [_vp, C.c_char_p, C.c_size_t],

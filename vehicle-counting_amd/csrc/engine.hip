@@ -1214,74 +1214,6 @@ int vc_tune_import(vc_engine* e, const char* text) {
     return VC_OK;
 }
 
-// Re-time the tile candidates of every detector conv that is launched on its own BESIDE the neighbour it really has: one forward pass of the
-// largest cached ReID plan is started on the ReID stream, then the candidate runs back to back on the detector stream for about as long
-// as that pass lasts.  The isolated timing of the first launch (tuned_cfg) prefers whatever is fastest with the chip to itself; in the
-// stream path the first half of every detector pass runs beside the ReID net of the batch before (profiles/r04_detector_pass_timeline.txt).
-int vc_tune_under_load(vc_engine* e, int* changed) {
-    VC_CHECK(e, VC_ERR_ARG, "null engine");
-    VC_HIP(hipSetDevice(e->cfg.device));
-    ReidPlan* bg = nullptr;
-    int bgk = 0;
-    for (auto& kv : e->reid_plans)
-        if (kv.first.second > bgk && !kv.second.ops.empty()) { bg = &kv.second; bgk = kv.first.second; }
-    VC_CHECK(bg && !e->yolo_plans.empty(), VC_ERR_STATE, "vc_tune_under_load: run the stream path once first (no cached detector / ReID plan)");
-    VC_HIP(hipStreamSynchronize(e->dstream)); VC_HIP(hipStreamSynchronize(e->rstream)); VC_HIP(hipStreamSynchronize(e->stream));
-    if (e->hstream) VC_HIP(hipStreamSynchronize(e->hstream));
-    const bool pa = e->prof_async, pr = e->profiling;
-    e->prof_async = false; e->profiling = false;
-    static const bool stream_on = getenv("VC_CONV_STREAM") && atoi(getenv("VC_CONV_STREAM")) != 0;
-    std::map<std::string, int> done;
-    int n_changed = 0, st = VC_OK;
-    for (auto& kv : e->yolo_plans) {
-        for (Op& op : kv.second.ops) {
-            if (op.kind != Op::CONV || op.tuned < 0) continue;           // consumed by a fused kernel, or the fixed heuristic (device-side row count)
-            const ConvP cp = op.conv;
-            const std::string key = tune_key(cp);
-            auto d = done.find(key);
-            if (d != done.end()) { op.tuned = d->second; continue; }
-            int best = op.tuned;
-            float best_ms = 1e30f;
-            for (int cfg = 0; cfg < conv_num_cfgs() && st == VC_OK; ++cfg) {
-                if (conv_stream_cfg(cfg) && !stream_on) continue;
-                if (launch_conv_cfg(cp, cfg, e->dstream) != VC_OK) continue;
-                hipEventRecord(e->ev0, e->dstream);
-                launch_conv_cfg(cp, cfg, e->dstream);
-                hipEventRecord(e->ev1, e->dstream);
-                hipEventSynchronize(e->ev1);
-                float t1 = 0.f;
-                hipEventElapsedTime(&t1, e->ev0, e->ev1);
-                const int reps = std::max(2, std::min(32, (int)(1.5f / std::max(t1, 0.01f))));
-                st = run_ops(e, bg->ops, VC_PROF_REID_AUX, e->rstream);   // the neighbour
-                if (st != VC_OK) break;
-                hipEventRecord(e->ev0, e->dstream);
-                for (int r = 0; r < reps; ++r) launch_conv_cfg(cp, cfg, e->dstream);
-                hipEventRecord(e->ev1, e->dstream);
-                hipEventSynchronize(e->ev1);
-                float ms = 0.f;
-                hipEventElapsedTime(&ms, e->ev0, e->ev1);
-                hipStreamSynchronize(e->rstream);
-                ms /= reps;
-                static const bool tlog = getenv("VC_TUNE_LOG") != nullptr;
-                if (tlog) fprintf(stderr, "[vc tune/load] %s cfg %d %.4f ms (alone %.4f)\n", key.c_str(), cfg, ms, t1);
-                if (ms < best_ms) { best_ms = ms; best = cfg; }
-            }
-            if (st != VC_OK) break;
-            done[key] = best;
-            if (best != op.tuned) ++n_changed;
-            op.tuned = best;
-            e->tuned[key] = best;
-            e->tuned_dirty = true;
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tuned["d" + std::to_string(e->cfg.device) + "_" + key] = best;
-        }
-        if (st != VC_OK) break;
-    }
-    e->prof_async = pa; e->profiling = pr;
-    if (changed) *changed = n_changed;
-    return st;
-}
-
 int vc_engine_sync(vc_engine* e) {
     VC_CHECK(e, VC_ERR_ARG, "null engine");
     VC_HIP(hipStreamSynchronize(e->stream));

@@ -374,12 +374,6 @@ class Engine:
         L.check(L.lib().vc_tune_export(self._h, buf, n.value, C.byref(n)))
         return buf.value.decode()
 
-    def tune_under_load(self) -> int:
-        """Re-time the detector's stand-alone convs beside a ReID forward pass (vc_tune_under_load); returns how many choices changed."""
-        n = C.c_int()
-        L.check(L.lib().vc_tune_under_load(self._h, C.byref(n)))
-        return n.value
-
     def tune_import(self, text: str):
         """Adopt another engine's autotune choices (before the first launch of those shapes)."""
         L.check(L.lib().vc_tune_import(self._h, text.encode()))
