@@ -331,7 +331,9 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
     eng = st.eng
     st.run_steps(first, warmup, False)
     st.sync(world)
-    eng.profile_reset(); eng.profile(2)            # in-flight event pairs around every conv launch of the timed steps (no host waits)
+    eng.profile_reset()
+    if not os.environ.get("VC_BENCH_NO_EVENTS"):  # (A/B switch: what the event pairs themselves cost)
+        eng.profile(2)                             # in-flight event pairs around every conv launch of the timed steps (no host waits)
     dt, post_ms, all_counts = st.timed(first + warmup, steps, world)
     if world > 1:
         t = torch.tensor([dt], device=st.dev, dtype=torch.float64)
