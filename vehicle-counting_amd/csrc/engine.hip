@@ -1545,7 +1545,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
                 int steps = 0; while (steps < 800 && tr[steps * 5]) ++steps;
                 double d[5] = {0, 0, 0, 0, 0}; int n3 = 0;
                 for (int k = 9; k + 1 < steps; ++k, ++n3) { for (int j = 0; j < 4; ++j) d[j] += (double)(tr[k * 5 + j + 1] - tr[k * 5 + j]); d[4] += (double)(tr[(k + 1) * 5] - tr[k * 5 + 4]); }
-                if (n3) fprintf(stderr, "[vc conv dbg] wg %d: cycles per step (steps 9..%d): dma issue %.0f, frag reads %.0f, mfma issue %.0f, vmcnt wait %.0f, barrier %.0f\n", w * 128, steps - 2, d[0] / n3, d[1] / n3, d[2] / n3, d[3] / n3, d[4] / n3);
+                if (n3) fprintf(stderr, "[vc conv dbg] wg %d: cycles per step (steps 9..%d), stamp intervals 0-1 %.0f, 1-2 %.0f, 2-3 %.0f, 3-4 %.0f, 4-next %.0f\n", w * 128, steps - 2, d[0] / n3, d[1] / n3, d[2] / n3, d[3] / n3, d[4] / n3);
                 if (steps > 30) { fprintf(stderr, "[vc conv dbg]   steps 18..26 total cycles:"); for (int k = 18; k < 27; ++k) fprintf(stderr, " %lld", tr[(k + 1) * 5] - tr[k * 5]); fprintf(stderr, "\n"); }
             }
             {   // persistent halo kernel: stamps 5 - 7 = second tile's set-up / K loop / epilogue
