@@ -74,12 +74,13 @@ def test_conv2d(case, precision):
 
 
 @pytest.mark.parametrize("slots", [0, 8])
-@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 50)))
+@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 50)) + [55])
 def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""
     s2halo = 44 <= cfg <= 49
-    halo = cfg in (28, 29, 30, 31, 36, 37, 38, 39) or s2halo    # 40-43 are implicit-GEMM tiles with 16 waves per workgroup
+    v2 = cfg == 55                                               # conv3x3_halo_v2_kernel (conv_halo_v2.hip)
+    halo = cfg in (28, 29, 30, 31, 36, 37, 38, 39) or s2halo or v2   # 40-43 are implicit-GEMM tiles with 16 waves per workgroup
     monkeypatch.setenv("VC_CONV_CFG", str(cfg))
     if slots:
         if halo:
@@ -99,6 +100,13 @@ def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
         # 20-column map (25 x 5 tiles across images) with three groups
         cases = [(2, 40, 32, 64, 72, 3, 2, 1, 1, 0), (5, 8, 6, 64, 40, 3, 2, 1, 2, 0), (1, 160, 160, 64, 128, 3, 2, 1, 1, 0),
                  (3, 20, 24, 128, 136, 3, 2, 1, 0, 0), (2, 40, 40, 192, 64, 3, 2, 1, 1, 0)]
+    if v2:
+        # row-aligned tiles (R rows with R * W <= 256 and a patch of at most 320 pixels; Cin a multiple of 64): 13 rows of 19 with a ragged
+        # last tile and a ragged channel tail, one tile that holds five whole 7 x 7 images, 4 x 5 images (a tile spans nine), the 40 x 40
+        # geometry of the detector (6 rows per tile, 8-row patch = exactly 320 pixels) with four slices and two channel tiles, residual
+        # before / after the activation
+        cases = [(2, 23, 19, 64, 72, 3, 1, 1, 1, 1), (5, 7, 7, 64, 40, 3, 1, 1, 2, 2), (9, 4, 5, 128, 130, 3, 1, 1, 1, 0),
+                 (3, 40, 40, 128, 256, 3, 1, 1, 1, 2), (7, 13, 13, 192, 128, 3, 1, 1, 2, 1)]
     for case in cases:
         B, H, W, Ci, Co, k, s, p, act, rm = case
         rng = np.random.default_rng(cfg * 131 + H)

@@ -1,5 +1,6 @@
-"""conv3x3_halo_pf_kernel (tile configurations 55 - 60) against the halo configurations the autotuner picks today (39, 30, 38, 31):
-bit-identity and isolated time on the 3x3 / s1 shapes of a 128-frame step.  Usage: python tools/experiments/halo_pf_compare.py [shape ...]"""
+"""conv3x3_halo_v2_kernel (tile configuration 55) against the halo configurations the autotuner picked before it (39, 30, 38, 31): bit-identity and
+isolated time on the 3x3 / s1 shapes of a 128-frame step (Bottleneck / BasicBlock form: residual + activation).
+Usage: [CFGS=39,30,55] python tools/experiments/halo_compare.py [shape ...]"""
 import os, re, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -11,7 +12,7 @@ SHAPES = {  # name: (B, H, W, Cin, Cout, act, res_mode)
     "reid7_256": (1536, 7, 7, 256, 256, 2, 1),
     "reid4_512": (1536, 4, 4, 512, 512, 2, 1),
 }
-CFGS = [int(c) for c in os.environ.get("CFGS", "39,38,30,31,55,56,57,58,59,60").split(",")]
+CFGS = [int(c) for c in os.environ.get("CFGS", "39,38,30,31,55").split(",")]
 
 def child(name, cfg):
     import vehicle_counting_amd.engine as E

@@ -1,4 +1,4 @@
-// Device-side pieces shared by the convolution kernels (conv_igemm.hip, conv_halo_pf.hip): MFMA fragment types, the LDS swizzle,
+// Device-side pieces shared by the convolution kernels (conv_igemm.hip, conv_halo_v2.hip): MFMA fragment types, the LDS swizzle,
 // the in-place MFMA statement and the epilogues (bias, activation, residual, bf16 / fp8 pack, concat-slice and split-destination stores).
 #pragma once
 #include "vc_common.h"

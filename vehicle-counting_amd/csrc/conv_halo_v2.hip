@@ -1,11 +1,10 @@
 // Halo-staged 3x3 / stride 1 / pad 1 convolution (bf16), second form: row-aligned tiles, streamed weight fragments, look-ahead
-// fragment reads and a patch fetch spread over the K loop.  Tile configuration 65 of conv_igemm.hip's table.
+// fragment reads and a patch fetch spread over the K loop.  Tile configuration 55 of conv_igemm.hip's table.
 // Same rows of the reference as conv_igemm.hip: the 3x3 convolutions of ultralytics/yolov5 v6.0 `Bottleneck` blocks that
 // /root/reference/networks/yolo.py:70 executes and of the DeepSORT appearance net's BasicBlocks,
 // /root/reference/networks/deepsort/deep/model.py:5-98 (row B5).
 //
-// What the per-step cycle stamps of conv3x3_halo_kernel / conv3x3_halo_ps_kernel showed on 128 -> 128 at 40^2 (128 frames, two workgroups
-// per CU; tools/experiments/halo_ps_trace.sh): a K step of 32 MFMAs per wave (512 matrix-pipe cycles) takes ~1800 cycles -- ~250 to issue the
+// What per-step cycle stamps of conv3x3_halo_kernel showed on 128 -> 128 at 40^2 (128 frames, two workgroups per CU): a K step of 32 MFMAs per wave (512 matrix-pipe cycles) takes ~1800 cycles -- ~250 to issue the
 // step's LDS-DMA instructions, ~500 for the twelve fragment reads and their `lgkmcnt(0)`, ~900 for the MFMAs while the other workgroup's
 // wave on the SIMD issues its own, ~100 + ~300 in the counted wait and the barrier -- and the first step of every 32-channel slice
 // ~4600 more: all workgroups of the chip request their 28 KB patches in the same microsecond, an HBM-bound burst (~11 B/clk/CU) that
@@ -89,32 +88,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_v2_kernel(const ConvP p, 
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)&lds[0];
     const int frow = lane & 15, fch = lane >> 4;
-    uint32_t xaddr[PT][9];                         // this lane's fragment of every tap in patch buffer 0 (buffer 1: + XBYTES as an immediate)
-    {
-        const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int q = wave * 64 + i * 16 + frow;
-            const bool ok = q < bp;
-            const int mm = m0 + (ok ? q : 0);
-            int g = (int)((float)mm * inv_w);                                     // global row, +-1 fix-up (mm < 2^24)
-            g -= (g * W > mm) ? 1 : 0;
-            g += ((g + 1) * W <= mm) ? 1 : 0;
-            const int x = mm - g * W;
-            int b = (int)((float)g * inv_h);
-            b -= (b * H > g) ? 1 : 0;
-            b += ((b + 1) * H <= g) ? 1 : 0;
-            const int y = g - b * H;
-            const int pc = q + W;                                                 // patch index of the centre tap
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const bool valid = ok && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-                const int px = valid ? pc + dy * W + dx : ZP;
-                xaddr[i][t] = lds_base + (uint32_t)((RCH + px * 4 + (fch ^ ((px >> 1) & 2))) * 16);
-            }
-        }
-    }
     // weight fragments: channel tile i of ring stage st sits i * 1024 + st * WSTAGE bytes behind this
     const uint32_t wfrag0 = lds_base + 16 * lds_slot<4>(frow, fch);
 
@@ -159,6 +132,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_v2_kernel(const ConvP p, 
     for (int j = 0; j < XI; ++j) VC_XPIECE(0, 0, j);
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) VC_WSTAGE(st, st);
+    // (the fragment addresses are computed while the first patch and weight tiles are on their way)
+    uint32_t xaddr[PT][9];                         // this lane's fragment of every tap in patch buffer 0 (buffer 1: + XBYTES as an immediate)
+    {
+        const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int q = wave * 64 + i * 16 + frow;
+            const bool ok = q < bp;
+            const int mm = m0 + (ok ? q : 0);
+            int g = (int)((float)mm * inv_w);                                     // global row, +-1 fix-up (mm < 2^24)
+            g -= (g * W > mm) ? 1 : 0;
+            g += ((g + 1) * W <= mm) ? 1 : 0;
+            const int x = mm - g * W;
+            int b = (int)((float)g * inv_h);
+            b -= (b * H > g) ? 1 : 0;
+            b += ((b + 1) * H <= g) ? 1 : 0;
+            const int y = g - b * H;
+            const int pc = q + W;                                                 // patch index of the centre tap
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool valid = ok && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+                const int px = valid ? pc + dy * W + dx : ZP;
+                xaddr[i][t] = lds_base + (uint32_t)((RCH + px * 4 + (fch ^ ((px >> 1) & 2))) * 16);
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * WI) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -255,7 +255,7 @@ static bool v2_applicable(const ConvP& p) {
 
 int launch_halo_v2_cfg(const ConvP& p_in, int cfg, hipStream_t s) {
     static const bool enabled = !(getenv("VC_CONV_HALO_V2") && atoi(getenv("VC_CONV_HALO_V2")) == 0);      // A/B switch
-    if (cfg != 65 || !enabled || !v2_applicable(p_in)) return VC_ERR_ARG;      // quietly: the autotuner skips it, launch_conv falls back
+    if (cfg != 55 || !enabled || !v2_applicable(p_in)) return VC_ERR_ARG;      // quietly: the autotuner skips it, launch_conv falls back
     ConvP p = p_in;
     const int R = v2_rows(p);
     const int rows = p.B * p.H;

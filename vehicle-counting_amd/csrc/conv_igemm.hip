@@ -1018,7 +1018,7 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 // weights-in-LDS streaming 1x1 (bf16): S(index, CT, KS, PT, NP): 128 -> 128, 256 -> 256, 256 -> 128, 128 -> 256 channels; NP passes over the
 // block's fragments, each for CT / NP channel tiles, keep accumulators + fragments + epilogue inside 256 registers at two waves per SIMD
 #define VC_STREAM_CFGS(S) S(50, 8, 4, 4, 2) S(51, 16, 8, 2, 2) S(52, 8, 8, 2, 1) S(53, 16, 4, 2, 2) S(54, 8, 4, 2, 1)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 6 + 4 + 1; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43) and the halo-staged 3x3/s2 (44-49)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54) and conv3x3_halo_v2_kernel (55)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1188,8 +1188,7 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #define VC_Y(i, bp, bc, wp, wc, ns) case i: return launch_halo<bp, bc, wp, wc, ns>(p, s);
         VC_HALO_CFGS(VC_Y)
 #undef VC_Y
-        case 55: case 56: case 57: case 58: case 59: case 60: case 61: case 62: case 63: case 64: return launch_halo_pf_cfg(p, cfg, s);     // conv_halo_pf.hip
-        case 65: return launch_halo_v2_cfg(p, cfg, s);        // conv_halo_v2.hip
+        case 55: return launch_halo_v2_cfg(p, cfg, s);        // conv_halo_v2.hip
 #define VC_V(i, bp, bc, wp, wc, ns) case i: return launch_s2halo<bp, bc, wp, wc, ns>(p, s);
         VC_S2HALO_CFGS(VC_V)
 #undef VC_V

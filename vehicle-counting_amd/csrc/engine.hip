@@ -1539,7 +1539,7 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
                            st[n / 10], st[n / 2], st[n * 9 / 10], st[n - 1], du[n / 10], du[n / 2], du[n * 9 / 10], du[n - 1]);
             if (n) fprintf(stderr, "[vc conv dbg] %ld workgroups, us per workgroup: prologue %.2f first-tile %.2f k-loop %.2f epilogue %.2f ; first start -> last end %.2f us\n",
                            n, acc[0] / n / 100, acc[1] / n / 100, acc[2] / n / 100, acc[3] / n / 100, (double)(hi - lo) / 100);
-            for (int w = 0; w < 4; ++w) {   // conv3x3_halo_ps_kernel: per-step cycle stamps of four workgroups (first tile)
+            for (int w = 0; w < 4; ++w) {   // conv3x3_halo_v2_kernel: per-step cycle stamps of four workgroups
                 const long long* tr = &h[400000 + w * 4096];
                 if (!tr[0]) continue;
                 int steps = 0; while (steps < 800 && tr[steps * 5]) ++steps;
@@ -1547,11 +1547,6 @@ int vc_conv2d_host(const vc_conv_desc* d, const float* x, const float* w, const 
                 for (int k = 9; k + 1 < steps; ++k, ++n3) { for (int j = 0; j < 4; ++j) d[j] += (double)(tr[k * 5 + j + 1] - tr[k * 5 + j]); d[4] += (double)(tr[(k + 1) * 5] - tr[k * 5 + 4]); }
                 if (n3) fprintf(stderr, "[vc conv dbg] wg %d: cycles per step (steps 9..%d), stamp intervals 0-1 %.0f, 1-2 %.0f, 2-3 %.0f, 3-4 %.0f, 4-next %.0f\n", w * 128, steps - 2, d[0] / n3, d[1] / n3, d[2] / n3, d[3] / n3, d[4] / n3);
                 if (steps > 30) { fprintf(stderr, "[vc conv dbg]   steps 18..26 total cycles:"); for (int k = 18; k < 27; ++k) fprintf(stderr, " %lld", tr[(k + 1) * 5] - tr[k * 5]); fprintf(stderr, "\n"); }
-            }
-            {   // persistent halo kernel: stamps 5 - 7 = second tile's set-up / K loop / epilogue
-                double a2[3] = {0, 0, 0}; long n2 = 0;
-                for (size_t b = 0; b < dbg_n; ++b) { const long long* t = &h[b * 8]; if (t[4] && t[7]) { for (int i = 0; i < 3; ++i) a2[i] += (double)(t[i + 5] - t[i + 4]); ++n2; } }
-                if (n2) fprintf(stderr, "[vc conv dbg] %ld workgroups with a second tile, us: set-up %.2f k-loop %.2f epilogue %.2f\n", n2, a2[0] / n2 / 100, a2[1] / n2 / 100, a2[2] / n2 / 100);
             }
             hipFree(dbg);
         }
