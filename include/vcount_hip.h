@@ -128,10 +128,12 @@ typedef struct vc_tracker_params {
     int nn_budget;            /* NN_BUDGET (<= engine nn_budget_cap) */
 } vc_tracker_params;
 
+/* tracker_id is an opaque handle (slot | generation << 16): every entry point that takes one refuses (VC_ERR_NOTFOUND / VC_ERR_ARG) a handle
+ * whose tracker has been destroyed, also after its slot has been handed to a later vc_tracker_create. */
 int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* tracker_id);
 int vc_tracker_reset(vc_engine* e, int tracker_id);
-/* Gives the tracker's tracks and its id back (the next vc_tracker_create may return the same id).  The reference drops its VideoTracker
- * after every video (modules/__init__.py:32-36); the drop-in's DeepSort calls this when it is closed or collected. */
+/* Gives the tracker's tracks and its slot back.  The reference drops its VideoTracker after every video (modules/__init__.py:32-36); the
+ * drop-in's DeepSort calls this when it is closed. */
 int vc_tracker_destroy(vc_engine* e, int tracker_id);
 /* Tracker.predict() + Tracker.update(detections) for detections already filtered/NMS'ed by the caller.
  * tlwh: k x 4 f64, conf: k f64, feat: k x 512 f32 (host). */

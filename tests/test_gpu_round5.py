@@ -1,0 +1,113 @@
+"""GPU: round-5 additions behind the C ABI --
+  * tracker handles carry a generation: a handle kept past vc_tracker_destroy is refused by every entry point, also once its slot
+    belongs to a later tracker; a closed VideoTracker drives nothing; finalisers queue their handles instead of blocking;
+  * vc_tune_import reaches op plans that have already run (cached plans resolve their tile configuration again);
+  * ReID passes with more crops than the plan cache keeps (transient plans) equal the cached path;
+  * conv3x3_halo_v2_kernel (tile configuration 55) bit for bit against conv3x3_halo_kernel on the detector's and the ReID net's shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vehicle_counting_amd.engine as E  # noqa: E402
+from vehicle_counting_amd import _lib as L  # noqa: E402
+from vehicle_counting_amd.synth import synth_frames  # noqa: E402
+from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
+
+NC = 8
+
+
+def test_stale_tracker_handles_are_refused():
+    from vehicle_counting_amd.track import VideoTracker
+    eng = E.Engine(None, synth_reid(1702), precision="f32", max_crops=16, max_frame_hw=(360, 640), max_tracks=64, nn_budget_cap=10, max_trackers=2)
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((2, 512)).astype(np.float32)
+    tlwh = np.array([[10, 10, 40, 60], [200, 100, 50, 50]], np.float64)
+    old = eng.tracker_create(nn_budget=5)
+    eng.tracker_step(old, tlwh, np.full(2, 0.9), f)
+    eng.tracker_destroy(old)
+    new = eng.tracker_create(nn_budget=5)                          # takes the slot the old tracker gave back
+    assert new & 0xffff == old & 0xffff and new != old
+    eng.tracker_step(new, tlwh[:1], np.full(1, 0.9), f[:1])
+    for call in (lambda: eng.tracker_step(old, tlwh, np.full(2, 0.9), f), lambda: eng.tracker_state(old), lambda: eng.tracker_reset(old),
+                 lambda: eng.tracker_destroy(old), lambda: eng.tracker_snapshot(old)):
+        with pytest.raises(L.VcError, match="stale tracker handle"):
+            call()
+    assert eng.tracker_state(new)["ids"].tolist() == [1]           # the stale calls touched nothing
+    frame = np.zeros((360, 640, 3), np.uint8)
+    with pytest.raises(L.VcError):
+        eng.videotracker_run([old], frame, np.array([[10., 10., 40., 60.]]), np.array([0]), np.array([0.9]))
+    eng.tracker_destroy(new)
+    cam = {"tracking_config": dict(MAX_DIST=0.2, MIN_CONFIDENCE=0.25, NMS_MAX_OVERLAP=0.5, MAX_IOU_DISTANCE=0.6, MAX_AGE=30, N_INIT=3, NN_BUDGET=10)}
+    vt = VideoTracker(2, cam, None, engine=eng)
+    handles = list(vt.tracker_ids)
+    vt.close()
+    with pytest.raises(RuntimeError, match="after close"):
+        vt.run(frame, np.array([[10., 10., 40., 60.]]), np.array([0]), np.array([0.9]))
+    vt2 = VideoTracker(2, cam, None, engine=eng)                   # the next video's trackers: the same slots, other handles
+    assert sorted(t & 0xffff for t in vt2.tracker_ids) == sorted(t & 0xffff for t in handles) and not set(vt2.tracker_ids) & set(handles)
+    del vt2                                                        # finaliser: queued, not destroyed ...
+    assert len(eng._deferred_destroy) == 2
+    vt3 = VideoTracker(2, cam, None, engine=eng)                   # ... until the next tracker is created (max_trackers = 2: it would not fit otherwise)
+    assert len(eng._deferred_destroy) == 0
+    vt3.close()
+    eng.close()
+
+
+def test_tune_import_reaches_plans_that_have_run():
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.0)
+    frames = synth_frames(2, 352, 640, n_obj=6, seed=3)
+    imgs = [f[:, :, ::-1] for f in frames]
+
+    def cfgs(eng):                                                  # tile configuration of every plain conv launch of one pass
+        eng.profile(True); eng.profile_reset(); eng.detect(imgs); log = eng.profile_ops(); eng.profile(False)
+        return [int(l.split("cfg=")[1].split()[0]) for l in log.splitlines() if l.startswith("conv")]
+
+    a = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=2, max_frame_hw=(352, 640))
+    a.detect(imgs)                                                  # plans built, every op's choice resolved
+    before = cfgs(a)
+    text = a.tune_export()
+    # every 3 x 3 / s1 layer that chose a halo-staged kernel is sent to the implicit GEMM (configuration 2) instead
+    lines, changed = [], 0
+    for l in text.strip().splitlines():
+        k, c = l.split()
+        if "_k3x3_s1_" in k and int(c) in (28, 29, 30, 31, 36, 37, 38, 39, 55):
+            c, changed = "2", changed + 1
+        lines.append(f"{k} {c}")
+    assert changed > 0
+    a.tune_import("\n".join(lines) + "\n")
+    after = cfgs(a)
+    assert len(after) == len(before)
+    assert not any(c in (28, 29, 30, 31, 36, 37, 38, 39, 55) for c in after) and any(b != c for b, c in zip(before, after))
+    a.close()
+
+
+def test_reid_transient_plans_equal_cached_plans():
+    eng = E.Engine(None, synth_reid(1702), precision="f32", max_crops=640, max_frame_hw=(360, 640))
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 255, (360, 640, 3), dtype=np.uint8)
+    n = 300                                                         # > VC_REID_PLAN_CACHE_MAX_K: a transient plan per call
+    cx, cy = rng.uniform(40, 600, n), rng.uniform(40, 320, n)
+    boxes = np.stack([cx, cy, rng.uniform(10, 60, n), rng.uniform(10, 60, n)], 1)
+    big1 = eng.embed(frame, boxes)
+    big2 = eng.embed(frame, boxes)
+    np.testing.assert_array_equal(big1, big2)
+    small = np.concatenate([eng.embed(frame, boxes[i:i + 100]) for i in range(0, n, 100)])     # cached plans (k = 100)
+    np.testing.assert_allclose(big1, small, rtol=0, atol=1e-6)      # fp32: the same fmaf chains whatever the batch
+    eng.close()
+
+
+@pytest.mark.parametrize("shape", [(16, 40, 40, 128, 128, 1, 2), (16, 20, 20, 256, 256, 1, 2), (96, 13, 13, 128, 128, 2, 1), (200, 7, 7, 256, 256, 2, 1),
+                                   (300, 4, 4, 512, 512, 2, 1), (3, 38, 50, 64, 192, 1, 0)])
+def test_halo_v2_equals_halo_kernel(shape, monkeypatch):
+    B, H, W, Ci, Co, act, rm = shape
+    rng = np.random.default_rng(H * 131 + Ci)
+    x = rng.standard_normal((B, H, W, Ci), dtype=np.float32)
+    w = (rng.standard_normal((Co, Ci, 3, 3), dtype=np.float32) / np.sqrt(Ci * 9)).astype(np.float32)
+    b = rng.standard_normal(Co, dtype=np.float32) * 0.1
+    res = rng.standard_normal((B, H, W, Co), dtype=np.float32) if rm else None
+    out = {}
+    for cfg in (30, 55):
+        monkeypatch.setenv("VC_CONV_CFG", str(cfg))
+        out[cfg] = E.conv2d(x, w, b, stride=1, pad=1, act=act, res=res, res_mode=rm, precision="bf16")
+    np.testing.assert_array_equal(out[30], out[55])

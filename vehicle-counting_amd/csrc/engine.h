@@ -76,9 +76,17 @@ struct Tracker {
     vc_tracker_params p;
     int known_tracks = 0;            // live tracks reported by the last completed batch
     int pending_dets = 0;            // detections of batches still in flight (each may start a track)
-    bool released = false;           // vc_tracker_destroy: the id is free for the next vc_tracker_create
+    bool released = false;           // vc_tracker_destroy: the slot is free for the next vc_tracker_create
+    int gen = 0;                     // generation of the slot: part of the handle the caller holds
 };
-inline bool tracker_ok(const std::vector<std::unique_ptr<Tracker>>& v, int id) { return id >= 0 && id < (int)v.size() && !v[id]->released; }
+// A tracker HANDLE (what vc_tracker_create returns and every entry point takes) = slot | generation << 16: a handle kept past
+// vc_tracker_destroy never addresses the tracker that reuses its slot (the next video's), it is refused.  Inside the library
+// (FrameClassDets::tracker, task tables, device arrays) trackers are addressed by slot.
+inline bool tracker_ok(const std::vector<std::unique_ptr<Tracker>>& v, int slot) { return slot >= 0 && slot < (int)v.size() && !v[slot]->released; }
+inline int tracker_slot(const std::vector<std::unique_ptr<Tracker>>& v, int handle) {
+    const int s = handle & 0xffff, g = (int)((unsigned)handle >> 16);
+    return handle >= 0 && tracker_ok(v, s) && v[s]->gen == g ? s : -1;
+}
 
 // one (frame, class) step of a batch as the host sees it
 struct TrackTaskHost { int tracker, label, frame, det_off, det_n; };
@@ -111,7 +119,6 @@ struct vc_engine {
     hipStream_t rstream = nullptr;   // ReID of the next batch (stream path), concurrent with detector and tracker
     hipStream_t hstream = nullptr;   // Detect-head ops of the P3 / P4 levels, beside the neck layers that follow them (Op::side)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_used = false;          // the last run_ops put ops on the head stream
     void* d_zero = nullptr; size_t zero_bytes = 0; bool want_hc_count = false;   // per-pass counters cleared by one memset (engine.hip)
     hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_reid[3] = {nullptr, nullptr, nullptr};

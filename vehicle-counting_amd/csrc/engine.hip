@@ -521,19 +521,32 @@ static void conv_timer_arm(vc_engine* e, ConvP& cp, double flops, double bytes, 
     cp.ev_start = pp.a; cp.ev_stop = pp.b;
 }
 
-static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s_main) {
+static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s_main, bool& side_used);
+// *side_used (nullable) = the ops forked onto the head stream.  The join (head stream -> main stream) is recorded HERE, on the error path too:
+// a pass that failed after the fork must not leave head ops running beside the next pass's memset of the counters they write.
+static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s_main, bool* side_used = nullptr) {
+    bool forked = false;
+    const int st = run_ops_body(e, ops, aux_cat, s_main, forked);
+    if (forked) {                                            // the P3 / P4 head ops ran on the head stream: whatever follows on the main stream waits for them
+        const hipError_t e1 = hipEventRecord(e->ev_join, e->hstream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s_main, e->ev_join, 0) : e1;
+        if (st == VC_OK && e2 != hipSuccess) { set_error("head stream join failed: %s", hipGetErrorString(e2)); return VC_ERR_HIP; }
+    }
+    if (side_used) *side_used = forked;
+    return st;
+}
+static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t s_main, bool& side_used) {
     // Op::side ops go to the head stream (detector passes only; not while every launch is bracketed by blocking events): the first of a run
     // of them waits for everything the main stream has been given so far, the caller joins the head stream before it reads their results
     const bool side_ok = s_main == e->dstream && e->hstream && e->opt.head_side && !e->profiling;
     bool prev_side = false;
-    e->side_used = false;
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         Op& op = ops[oi];
         const bool on_side = side_ok && op.side;
         if (on_side && !prev_side) {
             VC_HIP(hipEventRecord(e->ev_fork, s_main));
             VC_HIP(hipStreamWaitEvent(e->hstream, e->ev_fork, 0));
-            e->side_used = true;
+            side_used = true;
         }
         prev_side = on_side;
         hipStream_t s = on_side ? e->hstream : s_main;
@@ -551,11 +564,17 @@ static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t 
                 const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
                 conv_timer_arm(e, cp, fl, by, op);
                 const int front_fused_mode = e->opt.front_fused;   // 0 off, 1 stream path, 2 always
-                const bool fuse_front = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv) &&
-                                        (front_fused_mode == 2 || (e->stem_src && cp.in == e->ybuf["in"].ptr));
-                if (e->stem_src && cp.in == e->ybuf["in"].ptr)       // the letterbox was skipped for this pass: only a u8 stem can run it (the resize: only the fused front)
-                    VC_CHECK(stem_direct_on && (stem_u8_applicable(cp, e->stem_geom) || (fuse_front && front_fused_resize_ok(e->stem_geom))), VC_ERR_STATE,
-                             "letterbox fold-in: no u8 stem kernel applies to this geometry");
+                const bool front_ok = stem_direct_on && front_fused_mode > 0 && nx && nx->kind == Op::CONV && front_fused_applicable(cp, nx->conv);
+                bool u8_src = e->stem_src && cp.in == e->ybuf["in"].ptr;   // the letterbox was skipped for this pass (run_detector_dev)
+                if (u8_src && !(stem_direct_on && (stem_u8_applicable(cp, e->stem_geom) || (front_ok && front_fused_resize_ok(e->stem_geom))))) {
+                    // run_detector_dev decided the fold-in from the engine's widths, this op list decides which kernel runs: should they ever
+                    // disagree (a plan or layout change), the letterbox kernel runs now and the pass goes on from its tensor
+                    ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, s);
+                    VC_TRY(launch_letterbox(e->stem_src, e->ybuf["in"].ptr, cp.B, e->stem_geom, e->aux_prec, s));
+                    e->stem_src = nullptr; e->in_stale = false;
+                    u8_src = false;
+                }
+                const bool fuse_front = front_ok && (front_fused_mode == 2 || u8_src);
                 const bool c3_fused_on = e->opt.c3_fused != 0;
                 const bool fuse_c3 = c3_fused_on && oi + 3 < ops.size() && ops[oi + 1].kind == Op::CONV && ops[oi + 2].kind == Op::CONV && ops[oi + 3].kind == Op::CONV &&
                                      c3_fused_applicable(cp, ops[oi + 1].conv, ops[oi + 2].conv, ops[oi + 3].conv);
@@ -644,8 +663,7 @@ static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t 
                     cp.cfg = 102; cp.ablate = e->opt.ff_ablate;
                     if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = fl + fl1; e->prof_pairs[e->prof_used - 1].bytes = by01; }   // the pair armed above now times both layers
                     ProfScope ps(e, VC_PROF_CONV, fl + fl1, by01, s);
-                    const bool u8 = e->stem_src && cp.in == e->ybuf["in"].ptr;
-                    VC_TRY(launch_front_fused(cp, o1.conv, u8 ? e->stem_src : nullptr, e->stem_geom, s));
+                    VC_TRY(launch_front_fused(cp, o1.conv, u8_src ? e->stem_src : nullptr, e->stem_geom, s));
                     e->l0_stale = true;                                       // layer 0 lived in LDS only
                     ++oi;                                                     // the 3x3 conv is done
                 } else if (stem_direct_on && stem_direct_applicable(cp)) {   // YOLO stem, bf16: direct convolution (stem_direct.hip)
@@ -653,7 +671,7 @@ static int run_ops(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStream_t 
                     ProfScope ps(e, VC_PROF_CONV, fl, by, s);
                     // fp8 engine: the stem also writes the e4m3 copy the next layer reads (TO_FP8 of its own output, folded in)
                     const View* q8 = nx && nx->kind == Op::TO_FP8 && nx->a.ptr == cp.out && nx->a.co == cp.out_co ? &nx->b : nullptr;
-                    if (e->stem_src && cp.in == e->ybuf["in"].ptr) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s, q8, 1.0f / e->act_scale));   // letterbox folded in
+                    if (u8_src) VC_TRY(launch_stem_direct_u8(cp, e->stem_src, e->stem_geom, s, q8, 1.0f / e->act_scale));   // letterbox folded in
                     else VC_TRY(launch_stem_direct(cp, s, q8, 1.0f / e->act_scale));
                     if (q8) ++oi;                                            // the conversion op is done
                 } else if (reid_stem_on && nx && nx->kind == Op::MAXPOOL && nx->a.ptr == cp.out && reid_stem_applicable(cp, nx->b.cs, nx->b.co)) {
@@ -751,11 +769,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
         e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
         VC_HIP(hipMemsetAsync(e->d_zero, 0, e->zero_bytes, ds));
     }
-    VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));
-    if (e->side_used) {                                      // the P3 / P4 head ops ran on the head stream: the decode reads their rows
-        VC_HIP(hipEventRecord(e->ev_join, e->hstream));
-        VC_HIP(hipStreamWaitEvent(ds, e->ev_join, 0));
-    }
+    VC_TRY(run_ops(e, ops, VC_PROF_DETECT_AUX, ds));          // (joins the head stream before it returns: the decode reads the head ops' rows)
     if (e->sparse_pass && e->prof_async && e->h_hc_ring)     // executed-work accounting: this pass's gathered-row counts, next to the event pairs
         VC_HIP(hipMemcpyAsync(e->h_hc_ring + (size_t)e->hc_ring_cur * 4, e->d_hc_count, 4 * sizeof(int), hipMemcpyDeviceToHost, ds));
     // decode + NMS
@@ -817,7 +831,7 @@ int run_detector_dev(vc_engine* e, const uint8_t* d_frames, int B, int h, int w,
     e->in_stale = fuse;
     if (!fuse) { ProfScope ps(e, VC_PROF_DETECT_AUX, 0, 0, e->dstream); VC_TRY(launch_letterbox(d_frames, e->ybuf["in"].ptr, B, g, e->aux_prec, e->dstream)); }
     const int st = yolo_forward(e, B, nh, nw);
-    if (fuse) e->stem_src = d_frames;             // kept for vc_detect_debug_layer(-1)
+    if (fuse && e->in_stale) e->stem_src = d_frames;    // kept for vc_detect_debug_layer(-1) (not when run_ops fell back to the letterbox kernel)
     return st;
 }
 
@@ -871,6 +885,7 @@ static int reid_alloc(vc_engine* e) {
 // (conv_check), and the first layer has 2500 per crop: more than VC_REID_CHUNK crops run as several passes over slices of "in"
 // (the other activation buffers are reused; the passes are ordered on the stream).
 #define VC_REID_CHUNK 6400
+#define VC_REID_PLAN_CACHE_MAX_K 256       // crop counts whose op plans are kept (k0 is 0 for these: one chunk)
 static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float* feat_out);
 static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     // ... and its 50 x 50 x 64 output must stay below the 2 GiB a buffer descriptor addresses (fp32: 3200 crops)
@@ -880,8 +895,12 @@ static int reid_forward(vc_engine* e, int k, hipStream_t rs, float* feat_out) {
     return VC_OK;
 }
 static int reid_forward_chunk(vc_engine* e, int k0, int k, hipStream_t rs, float* feat_out) {
-    if (e->reid_plans.size() > 8192) e->reid_plans.clear();                 // crop counts vary from call to call: bounded cache
-    ReidPlan& plan = e->reid_plans[{k0, k}];
+    // The plan cache pays at batch 1 (a few crops per frame, the same counts again and again).  A batch of the stream path has thousands of
+    // distinct crop counts: those build a transient plan (21 ops, tens of microseconds beside a multi-millisecond pass) instead of
+    // filling the map (~10 KB per entry, a full clear at 8192 entries).
+    ReidPlan transient;
+    const bool cached = k <= VC_REID_PLAN_CACHE_MAX_K;
+    ReidPlan& plan = cached ? e->reid_plans[{k0, k}] : transient;
     std::vector<Op>& ops = plan.ops;
     if (!ops.empty()) {
         VC_TRY(run_ops(e, ops, VC_PROF_REID_AUX, rs));
@@ -965,11 +984,11 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
     // GPU_MAX_HW_QUEUES >= 8 is therefore a DEPLOYMENT requirement; the runtime reads it once, when it builds its queue
     // pool, so the embedding application has to export it before its first HIP call.  The library does not touch the process
     // environment (setenv is not thread-safe against concurrent getenv); the Python binding sets a default at import
-    // (_lib.py), and an engine created without it says so once.
+    // (_lib.py), and an engine created without it says so once when VC_VERBOSE is set.
     {
         static bool warned = false;
         const char* q = getenv("GPU_MAX_HW_QUEUES");
-        if (!warned && (!q || atoi(q) < 8) && !getenv("VC_QUIET")) {
+        if (!warned && (!q || atoi(q) < 8) && getenv("VC_VERBOSE")) {     // opt-in (a library does not write to the process's stderr unasked)
             warned = true;
             fprintf(stderr, "libvcount_hip: GPU_MAX_HW_QUEUES is %s; export GPU_MAX_HW_QUEUES=8 before the first HIP call or the engine's streams share hardware queues (INTEGRATION.md)\n", q ? q : "unset");
         }
@@ -1211,6 +1230,9 @@ int vc_tune_import(vc_engine* e, const char* text) {
         for (const auto& kv : e->tuned) g_tuned["d" + std::to_string(e->cfg.device) + "_" + kv.first] = kv.second;
     }
     if (n) e->tuned_dirty = true;
+    // cached op plans resolved their tile configuration at their first launch: they look the (imported) choice up again
+    for (auto& kv : e->yolo_plans) for (Op& op : kv.second.ops) op.tuned = -2;
+    for (auto& kv : e->reid_plans) for (Op& op : kv.second.ops) op.tuned = -2;
     return VC_OK;
 }
 

@@ -256,7 +256,8 @@ static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const in
         for (int c = 0; c < num_classes; ++c) {
             std::vector<int>& g = by_class[c];
             if (g.empty()) continue;
-            VC_CHECK(tracker_ok(e->trackers, trackers[c]), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            const int ts = tracker_slot(e->trackers, trackers[c]);
+            VC_CHECK(ts >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle %d for class %d", trackers[c], c);
             std::vector<double> bx(g.size() * 4), cf(g.size());
             std::vector<int> rows(g.size());
             for (size_t i = 0; i < g.size(); ++i) {
@@ -264,8 +265,8 @@ static int enqueue_batch_tracking(vc_engine* e, vc_engine::Pending& pd, const in
                 cf[i] = d.conf[g[i]];
                 rows[i] = pd.row0[f] + g[i];
             }
-            FrameClassDets fc{c, trackers[c], {}};
-            prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[trackers[c]]->p, fc.dets);
+            FrameClassDets fc{c, ts, {}};
+            prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[ts]->p, fc.dets);
             frames[f].push_back(std::move(fc));
             g.clear();
         }
@@ -412,14 +413,15 @@ int vc_videotracker_run_features(vc_engine* e, const int* trackers, int num_clas
         for (int c = 0; c < num_classes; ++c) {                                        // modules/track.py:50-59
             std::vector<int>& g = by_class[c];
             if (g.empty()) continue;
-            VC_CHECK(tracker_ok(e->trackers, trackers[c]), VC_ERR_NOTFOUND, "bad tracker id %d for class %d", trackers[c], c);
+            const int ts = tracker_slot(e->trackers, trackers[c]);
+            VC_CHECK(ts >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle %d for class %d", trackers[c], c);
             std::vector<double> bx(g.size() * 4), cf(g.size());
             for (size_t k = 0; k < g.size(); ++k) {
                 memcpy(&bx[k * 4], rows7 + (size_t)g[k] * 7 + 1, 4 * sizeof(double));
                 cf[k] = rows7[(size_t)g[k] * 7 + 5];
             }
-            FrameClassDets fc{c, trackers[c], {}};
-            prepare_dets(bx.data(), cf.data(), g.data(), (int)g.size(), e->trackers[trackers[c]]->p, fc.dets);
+            FrameClassDets fc{c, ts, {}};
+            prepare_dets(bx.data(), cf.data(), g.data(), (int)g.size(), e->trackers[ts]->p, fc.dets);
             frames.back().push_back(std::move(fc));
             g.clear();
         }

@@ -81,6 +81,7 @@ int tracker_init_pool(vc_engine* e) {
     const size_t T = e->cfg.max_tracks, S = e->cfg.nn_budget_cap;
     VC_CHECK(T >= 1 && S >= 1, VC_ERR_ARG, "max_tracks and nn_budget_cap must be positive");
     e->max_trackers = e->cfg.max_trackers > 0 ? e->cfg.max_trackers : 256;
+    VC_CHECK(e->max_trackers <= 65535, VC_ERR_ARG, "max_trackers %d: a tracker handle addresses at most 65535 slots", e->max_trackers);
     e->list_cap = e->cfg.tracks_per_tracker > 0 ? e->cfg.tracks_per_tracker : 512;
     e->list_cap = (int)std::min<size_t>((size_t)e->list_cap, T);
     e->pool.max_tracks = (int)T; e->pool.budget_cap = (int)S;
@@ -445,10 +446,11 @@ int frame_track(vc_engine* e, const uint8_t* d_frame_base, int frame_index, int 
             cf[i] = conf[g[i]];
             rows[i] = g[i];
         }
-        VC_CHECK(tracker_ok(e->trackers, tracker_ids[j]), VC_ERR_NOTFOUND, "bad tracker id %d", tracker_ids[j]);
-        FrameClassDets fc{labels[j], tracker_ids[j], {}};
-        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[tracker_ids[j]]->p, fc.dets);
-        total_tracks += e->trackers[tracker_ids[j]]->known_tracks + (int)fc.dets.conf.size();
+        const int ts = tracker_slot(e->trackers, tracker_ids[j]);             // (handles, as the caller holds them)
+        VC_CHECK(ts >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle %d", tracker_ids[j]);
+        FrameClassDets fc{labels[j], ts, {}};
+        prepare_dets(bx.data(), cf.data(), rows.data(), (int)g.size(), e->trackers[ts]->p, fc.dets);
+        total_tracks += e->trackers[ts]->known_tracks + (int)fc.dets.conf.size();
         frames[0].push_back(std::move(fc));
     }
     const int cap = std::max(total_tracks, 16);
@@ -525,21 +527,24 @@ int vc_tracker_create(vc_engine* e, const vc_tracker_params* p, int* id) {
     VC_HIP(hipMemcpy(e->d_hdrs + slot, &h, sizeof(h), hipMemcpyHostToDevice));
     Tracker& t = *e->trackers[slot];
     t.p = *p; t.known_tracks = 0; t.pending_dets = 0; t.released = false;
-    *id = slot;
+    *id = slot | (t.gen << 16);
     return VC_OK;
 }
 
 // The reference builds a new VideoTracker (one DeepSort per class) for every video (modules/__init__.py:32-36) and drops the old one:
 // the drop-in's DeepSort gives its tracker back here, so that a process that walks a folder of videos does not run out of ids.
-int vc_tracker_destroy(vc_engine* e, int id) {
-    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
-    VC_TRY(vc_tracker_reset(e, id));     // waits for the batches in flight, returns the track slots to the pool
+int vc_tracker_destroy(vc_engine* e, int handle) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
+    VC_TRY(vc_tracker_reset(e, handle)); // waits for the batches in flight, returns the track slots to the pool
     e->trackers[id]->released = true;
+    e->trackers[id]->gen = (e->trackers[id]->gen + 1) & 0x7fff;      // handles of this incarnation are refused from now on
     return VC_OK;
 }
 
-int vc_tracker_reset(vc_engine* e, int id) {
-    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+int vc_tracker_reset(vc_engine* e, int handle) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -552,8 +557,9 @@ int vc_tracker_reset(vc_engine* e, int id) {
     return VC_OK;
 }
 
-int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf, const float* feat, int k) {
-    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+int vc_tracker_step(vc_engine* e, int handle, const double* tlwh, const double* conf, const float* feat, int k) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_CHECK(k == 0 || (tlwh && conf && feat), VC_ERR_ARG, "null argument");
     VC_CHECK(k >= 0 && k <= e->det_cap, VC_ERR_CAPACITY, "%d detections exceed capacity %d", k, e->det_cap);
     VC_HIP(hipSetDevice(e->cfg.device));
@@ -573,8 +579,9 @@ int vc_tracker_step(vc_engine* e, int id, const double* tlwh, const double* conf
     return track_collect(e, 3, buf.data(), cap, &m);
 }
 
-int vc_tracker_count(vc_engine* e, int id, int* n) {
-    VC_CHECK(e && n && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+int vc_tracker_count(vc_engine* e, int handle, int* n) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && n && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -583,9 +590,10 @@ int vc_tracker_count(vc_engine* e, int id, int* n) {
     return VC_OK;
 }
 
-int vc_tracker_state(vc_engine* e, int id, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
+int vc_tracker_state(vc_engine* e, int handle, int cap, int64_t* ids, int* state, int* hits, int* age, int* tsu, double* mean8,
                      double* cov64, int* gallery_count) {
-    VC_CHECK(e && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -639,8 +647,9 @@ struct SnapTrack { int64_t id; int32_t state, hits, age, tsu, gal_count, gal_hea
 const char kSnapMagic[8] = {'V', 'C', 'T', 'R', 'K', '0', '1', 0};
 }  // namespace
 
-int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* size) {
-    VC_CHECK(e && size && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+int vc_tracker_snapshot(vc_engine* e, int handle, void* buf, size_t cap, size_t* size) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && size && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
     HostTrackerState st;
@@ -674,8 +683,9 @@ int vc_tracker_snapshot(vc_engine* e, int id, void* buf, size_t cap, size_t* siz
     return VC_OK;
 }
 
-int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
-    VC_CHECK(e && buf && tracker_ok(e->trackers, id), VC_ERR_NOTFOUND, "bad tracker id");
+int vc_tracker_restore(vc_engine* e, int handle, const void* buf, size_t size) {
+    const int id = e ? tracker_slot(e->trackers, handle) : -1;
+    VC_CHECK(e && buf && id >= 0, VC_ERR_NOTFOUND, "bad or stale tracker handle");
     VC_CHECK(size >= sizeof(SnapHeader), VC_ERR_ARG, "snapshot truncated");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));
@@ -732,7 +742,7 @@ int vc_tracker_restore(vc_engine* e, int id, const void* buf, size_t size) {
 
 int vc_deepsort_update(vc_engine* e, int id, const uint8_t* bgr, int h, int w, const double* bbox_xyxy, const double* conf, int k,
                        int64_t* out_rows7, int cap_rows, int* out_m) {
-    VC_CHECK(e && bgr && out_m && tracker_ok(e->trackers, id), VC_ERR_ARG, "bad argument");
+    VC_CHECK(e && bgr && out_m && tracker_slot(e->trackers, id) >= 0, VC_ERR_ARG, "bad argument (null pointer, bad or stale tracker handle)");
     VC_CHECK(k >= 1 && bbox_xyxy && conf, VC_ERR_ARG, "DeepSort.update needs at least one box (the reference only calls it then)");
     VC_HIP(hipSetDevice(e->cfg.device));
     VC_TRY(async_wait_all(e));

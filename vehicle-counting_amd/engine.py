@@ -33,6 +33,7 @@ class Engine:
         self.cfg = cfg
         self.precision = precision
         self._h = C.c_void_p()
+        self._deferred_destroy = []          # tracker handles queued by finalisers (tracker_destroy_later)
         L.check(lib.vc_engine_create(C.byref(cfg), C.byref(self._h)))
         if yolo_sd is not None:
             self._upload(L.NET_YOLO, lambda n: (yolo_sd[n + ".weight"], yolo_sd[n + ".bias"]))
@@ -147,6 +148,8 @@ class Engine:
     # ---------------------------------------------------------------- tracker
     def tracker_create(self, max_dist=0.2, min_confidence=0.3, nms_max_overlap=1.0, max_iou_distance=0.7, max_age=70,
                        n_init=3, nn_budget=100):
+        while self._deferred_destroy:                      # handles queued by DeepSort.__del__
+            L.check(L.lib().vc_tracker_destroy(self._h, self._deferred_destroy.pop()))
         p = L.TrackerParams(max_dist, min_confidence, nms_max_overlap, max_iou_distance, max_age, n_init, nn_budget)
         tid = C.c_int()
         L.check(L.lib().vc_tracker_create(self._h, C.byref(p), C.byref(tid)))
@@ -155,6 +158,10 @@ class Engine:
     def tracker_destroy(self, tid):
         if self._h:
             L.check(L.lib().vc_tracker_destroy(self._h, tid))
+
+    def tracker_destroy_later(self, tid):
+        """From a finaliser: the handle is given back at the next tracker_create (vc_tracker_destroy waits for the batches in flight)."""
+        self._deferred_destroy.append(tid)
 
     def tracker_reset(self, tid):
         L.check(L.lib().vc_tracker_reset(self._h, tid))

@@ -20,15 +20,20 @@ class DeepSort:
                                                 max_iou_distance=max_iou_distance, max_age=max_age, n_init=n_init, nn_budget=nn_budget)
 
     def close(self):
-        """Gives the tracker (its tracks, galleries and its id) back to the engine.  The reference simply drops its DeepSort objects when
-        CountingPipeline builds the next video's VideoTracker (modules/__init__.py:32-36); here that is `__del__`, or an explicit close()."""
+        """Gives the tracker (its tracks, galleries and its slot) back to the engine; the handle is dead afterwards (the engine refuses it
+        even once the slot belongs to a later tracker).  The reference simply drops its DeepSort objects when CountingPipeline builds the
+        next video's VideoTracker (modules/__init__.py:32-36); the drop-in's pipeline closes its stages explicitly (pipeline._video)."""
         tid, self.tracker_id = self.tracker_id, None
         if tid is not None and getattr(self.engine, "_h", None):
             self.engine.tracker_destroy(tid)
 
     def __del__(self):
+        # A finaliser runs at arbitrary points (also inside another engine call): it must not wait for batches in flight the way
+        # vc_tracker_destroy does.  It only queues the handle; the engine gives queued handles back the next time a tracker is created.
         try:
-            self.close()
+            tid, self.tracker_id = self.tracker_id, None
+            if tid is not None and getattr(self.engine, "_h", None):
+                self.engine.tracker_destroy_later(tid)
         except Exception:          # interpreter shutdown, engine already destroyed
             pass
 
@@ -82,8 +87,11 @@ class VideoTracker:
     def close(self):
         for d in self.deepsort:
             d.close()
+        self.tracker_ids = None            # a closed VideoTracker drives nothing (its handles are dead in the engine as well)
 
     def run(self, image, boxes, labels, scores):
+        if self.tracker_ids is None:
+            raise RuntimeError("VideoTracker.run after close()")
         rows = self.engine.videotracker_run(self.tracker_ids, image, boxes, labels, scores)
         return {"tracks": [int(r[4]) for r in rows], "boxes": rows[:, :4].copy() if len(rows) else np.array([]),
                 "labels": [int(r[5]) for r in rows], "scores": []}
