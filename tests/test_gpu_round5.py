@@ -111,3 +111,27 @@ def test_halo_v2_equals_halo_kernel(shape, monkeypatch):
         monkeypatch.setenv("VC_CONV_CFG", str(cfg))
         out[cfg] = E.conv2d(x, w, b, stride=1, pad=1, act=act, res=res, res_mode=rm, precision="bf16")
     np.testing.assert_array_equal(out[30], out[55])
+
+
+def test_upsample_folded_into_its_consumer_gives_the_same_bits():
+    """nn.Upsample + Concat in front of C3.cv1 | cv2 (YOLOv5 layers 11-13, 15-17) read by conv_igemm_kernel<..., UP> straight from the
+    half-size map: layers 13 / 17 / 20 / 23 and the detections equal the pass with upsample2x_kernel, and the concat layers a debug read
+    asks for are produced on demand."""
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.5)
+    for (B, H, W) in ((3, 352, 640), (2, 640, 640), (1, 333, 500)):
+        frames = synth_frames(B, H, W, n_obj=6, seed=7)
+        imgs = [f[:, :, ::-1] for f in frames]
+        eng = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W))
+        out = {}
+        for on in (1, 0, 1):
+            eng.set_option("fuse_upsample", on)
+            dets = eng.detect(imgs)
+            layers = {l: eng.debug_layer(l, batch=B) for l in (13, 17, 20, 23, 12, 16)}
+            if on in out:
+                continue
+            out[on] = (dets, layers)
+        for a, b in zip(out[1][0], out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        for l in out[1][1]:
+            np.testing.assert_array_equal(out[1][1][l], out[0][1][l])
+        eng.close()

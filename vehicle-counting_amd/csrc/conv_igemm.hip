@@ -32,7 +32,11 @@ namespace vc {
 // hardware answers with zeros (verified by the padded test cases); the per-row validity of all kh*kw taps is one 64-bit
 // mask computed once, the tap offset advances incrementally, every LDS address is loop invariant: the K loop is
 // {KC/4 x (PT+CT ds_read_b128, PT*CT MFMA)} + (XI+WI) DMA issues + one barrier.
-template <int BP, int BC, int WP, int WC, int KC, int NS, int PR>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
+// UP: the first p.up_C input channels of a pointwise conv come from a tensor of half the height and width, nearest-upsampled on the fly
+// (nn.Upsample(None, 2, 'nearest') + Concat in front of C3.cv1 | cv2, YOLOv5 layers 11-13 and 15-17): the staged row of output pixel
+// (b, y, x) reads pixel (b, y / 2, x / 2) of p.in_up for K tiles below up_C and the concat buffer for the rest, so the upsampled map
+// is neither written nor read.  Same values in the same K order: bit-identical to upsample2x_kernel + this kernel.
+template <int BP, int BC, int WP, int WC, int KC, int NS, int PR, bool UP = false>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
 __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p_arg) {
     ConvP p = p_arg;
     if (p_arg.m_dev) {                        // device-side problem size (uniform): fewer pixels, fewer tiles
@@ -103,6 +107,9 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     // per staged pixel row: byte offset of its (iy0, ix0) corner and the validity mask of the kh*kw taps; quotients come from
     // an exact float reciprocal with a +-1 fix-up, the mask from row/column ranges (no run-time integer divisions)
     uint32_t xoff[XI], xoffl[XI], woff[WI];
+    uint32_t xoffu[UP ? XI : 1];              // UP: this lane's chunk in the half-size source
+    const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(UP ? p.in_up : p.in), 0, UP ? (int)((size_t)p.B * (p.H / 2) * (p.W / 2) * p.up_cs * ES) : 0, 0x00020000);
     unsigned long long xmask[XI];
     int kc_c = 0, kc_t = 0, kc_s = 0, u_tap = 0, u_s = 0, u_c = 0;
     uint32_t kc_off = 0, u_tapoff = 0;
@@ -118,6 +125,17 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             if (pointwise) {                  /* 1x1 / stride 1: output pixel m reads input pixel m, one tap */            \
                 xoff[i] = (uint32_t)((mm * p.in_cs + p.in_co) * ES);                                                      \
                 xmask[i] = ok ? 1ull : 0ull;                                                                              \
+                if constexpr (UP) {                                                                                       \
+                    int b = (int)((float)mm * inv_howo);                                                                  \
+                    b -= (b * HoWo > mm) ? 1 : 0;                                                                         \
+                    b += ((b + 1) * HoWo <= mm) ? 1 : 0;                                                                  \
+                    const int rem = mm - b * HoWo;                                                                        \
+                    int oy = (int)((float)rem * inv_wo);                                                                  \
+                    oy -= (oy * p.Wo > rem) ? 1 : 0;                                                                      \
+                    oy += ((oy + 1) * p.Wo <= rem) ? 1 : 0;                                                               \
+                    const int ox = rem - oy * p.Wo;                                                                       \
+                    xoffu[i] = (uint32_t)((((b * (p.H / 2) + (oy >> 1)) * (p.W / 2) + (ox >> 1)) * p.up_cs + p.up_co + kc0 * CH) * ES); \
+                }                                                                                                         \
             } else {                                                                                                      \
                 int b = (int)((float)mm * inv_howo);    /* mm < 2^24: the float product is within 1 of the quotient */     \
                 b -= (b * HoWo > mm) ? 1 : 0;                                                                             \
@@ -163,9 +181,10 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     if ((p.ablate == 1 || p.ablate == 3) && s_issued >= NS) {                                                                               \
     } else if (ut) {                                                                                                            \
         const uint32_t so = u_tapoff + (uint32_t)(u_c * ES);                                                             \
+        const bool from_up = UP && u_c < p.up_C;      /* (uniform) this K tile lies in the upsampled half of the concat */   \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                 \
-            const uint32_t o = ((xmask[i] >> u_tap) & 1ull) ? xoffl[i] + so : OOB;                                       \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)&lds[buf][(PASS * i + uwave * RPI) * KC], 16, (int)o, 0, 0, 0); \
+            const uint32_t o = ((xmask[i] >> u_tap) & 1ull) ? (from_up ? xoffu[UP ? i : 0] : xoffl[i]) + so : OOB;        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(from_up ? usrd : xsrd, (lds_ptr_t)&lds[buf][(PASS * i + uwave * RPI) * KC], 16, (int)o, 0, 0, 0); \
         }                                                                                                                \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) {                                                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_ptr_t)&lds[buf][BP * KC + (PASS * i + uwave * RPI) * KC], 16,     \
@@ -1054,6 +1073,7 @@ static int launch_one(ConvP p, hipStream_t s) {
     // detector, the tracker walk), which then wait for a conv launch to end: 64 slots are left free (round 2, 128-frame steps:
     // 0 / 32 / 64 / 96 / 128 free slots = 14.9 / 15.1 / 15.6 / 15.6 / 15.4 k frames/s; 256 free slots cost 9 % of conv time).
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
+    if (p.in_up && p.prec != PREC_BF16) return VC_ERR_ARG;        // (conv_check refuses it with a message)
     if (p.prec == PREC_F32) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
@@ -1067,6 +1087,18 @@ static int launch_one(ConvP p, hipStream_t s) {
             launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_FP8>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
         } else {
             return VC_ERR_ARG;                                       // quietly: the autotuner skips it (fp8 runs on the 128-byte-row tiles only)
+        }
+    } else if (p.in_up) {
+        // the upsample fold-in is instantiated for the tiles the wide pointwise layers use (256 x 256 on 16 waves, 128 / 256 x 128 on 2 x 2)
+        constexpr bool UP_OK = (BP == 256 && BC == 256 && KC == 4 && NS <= 4) ||
+                               (WP == 2 && WC == 2 && BC == 128 && (BP == 128 || BP == 256) && (KC == 8 || (KC == 4 && NS == 2 && BP == 128)));
+        if constexpr (UP_OK) {
+            static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, true>, WP * WC * 64);
+            const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
+            const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+            launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, true>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+        } else {
+            return VC_ERR_ARG;                                       // quietly: the autotuner skips it
         }
     } else {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, WP * WC * 64);
@@ -1141,7 +1173,7 @@ static int launch_s2halo(ConvP p, hipStream_t s) {
 
 static bool direct1x1_applicable(const ConvP& p, int ct, int ks) {
     if (p.prec != PREC_BF16 || p.kh != 1 || p.kw != 1 || p.sh != 1 || p.sw != 1 || p.ph != 0 || p.pw != 0) return false;
-    if (p.Cin != ks * 32 || p.K != p.Cin || p.Ho != p.H || p.Wo != p.W || p.in_cs % 8 != 0 || p.in_co % 8 != 0) return false;
+    if (p.Cin != ks * 32 || p.K != p.Cin || p.Ho != p.H || p.Wo != p.W || p.in_cs % 8 != 0 || p.in_co % 8 != 0 || p.in_up) return false;
     // the 16-byte-store epilogue only (conv_epilogue_bf16's preconditions), SiLU or no activation, no residual
     if (p.out_f32 || p.res_mode != RES_NONE || (p.act != ACT_SILU && p.act != ACT_NONE) || p.out_cs % 8 != 0 || p.out_co % 8 != 0) return false;
     if (p.split != 0 && (p.split % 8 != 0 || p.out2_cs % 8 != 0 || p.out2_co % 8 != 0)) return false;
@@ -1226,6 +1258,9 @@ int conv_check(const ConvP& p) {
     VC_CHECK(p.res_mode == RES_NONE || (p.res_cs % 4 == 0 && p.res_co % 4 == 0), VC_ERR_ARG, "conv: residual alignment");
     VC_CHECK(p.Kp % conv_k_tile(p.prec) == 0 && p.Kp >= p.K, VC_ERR_ARG, "conv: bad K padding %d/%d", p.K, p.Kp);
     VC_CHECK(p.M > 0 && p.Cout > 0, VC_ERR_ARG, "conv: empty problem");
+    VC_CHECK(!p.in_up || (p.prec == PREC_BF16 && p.kh == 1 && p.kw == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.H % 2 == 0 && p.W % 2 == 0 &&
+                          p.up_C > 0 && p.up_C < p.Cin && p.up_C % 64 == 0 && p.Cin % 64 == 0 && p.up_cs % 8 == 0 && p.up_co % 8 == 0 && !p.m_dev), VC_ERR_ARG,
+             "conv: the upsample fold-in needs a bf16 pointwise conv on an even-sized map with 64-channel-aligned halves");
     VC_CHECK((size_t)p.B * p.H * p.W * p.in_cs * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: input tensor exceeds the 2 GiB buffer descriptor");
     VC_CHECK((size_t)((p.Cout + 127) / 128 * 128) * p.Kp * elem_size(p.prec) < (1ull << 31), VC_ERR_CAPACITY, "conv: weights exceed 2 GiB");
     VC_CHECK(p.kh * p.kw <= 40, VC_ERR_ARG, "conv: at most 40 taps (validity mask is 64 bits incl. K padding)");

@@ -441,7 +441,8 @@ static std::string tune_key(const ConvP& c) {
     int bucket = 1;
     while (bucket < c.M) bucket <<= 1;
     char k[160];
-    snprintf(k, sizeof(k), "p%d_ci%d_co%d_k%dx%d_s%d_h%d_w%d_K%d_m%d_sp%d", c.prec, c.Cin, c.Cout, c.kh, c.kw, c.sh, c.H, c.W, c.K, bucket, c.split);
+    snprintf(k, sizeof(k), "p%d_ci%d_co%d_k%dx%d_s%d_h%d_w%d_K%d_m%d_sp%d%s", c.prec, c.Cin, c.Cout, c.kh, c.kw, c.sh, c.H, c.W, c.K, bucket, c.split,
+             c.in_up ? "_up" : "");      // (the upsample fold-in runs on a subset of the tile configurations)
     return k;
 }
 
@@ -540,6 +541,7 @@ static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStre
     // of them waits for everything the main stream has been given so far, the caller joins the head stream before it reads their results
     const bool side_ok = s_main == e->dstream && e->hstream && e->opt.head_side && !e->profiling;
     bool prev_side = false;
+    const Op* pending_up = nullptr;          // an UPSAMPLE op whose consumer (the next op) reads the half-size map itself
     for (size_t oi = 0; oi < ops.size(); ++oi) {
         Op& op = ops[oi];
         const bool on_side = side_ok && op.side;
@@ -554,10 +556,16 @@ static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStre
             case Op::CONV: {
                 const double es = elem_size(op.conv.prec);
                 const double fl = op.flops_override >= 0 ? op.flops_override : 2.0 * op.conv.M * (double)(op.cout_logical ? op.cout_logical : op.conv.Cout) * op.C;
-                const double by = op.bytes_override >= 0 ? op.bytes_override
-                                                         : ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
-                                                               (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
+                double by = op.bytes_override >= 0 ? op.bytes_override
+                                                   : ((double)op.conv.B * op.conv.H * op.conv.W * op.conv.Cin + (double)op.conv.Cout * op.conv.K) * es +
+                                                         (double)op.conv.M * op.conv.Cout * (op.conv.out_f32 ? 4 : es);
+                if (pending_up) by -= 0.75 * (double)op.conv.M * pending_up->a.C * es;   // (folded upsample: three quarters of that half of the input are never read)
                 ConvP cp = op.conv;
+                if (pending_up) {                                             // Upsample + Concat folded into this pointwise conv (conv_igemm_kernel<..., UP>)
+                    const View& u = pending_up->a;
+                    cp.in_up = u.ptr; cp.up_C = u.C; cp.up_cs = u.cs; cp.up_co = u.co;
+                    pending_up = nullptr;
+                }
                 double fl_exec = -1;                                          // executed FLOPs when they differ from `fl` (device-side row count)
                 static const bool stem_direct_on = !(getenv("VC_STEM_DIRECT") && atoi(getenv("VC_STEM_DIRECT")) == 0);
                 static const bool reid_stem_on = !(getenv("VC_REID_STEM_FUSED") && atoi(getenv("VC_REID_STEM_FUSED")) == 0);
@@ -712,7 +720,19 @@ static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStre
                 break;
             }
             case Op::SPPF: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, s)); break; }
-            case Op::UPSAMPLE: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_upsample2x(op.a, op.b, e->prec, s)); break; }
+            case Op::UPSAMPLE: {
+                // bf16: when the consumer is the pointwise conv over [upsampled | skip] (C3.cv1 | cv2 of layers 13 / 17) it reads the half-size
+                // map itself; the slice of the concat buffer stays unwritten (vc_detect_debug_layer produces it on demand)
+                const Op* nx = oi + 1 < ops.size() ? &ops[oi + 1] : nullptr;
+                const bool fold = e->opt.fuse_upsample && e->prec == PREC_BF16 && nx && nx->kind == Op::CONV && nx->conv.prec == PREC_BF16 && nx->conv.kh == 1 &&
+                                  nx->conv.kw == 1 && nx->conv.sh == 1 && nx->conv.ph == 0 && !nx->conv.m_dev && nx->conv.in == op.b.ptr && nx->conv.in_co == op.b.co &&
+                                  nx->conv.in_cs == op.b.cs && nx->conv.H == 2 * op.a.H && nx->conv.W == 2 * op.a.W && op.a.C % 64 == 0 && nx->conv.Cin % 64 == 0 &&
+                                  op.a.C < nx->conv.Cin && op.a.cs % 8 == 0 && op.a.co % 8 == 0;
+                if (fold) { pending_up = &op; e->up_folded.push_back({op.a, op.b}); break; }
+                ProfScope ps(e, aux_cat, 0, 0, s);
+                VC_TRY(launch_upsample2x(op.a, op.b, e->prec, s));
+                break;
+            }
             case Op::MAXPOOL: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_maxpool3s2(op.a, op.b, e->aux_prec, s)); break; }   // ReID only
             case Op::TO_FP8: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_bf16_to_fp8(op.a, op.b, 1.0f / e->act_scale, s)); break; }
             case Op::HEAD_COMPACT: {
@@ -765,6 +785,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     }
     std::vector<Op>& ops = plan.ops;
     e->l0_stale = false;
+    e->up_folded.clear();
     if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
         e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
         VC_HIP(hipMemsetAsync(e->d_zero, 0, e->zero_bytes, ds));
@@ -1006,7 +1027,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
-        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1);
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1); e->opt.fuse_upsample = env_int("VC_FUSE_UPSAMPLE", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -1195,6 +1216,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "sparse_head") e->opt.sparse_head = value;
     else if (n == "reid_block_fused") e->opt.reid_block_fused = value;
     else if (n == "head_side") e->opt.head_side = value;
+    else if (n == "fuse_upsample") e->opt.fuse_upsample = value;
     else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
@@ -1327,6 +1349,11 @@ int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int d
         }
         View v = mkview(e->ybuf["in"], e->last_B, e->last_nh, e->last_nw, 3, 0);
         return read_view_f32(e, v, out, cap, dims);
+    }
+    if ((layer == 11 || layer == 12 || layer == 15 || layer == 16) && !e->up_folded.empty()) {   // the last pass folded the upsampling into its consumer
+        for (const auto& ab : e->up_folded) VC_TRY(launch_upsample2x(ab.first, ab.second, e->prec, e->dstream));
+        VC_HIP(hipStreamSynchronize(e->dstream));
+        e->up_folded.clear();
     }
     VC_CHECK(!(layer == 0 && e->l0_stale), VC_ERR_STATE,
              "layer 0 was not written by the last pass (front_fused_kernel keeps it in LDS); vc_engine_set_option(e, \"front_fused\", 0) and run again");

@@ -164,6 +164,10 @@ struct ConvP {
     const int* m_dev;    // optional: the number of valid output pixels lives on the DEVICE (a compacted batch whose size the host does not
                          // know, e.g. the sparse Detect head): the kernel processes min(M, *m_dev) pixels; M bounds the launch.  Only the
                          // implicit-GEMM family (conv_igemm_kernel) honours it
+    // optional (bf16 pointwise convs, conv_igemm_kernel<..., UP>): input channels [0, up_C) are the nearest-neighbour 2 x upsampling of this
+    // [B][H/2][W/2] tensor (channel stride up_cs, offset up_co) instead of channels [in_co, in_co + up_C) of `in` (Upsample + Concat folded in)
+    const void* in_up;
+    int up_C, up_cs, up_co;
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
     int s2_th, s2_tw;    // set by the launcher of conv3x3s2_halo_kernel: its output tile rectangle (rows x columns)
     int slots;           // tests only: > 0 forces the persistent grid to this many workgroups (long tile walks); set by vc_conv2d_host from
