@@ -374,7 +374,7 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
         "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": max(hbm_frac, mfma_frac), "traffic": traffic,
         "mfma_frac": mfma_frac, "mfma_tflops": mfma_tflops, "mfma_peak_tflops": peak_tflops, "hbm_frac": hbm_frac, "hbm_gbs": hbm_gbs,
         "time_base": "wall clock of the timed region: algorithmic conv work per step / ms_per_step",
-        "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv3x3s2_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / front_fused_kernel<*> / c3_fused_kernel / bneck_fused_kernel / reid_block_fused_kernel / reid_stem_pool_kernel (all detector + ReID conv launches of a step)",
+        "kernel": "vc::conv_igemm_kernel<*> / conv3x3_halo_kernel<*> / conv3x3_halo_v2_kernel<*> / conv3x3s2_halo_kernel<*> / conv1x1_direct_kernel<*> / stem_direct_kernel<*> / front_fused_kernel<*> / c3_fused_kernel / bneck_fused_kernel / reid_block_fused_kernel / reid_stem_pool_kernel (all detector + ReID conv launches of a step)",
         "launches_per_step": conv["launches"] / 2.0,
         "algorithmic_gflop_per_step": flops_step / 1e9, "algorithmic_bytes_per_launch": conv_timed["bytes"] / max(conv_timed["launches"], 1),
         "algorithmic_note": "EXECUTED work of the launches: the sparse Detect head counts the gathered rows it computes (row counts read back from the device); the dense head it replaces is in algorithmic_dense_*, not in frac",
@@ -534,7 +534,7 @@ def main():
     # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
     # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if args.workload == "s640-bf16" and os.path.exists(tp):
             with open(tp) as f:

@@ -9,7 +9,7 @@ CLOCK_GHZ = 2.4          # peak engine clock (MI355X_MICROARCH.md); the sustaine
 busy, n = {}, {}
 for l in open(sys.argv[1]):
     m = re.match(r"(.*) (SQ_\S+) (\S+) n= (\d+)$", l.strip())        # (names are cut at 70 characters by pmc_summary.py: they need not end with ")")
-    if m and m.group(2) == "SQ_VALU_MFMA_BUSY_CYCLES" and any(t in m.group(1) for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel")):
+    if m and m.group(2) == "SQ_VALU_MFMA_BUSY_CYCLES" and any(t in m.group(1) for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_halo_v2_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel")):
         busy[m.group(1)] = float(m.group(3)); n[m.group(1)] = int(m.group(4))
 dur = {}
 for l in open(sys.argv[2]):

@@ -18,7 +18,7 @@ f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZ
 out = {"unit": "bytes per launch", "fetch_correction": 2.0, "kernels": {}}
 tot_b = tot_n = 0
 for k in f:
-    if not any(t in k for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel")):
+    if not any(t in k for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_halo_v2_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel")):
         continue
     fb = f[k][0] * 1024 * 2.0
     wb = w.get(k, (0, 1))[0] * 1024

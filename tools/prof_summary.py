@@ -16,10 +16,10 @@ def main(db, cmd):
     print("|---|---|---|---|---|---|---|")
     for name, n, tot, avg, mn, mx in rows:
         print(f"| `{name}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.1f} |")
-    conv = [r for r in rows if any(t in r[0] for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel"))]
+    conv = [r for r in rows if any(t in r[0] for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_halo_v2_kernel", "conv3x3s2_halo_kernel", "conv1x1_direct_kernel", "stem_direct_kernel", "front_fused_kernel", "c3_fused_kernel", "bneck_fused_kernel", "reid_block_fused_kernel", "reid_stem_pool_kernel"))]
     if conv:
         n, tot = sum(r[1] for r in conv), sum(r[2] for r in conv)
-        print(f"\nall conv kernels (`conv_igemm_kernel<*>`, `conv3x3_halo_kernel<*>`, `conv3x3s2_halo_kernel<*>`, `conv1x1_direct_kernel<*>`, `stem_direct_kernel<*>`, `front_fused_kernel<*>`, `c3_fused_kernel`, `bneck_fused_kernel`, `reid_block_fused_kernel`, `reid_stem_pool_kernel`): {n} launches, {tot / 1e6:.3f} ms, average {tot / n / 1e3:.2f} us per launch")
+        print(f"\nall conv kernels (`conv_igemm_kernel<*>`, `conv3x3_halo_kernel<*>`, `conv3x3_halo_v2_kernel<*>`, `conv3x3s2_halo_kernel<*>`, `conv1x1_direct_kernel<*>`, `stem_direct_kernel<*>`, `front_fused_kernel<*>`, `c3_fused_kernel`, `bneck_fused_kernel`, `reid_block_fused_kernel`, `reid_stem_pool_kernel`): {n} launches, {tot / 1e6:.3f} ms, average {tot / n / 1e3:.2f} us per launch")
 
 
 if __name__ == "__main__":
