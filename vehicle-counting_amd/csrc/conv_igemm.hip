@@ -1116,6 +1116,7 @@ static int conv_heuristic(const ConvP& p) {
         const long t = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
         return t >= 512 ? 5 : 6;
     }
+    if (p.in_up) return 2;                     // the upsample fold-in is instantiated for a subset of the tiles (launch_one): 128 x 128 is one of them
     // narrow layers get tall pixel tiles; late (small-M) layers get small tiles so the grid still covers 256 CUs
     if (p.Cout <= 32) return 0;
     if (p.Cout <= 64) return 1;
