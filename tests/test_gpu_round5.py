@@ -135,3 +135,32 @@ def test_upsample_folded_into_its_consumer_gives_the_same_bits():
         for l in out[1][1]:
             np.testing.assert_array_equal(out[1][1][l], out[0][1][l])
         eng.close()
+
+
+def test_halo_v2_random_geometries(monkeypatch):
+    """Seeded sweep over what a caller can vary: map sizes down to 3 x 4 and up to 64 wide (tiles of one row up to tiles that hold several
+    images), ragged last tiles, 2 - 6 channel slices, ragged channel tails, every activation / residual mode -- conv3x3_halo_v2_kernel against
+    conv3x3_halo_kernel bit for bit wherever the launcher accepts the shape (it must accept the detector's and the ReID net's)."""
+    rng = np.random.default_rng(20250929)
+    ran = 0
+    for case in range(40):
+        W = int(rng.choice([4, 5, 7, 13, 16, 20, 25, 31, 40, 48, 64]))
+        H = int(rng.integers(3, 41))
+        B = int(rng.integers(1, 7))
+        Ci = int(rng.choice([64, 128, 192, 256, 384]))
+        Co = int(rng.choice([8, 40, 64, 128, 136, 256]))
+        act, rm = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        rows = min(256 // W, 320 // W - 2, B * H)
+        if rows < 1 or rows * W < 160:                              # conv_halo_v2.hip::v2_applicable
+            continue
+        x = rng.standard_normal((B, H, W, Ci), dtype=np.float32)
+        w = (rng.standard_normal((Co, Ci, 3, 3), dtype=np.float32) / np.sqrt(Ci * 9)).astype(np.float32)
+        b = rng.standard_normal(Co, dtype=np.float32) * 0.1
+        res = rng.standard_normal((B, H, W, Co), dtype=np.float32) if rm else None
+        out = {}
+        for cfg in (30, 55):
+            monkeypatch.setenv("VC_CONV_CFG", str(cfg))
+            out[cfg] = E.conv2d(x, w, b, stride=1, pad=1, act=act, res=res, res_mode=rm, precision="bf16")
+        np.testing.assert_array_equal(out[30], out[55], err_msg=f"case {case}: B {B} H {H} W {W} Ci {Ci} Co {Co} act {act} res {rm}")
+        ran += 1
+    assert ran >= 15
