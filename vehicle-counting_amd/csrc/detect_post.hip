@@ -123,14 +123,17 @@ __global__ __launch_bounds__(256) void head_compact_kernel(const uint16_t* __res
     }
 }
 
-// decode_kernel's arithmetic on the gathered logits: one thread per (gathered pixel, anchor)
+// decode_kernel's arithmetic on the gathered logits: SIXTEEN lanes per (gathered pixel, anchor) -- the class scores are what costs (80 precise
+// sigmoids per anchor, one thread per anchor walked them one after the other: 29 us per pass on the detector queue's tail); lane s takes classes
+// s, s + 16, ... in ascending order, the group reduces (score, class) with "larger score, then smaller class" = the serial loop's strict `>`.
 __global__ __launch_bounds__(256) void decode_sparse_kernel(const DecodeLevel l0, const DecodeLevel l1, const DecodeLevel l2, const int* __restrict__ counts,
                                                             const int* __restrict__ list0, const int* __restrict__ list1, const int* __restrict__ list2,
                                                             int cap0, int cap1, int cap2, int nc, float conf_thres, int max_cand, DetectPostBuffers pb) {
     const int no = nc + 5;
     const int n0 = min(counts[0], cap0), n1 = min(counts[1], cap1), n2 = min(counts[2], cap2);
     const long total = 3l * ((long)n0 + n1 + n2);
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 15;
+    for (long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; g < total; g += ((long)gridDim.x * blockDim.x) >> 4) {
         long e = g / 3;
         const int a = (int)(g - e * 3);
         const int level = e < n0 ? 0 : (e < (long)n0 + n1 ? 1 : 2);
@@ -142,20 +145,26 @@ __global__ __launch_bounds__(256) void decode_sparse_kernel(const DecodeLevel l0
         const size_t qoff = (size_t)s * lv.cs + a * no;
         auto ld = [&](int c) -> float { return __uint_as_float((uint32_t)((const uint16_t*)lv.logits)[qoff + c] << 16); };
         const float obj = sigmoidf_(ld(4));
-        if (!(obj > conf_thres)) continue;
+        if (!(obj > conf_thres)) continue;                   // (the same for the sixteen lanes of a group)
+        float best = -1.0f;
+        int bj = 0;
+        for (int c = sub; c < nc; c += 16) {
+            const float v = sigmoidf_(ld(5 + c)) * obj;
+            if (v > best) { best = v; bj = c; }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            const float ob = __shfl_xor(best, d);
+            const int oj = __shfl_xor(bj, d);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (sub != 0 || !(best > conf_thres)) continue;
         const float sx = sigmoidf_(ld(0)), sy = sigmoidf_(ld(1)), sw = sigmoidf_(ld(2)), sh = sigmoidf_(ld(3));
         const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
         const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
         const float tw = sw * 2.0f, th = sh * 2.0f;
         const float w = tw * tw * lv.anchor_w[a];
         const float h = th * th * lv.anchor_h[a];
-        float best = -1.0f;
-        int bj = 0;
-        for (int c = 0; c < nc; ++c) {
-            const float v = sigmoidf_(ld(5 + c)) * obj;
-            if (v > best) { best = v; bj = c; }
-        }
-        if (!(best > conf_thres)) continue;
         const int pos = atomicAdd(pb.cand_count + b, 1);
         if (pos >= max_cand) { pb.overflow[b] = 1; continue; }
         const size_t o = (size_t)b * max_cand + pos;
