@@ -164,3 +164,26 @@ def test_halo_v2_random_geometries(monkeypatch):
         np.testing.assert_array_equal(out[30], out[55], err_msg=f"case {case}: B {B} H {H} W {W} Ci {Ci} Co {Co} act {act} res {rm}")
         ran += 1
     assert ran >= 15
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32", "fp8"])
+def test_sppf_register_form_gives_the_same_bits(precision):
+    """SPPF's three chained MaxPool2d(5, 1, 2) (ultralytics/yolov5 v6.0 models/common.py::SPPF, layer 9 of the detector
+    /root/reference/networks/yolo.py:58 loads) as row / column window maxima in registers (sppf_pool_sep_kernel) against the LDS-plane kernels
+    it replaced: layer 9 (SPPF.cv2 reads all four slices of the concat) and the detections are the same bits, on square, letterboxed (12 x 20,
+    14 x 20) and 1280^2 (40 x 40) planes."""
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.5)
+    for (B, H, W, size) in ((3, 640, 640, 640), (2, 360, 640, 640), (1, 333, 500, 640), (1, 1280, 1280, 1280), (1, 720, 1280, 1280)):
+        frames = synth_frames(B, H, W, n_obj=6, seed=11)
+        imgs = [f[:, :, ::-1] for f in frames]
+        eng = E.Engine(sd, None, precision=precision, num_classes=NC, img_size=size, max_batch=B, max_frame_hw=(H, W))
+        out = {}
+        for on in (1, 0):
+            eng.set_option("sppf_sep", on)
+            dets = eng.detect(imgs)
+            out[on] = (dets, eng.debug_layer(9, batch=B))
+        for a, b in zip(out[1][0], out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+        assert np.isfinite(out[1][1]).all() and np.abs(out[1][1]).max() > 0
+        eng.close()

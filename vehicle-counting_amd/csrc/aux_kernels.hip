@@ -334,6 +334,94 @@ __global__ __launch_bounds__(1024) void sppf_pool_wide_kernel(View cat, int C) {
     }
 }
 
+// Register form (the one that runs at 20x20 and 40x40 since round 5).  pool5 o pool5 = pool9 and pool5 o pool5 o pool5 = pool13 of x, and a square
+// window maximum is a column maximum of row maxima, so the three outputs are col_r(row_r(x)) for r = 2, 4, 6.  A thread owns ONE ROW of one
+// 4-byte word of the channel slice in registers (W global loads in flight at once), builds the row maxima of all three radii from shared
+// partial windows (pairs -> quads -> octets: 7 packed max per position for the three radii together), hands them to the thread that owns the
+// COLUMN through one LDS plane (one radius at a time: 27 KB per workgroup at 20x20, every workgroup of a 128-frame batch resident at once), and
+// that thread finishes the column maxima in registers and stores.  Per position: 3 LDS writes + 3 LDS reads and 5 workgroup barriers per launch,
+// against 33 LDS accesses per position and 7 barriers in sppf_pool_wide_kernel: 65 -> ~25 us per 128 frames at 20x20 x 256 channels
+// (26 MB in, 79 MB out: ~17 us at the chip's copy rate).  Maxima select, so the result is that of the other forms bit for bit.
+template <int ET, int RAD, int MAXD>
+__device__ __forceinline__ void window_max(const uint32_t (&p)[MAXD + 12], uint32_t (&out)[MAXD]) {     // p[i] = position i - 6; out[x] = max p[x+6-RAD .. x+6+RAD]
+    uint32_t a[MAXD + 11], b[MAXD + 9];
+#pragma unroll
+    for (int i = 0; i < MAXD + 11; ++i) a[i] = word_max<ET>(p[i], p[i + 1]);
+#pragma unroll
+    for (int i = 0; i < MAXD + 9; ++i) b[i] = word_max<ET>(a[i], a[i + 2]);                               // p[i .. i+3]
+    if (RAD == 2) {
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x) out[x] = word_max<ET>(b[x + 4], p[x + 8]);
+    } else {
+        uint32_t c[MAXD + 5];
+#pragma unroll
+        for (int i = 0; i < MAXD + 5; ++i) c[i] = word_max<ET>(b[i], b[i + 4]);                           // p[i .. i+7]
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x)
+            out[x] = RAD == 4 ? word_max<ET>(c[x + 2], p[x + 10]) : word_max<ET>(word_max<ET>(c[x], b[x + 8]), p[x + 12]);
+    }
+}
+
+template <int ET, int MAXD>
+__global__ __launch_bounds__(MAXD > 20 ? 320 : 640) void sppf_pool_sep_kernel(View cat, int C, int WS, int rstride) {
+    constexpr int ES = ET == 0 ? 4 : (ET == 1 ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) uint32_t smw[];       // [H][rstride]: position x, word w of row y at y * rstride + x * WS + w
+    const int cw = WS * 4 / ES, groups = C / cw;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * cw;
+    const int H = cat.H, W = cat.W;
+    const int w = threadIdx.x % WS, q = threadIdx.x / WS;                // q: this thread's row in the row pass, its column in the column passes
+    char* base = (char*)cat.ptr + (((size_t)b * H * W) * cat.cs + cat.co + c0) * ES + w * 4;
+    const size_t pstride = (size_t)cat.cs * ES;
+    uint32_t R[3][MAXD];
+    if (q < H) {
+        uint32_t p[MAXD + 12];
+#pragma unroll
+        for (int i = 0; i < MAXD + 12; ++i) p[i] = 0u;                   // key 0 sits below every value's key: the padding of MaxPool2d
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x)
+            if (x < W) p[x + 6] = *(const uint32_t*)(base + (size_t)(q * W + x) * pstride);
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x) p[x + 6] = x < W ? word_key<ET>(p[x + 6]) : 0u;
+        // the three radii share their partial windows
+        uint32_t a[MAXD + 11], bq[MAXD + 9], c[MAXD + 5];
+#pragma unroll
+        for (int i = 0; i < MAXD + 11; ++i) a[i] = word_max<ET>(p[i], p[i + 1]);
+#pragma unroll
+        for (int i = 0; i < MAXD + 9; ++i) bq[i] = word_max<ET>(a[i], a[i + 2]);
+#pragma unroll
+        for (int i = 0; i < MAXD + 5; ++i) c[i] = word_max<ET>(bq[i], bq[i + 4]);
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x) {
+            R[0][x] = word_max<ET>(bq[x + 4], p[x + 8]);
+            R[1][x] = word_max<ET>(c[x + 2], p[x + 10]);
+            R[2][x] = word_max<ET>(word_max<ET>(c[x], bq[x + 8]), p[x + 12]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k) __syncthreads();                                          // the column passes of the radius before have read the plane
+        if (q < H) {
+#pragma unroll
+            for (int x = 0; x < MAXD; ++x)
+                if (x < W) smw[q * rstride + x * WS + w] = R[k][x];
+        }
+        __syncthreads();
+        if (q < W) {
+            uint32_t p[MAXD + 12], o[MAXD];
+#pragma unroll
+            for (int i = 0; i < MAXD + 12; ++i) p[i] = 0u;
+#pragma unroll
+            for (int y = 0; y < MAXD; ++y)
+                if (y < H) p[y + 6] = smw[y * rstride + q * WS + w];
+            if (k == 0) window_max<ET, 2, MAXD>(p, o); else if (k == 1) window_max<ET, 4, MAXD>(p, o); else window_max<ET, 6, MAXD>(p, o);
+            char* ob = base + (size_t)(k + 1) * C * ES + (size_t)q * pstride;
+#pragma unroll
+            for (int y = 0; y < MAXD; ++y)
+                if (y < H) *(uint32_t*)(ob + (size_t)y * W * pstride) = word_unkey<ET>(o[y]);
+        }
+    }
+}
+
 // fp8 fallback for planes that do not fit LDS: every output reads its 13 x 13 window (4 channels per thread)
 __global__ __launch_bounds__(256) void sppf_pool_fp8_kernel(View cat, int C) {
     const int cv = C / 4;
@@ -366,9 +454,31 @@ __global__ __launch_bounds__(256) void sppf_pool_fp8_kernel(View cat, int C) {
     }
 }
 
-int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s) {
+int launch_sppf_pool(const View& cat, int C, int prec, int form, hipStream_t s) {
     const int es = prec == PREC_F32 ? 4 : (prec == PREC_FP8 ? 1 : 2);
     VC_CHECK(C % 4 == 0 && cat.cs % 4 == 0 && cat.co % 4 == 0, VC_ERR_ARG, "sppf: channel alignment");
+    // form 1 (the engine's default): the register form wherever the plane is at most 40 x 40 -- every SPPF input of 640^2 ... 1280^2 frames
+    const int maxd = std::max(cat.H, cat.W);
+    if (form == 1 && maxd <= 40 && (cat.cs * es) % 4 == 0 && (cat.co * es) % 4 == 0) {
+        static const int ws_env = getenv("VC_SPPF_WS") ? atoi(getenv("VC_SPPF_WS")) : 0;       // A/B switch
+        int ws = 0, rstride = 0;
+        for (int cand : {32, 16, 8, 4}) {
+            if (ws || (ws_env && cand != ws_env)) continue;
+            const int rs = cat.W * cand + ((cand - (cat.W * cand) % 64) % 64 + 64) % 64;      // a wave's 64 / cand rows land on distinct banks
+            if (C % (cand * 4 / es) == 0 && maxd * cand <= (maxd > 20 ? 320 : 640) && (size_t)cat.H * rs * 4 <= 56 * 1024) { ws = cand; rstride = rs; }
+        }
+        if (ws) {
+            const int blocks = cat.B * (C / (ws * 4 / es));
+            const int threads = (maxd * ws + 63) / 64 * 64;
+            const size_t lds = (size_t)cat.H * rstride * 4;
+#define VC_SPPF_SEP(ET) { if (maxd <= 20) hipLaunchKernelGGL((sppf_pool_sep_kernel<ET, 20>), dim3(blocks), dim3(threads), lds, s, cat, C, ws, rstride); \
+                          else hipLaunchKernelGGL((sppf_pool_sep_kernel<ET, 40>), dim3(blocks), dim3(threads), lds, s, cat, C, ws, rstride); }
+            if (prec == PREC_F32) VC_SPPF_SEP(0) else if (prec == PREC_FP8) VC_SPPF_SEP(2) else VC_SPPF_SEP(1)
+#undef VC_SPPF_SEP
+            VC_HIP(hipGetLastError());
+            return VC_OK;
+        }
+    }
     // The wide LDS kernel with the widest slice that fits: 64-byte (or narrower) slices when two such workgroups fit a CU's LDS
     // (every workgroup of a 128-frame batch is then resident at once -- the kernel is six LDS passes and seven barriers long, i.e.
     // latency-bound), wider ones otherwise.

@@ -125,7 +125,7 @@ struct vc_engine {
     bool finalized = false;
     // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
     // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv per launch
-    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1, head_side = 1, fuse_upsample = 1; } opt;
+    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1, head_side = 1, fuse_upsample = 1, sppf_sep = 1; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 

@@ -719,7 +719,7 @@ static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStre
                 }
                 break;
             }
-            case Op::SPPF: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, s)); break; }
+            case Op::SPPF: { ProfScope ps(e, aux_cat, 0, 0, s); VC_TRY(launch_sppf_pool(op.a, op.C, e->prec, e->opt.sppf_sep, s)); break; }
             case Op::UPSAMPLE: {
                 // bf16: when the consumer is the pointwise conv over [upsampled | skip] (C3.cv1 | cv2 of layers 13 / 17) it reads the half-size
                 // map itself; the slice of the concat buffer stays unwritten (vc_detect_debug_layer produces it on demand)
@@ -1027,7 +1027,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
-        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1); e->opt.fuse_upsample = env_int("VC_FUSE_UPSAMPLE", 1);
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1); e->opt.fuse_upsample = env_int("VC_FUSE_UPSAMPLE", 1); e->opt.sppf_sep = env_int("VC_SPPF_SEP", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -1217,6 +1217,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "reid_block_fused") e->opt.reid_block_fused = value;
     else if (n == "head_side") e->opt.head_side = value;
     else if (n == "fuse_upsample") e->opt.fuse_upsample = value;
+    else if (n == "sppf_sep") e->opt.sppf_sep = value;
     else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }

@@ -24,7 +24,7 @@ struct LetterboxGeom {
 // src: B x src_h x src_w x 3 u8.  dst: B x net_h x net_w x 4 (prec), channel 3 = 0, values /255.
 int launch_letterbox(const uint8_t* src, void* dst, int B, const LetterboxGeom& g, int prec, hipStream_t s);
 // SPPF: x = view slice [0,C); writes maxpool5, maxpool5∘2, maxpool5∘3 into slices [C,2C), [2C,3C), [3C,4C) of the same buffer.
-int launch_sppf_pool(const View& cat, int C, int prec, hipStream_t s);
+int launch_sppf_pool(const View& cat, int C, int prec, int form, hipStream_t s);   // form 1: register form where it applies, 0: the LDS-plane forms
 int launch_upsample2x(const View& src, const View& dst, int prec, hipStream_t s);
 // bf16 NHWC -> OCP e4m3fn, value x inv_scale, clamped to +-448 (the stem's output entering the fp8 layers)
 int launch_bf16_to_fp8(const View& src, const View& dst, float inv_scale, hipStream_t s);
