@@ -126,56 +126,94 @@ __global__ __launch_bounds__(256) void head_compact_kernel(const uint16_t* __res
 // decode_kernel's arithmetic on the gathered logits: SIXTEEN lanes per (gathered pixel, anchor) -- the class scores are what costs (80 precise
 // sigmoids per anchor, one thread per anchor walked them one after the other: 29 us per pass on the detector queue's tail); lane s takes classes
 // s, s + 16, ... in ascending order, the group reduces (score, class) with "larger score, then smaller class" = the serial loop's strict `>`.
+// Candidate slots: a workgroup takes a CONTIGUOUS run of the gathered anchors (16 per pass, up to 8 passes when there are more anchors than the
+// grid has groups), parks its survivors in LDS and asks for their slots with ONE atomicAdd per frame it met -- the gather order follows the pixel
+// index, so a run is one or two frames.  One returning atomic per candidate on a frame's counter is a chain of ~90 ns steps: with the ~8000
+// candidates per frame of the dense workloads that chain WAS the kernel (735 us per 32 frames of m1024-bf16, 548 us at 1280 x 720).  Which slot a
+// candidate gets does not matter: rank_sort_kernel orders a frame's candidates by (score, flattened index), a total order.
+#define VC_DS_MAXP 8
 __global__ __launch_bounds__(256) void decode_sparse_kernel(const DecodeLevel l0, const DecodeLevel l1, const DecodeLevel l2, const int* __restrict__ counts,
                                                             const int* __restrict__ list0, const int* __restrict__ list1, const int* __restrict__ list2,
                                                             int cap0, int cap1, int cap2, int nc, float conf_thres, int max_cand, DetectPostBuffers pb) {
+    __shared__ float4 s_box[16 * VC_DS_MAXP];
+    __shared__ float s_conf[16 * VC_DS_MAXP];
+    __shared__ int s_cls[16 * VC_DS_MAXP], s_idx[16 * VC_DS_MAXP], s_b[16 * VC_DS_MAXP], s_base[16 * VC_DS_MAXP];
+    __shared__ int s_n;
     const int no = nc + 5;
     const int n0 = min(counts[0], cap0), n1 = min(counts[1], cap1), n2 = min(counts[2], cap2);
     const long total = 3l * ((long)n0 + n1 + n2);
-    const int sub = threadIdx.x & 15;
-    for (long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; g < total; g += ((long)gridDim.x * blockDim.x) >> 4) {
-        long e = g / 3;
-        const int a = (int)(g - e * 3);
-        const int level = e < n0 ? 0 : (e < (long)n0 + n1 ? 1 : 2);
-        const DecodeLevel& lv = level == 0 ? l0 : (level == 1 ? l1 : l2);
-        const int s = (int)(level == 0 ? e : (level == 1 ? e - n0 : e - n0 - n1));
-        const int m = (level == 0 ? list0 : (level == 1 ? list1 : list2))[s];
-        const int ppf = lv.ny * lv.nx;
-        const int b = m / ppf, rem = m - b * ppf, y = rem / lv.nx, x = rem - y * lv.nx;
-        const size_t qoff = (size_t)s * lv.cs + a * no;
-        auto ld = [&](int c) -> float { return __uint_as_float((uint32_t)((const uint16_t*)lv.logits)[qoff + c] << 16); };
-        const float obj = sigmoidf_(ld(4));
-        if (!(obj > conf_thres)) continue;                   // (the same for the sixteen lanes of a group)
-        float best = -1.0f;
-        int bj = 0;
-        for (int c = sub; c < nc; c += 16) {
-            const float v = sigmoidf_(ld(5 + c)) * obj;
-            if (v > best) { best = v; bj = c; }
-        }
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long per_pass = 16l * gridDim.x;
+    const int passes = (int)min((long)VC_DS_MAXP, max(1l, (total + per_pass - 1) / per_pass));
+    const long run = 16l * passes;
+    for (long g0 = (long)blockIdx.x * run; g0 < total; g0 += (long)gridDim.x * run) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (int k = 0; k < passes; ++k) {
+            const long g = g0 + k * 16 + grp;
+            if (g >= total) continue;
+            long e = g / 3;
+            const int a = (int)(g - e * 3);
+            const int level = e < n0 ? 0 : (e < (long)n0 + n1 ? 1 : 2);
+            const DecodeLevel& lv = level == 0 ? l0 : (level == 1 ? l1 : l2);
+            const int s = (int)(level == 0 ? e : (level == 1 ? e - n0 : e - n0 - n1));
+            const int m = (level == 0 ? list0 : (level == 1 ? list1 : list2))[s];
+            const int ppf = lv.ny * lv.nx;
+            const int b = m / ppf, rem = m - b * ppf, y = rem / lv.nx, x = rem - y * lv.nx;
+            const size_t qoff = (size_t)s * lv.cs + a * no;
+            auto ld = [&](int c) -> float { return __uint_as_float((uint32_t)((const uint16_t*)lv.logits)[qoff + c] << 16); };
+            const float obj = sigmoidf_(ld(4));
+            if (!(obj > conf_thres)) continue;                   // (the same for the sixteen lanes of a group)
+            float best = -1.0f;
+            int bj = 0;
+            for (int c = sub; c < nc; c += 16) {
+                const float v = sigmoidf_(ld(5 + c)) * obj;
+                if (v > best) { best = v; bj = c; }
+            }
 #pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) {
-            const float ob = __shfl_xor(best, d);
-            const int oj = __shfl_xor(bj, d);
-            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            for (int d = 8; d >= 1; d >>= 1) {
+                const float ob = __shfl_xor(best, d);
+                const int oj = __shfl_xor(bj, d);
+                if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            }
+            if (sub != 0 || !(best > conf_thres)) continue;
+            const float sx = sigmoidf_(ld(0)), sy = sigmoidf_(ld(1)), sw = sigmoidf_(ld(2)), sh = sigmoidf_(ld(3));
+            const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
+            const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
+            const float tw = sw * 2.0f, th = sh * 2.0f;
+            const float w = tw * tw * lv.anchor_w[a];
+            const float h = th * th * lv.anchor_h[a];
+            const float hw = w / 2.0f, hh = h / 2.0f;
+            const int i = atomicAdd(&s_n, 1);
+            s_box[i] = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+            s_conf[i] = best; s_cls[i] = bj; s_b[i] = b;
+            s_idx[i] = lv.base + (a * lv.ny + y) * lv.nx + x;      // the anchor's position in the reference's flattened prediction
         }
-        if (sub != 0 || !(best > conf_thres)) continue;
-        const float sx = sigmoidf_(ld(0)), sy = sigmoidf_(ld(1)), sw = sigmoidf_(ld(2)), sh = sigmoidf_(ld(3));
-        const float cx = (sx * 2.0f - 0.5f + (float)x) * lv.stride;
-        const float cy = (sy * 2.0f - 0.5f + (float)y) * lv.stride;
-        const float tw = sw * 2.0f, th = sh * 2.0f;
-        const float w = tw * tw * lv.anchor_w[a];
-        const float h = th * th * lv.anchor_h[a];
-        const int pos = atomicAdd(pb.cand_count + b, 1);
-        if (pos >= max_cand) { pb.overflow[b] = 1; continue; }
-        const size_t o = (size_t)b * max_cand + pos;
-        const float hw = w / 2.0f, hh = h / 2.0f;
-        pb.cand_box[o * 4 + 0] = cx - hw;
-        pb.cand_box[o * 4 + 1] = cy - hh;
-        pb.cand_box[o * 4 + 2] = cx + hw;
-        pb.cand_box[o * 4 + 3] = cy + hh;
-        pb.cand_conf[o] = best;
-        pb.cand_cls[o] = bj;
-        pb.cand_idx[o] = lv.base + (a * lv.ny + y) * lv.nx + x;      // the anchor's position in the reference's flattened prediction
+        __syncthreads();
+        const int n = s_n, t = threadIdx.x;
+        int first = 0, rank = 0;
+        if (t < n) {
+            const int b = s_b[t];
+            int cnt = 0;
+            first = -1;
+            for (int j = 0; j < n; ++j)
+                if (s_b[j] == b) { if (first < 0) first = j; rank += j < t ? 1 : 0; ++cnt; }
+            if (first == t) s_base[t] = atomicAdd(pb.cand_count + b, cnt);
+        }
+        __syncthreads();
+        if (t < n) {
+            const int b = s_b[t], pos = s_base[first] + rank;
+            if (pos >= max_cand) pb.overflow[b] = 1;
+            else {
+                const size_t o = (size_t)b * max_cand + pos;
+                *(float4*)(pb.cand_box + o * 4) = s_box[t];
+                pb.cand_conf[o] = s_conf[t];
+                pb.cand_cls[o] = s_cls[t];
+                pb.cand_idx[o] = s_idx[t];
+            }
+        }
+        // (the next run's `s_n = 0` sits behind this run's last LDS read: the barrier at the top of the loop orders the candidate arrays)
+        __syncthreads();
     }
 }
 
