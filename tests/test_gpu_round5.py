@@ -187,3 +187,40 @@ def test_sppf_register_form_gives_the_same_bits(precision):
         np.testing.assert_array_equal(out[1][1], out[0][1])
         assert np.isfinite(out[1][1]).all() and np.abs(out[1][1]).max() > 0
         eng.close()
+
+
+def test_s2_conv_with_its_pointwise_reader_gives_the_same_bits():
+    """YOLOv5s layer 3 (Conv 64 -> 128, 3x3 / s2: ultralytics/yolov5 v6.0 models/yolo.py as loaded by /root/reference/networks/yolo.py:58) and
+    C3.cv1 | cv2 of layer 4, its only reader, in one launch (conv3x3s2_halo_kernel<..., F2>): layers 4, 6, 9, 17 and the detections equal the
+    two-launch pass bit for bit, and layer 3 itself -- never written by the fused pass -- is produced on demand for vc_detect_debug_layer.
+    The stand-alone layer 3 is pinned to the halo-staged stride-2 kernel (tile configuration 49): that family walks K by tap parity class, the
+    implicit GEMM tap by tap, and the two orders round differently (every tile-configuration choice of a 3 x 3 / s2 layer has that effect)."""
+    sd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=0.5)
+    for (B, H, W) in ((3, 352, 640), (2, 640, 640), (1, 333, 500), (5, 96, 160)):
+        frames = synth_frames(B, H, W, n_obj=6, seed=13)
+        imgs = [f[:, :, ::-1] for f in frames]
+        eng = E.Engine(sd, None, precision="bf16", num_classes=NC, max_batch=B, max_frame_hw=(H, W))
+        eng.set_option("fuse_s2_pw", 0)
+        eng.detect(imgs)
+        lines, pinned = [], 0
+        for l in eng.tune_export().strip().splitlines():
+            k, c = l.split()
+            if "_ci64_co128_k3x3_s2_" in k:
+                c, pinned = "49", pinned + 1
+            lines.append(f"{k} {c}")
+        assert pinned > 0
+        eng.tune_import("\n".join(lines) + "\n")
+        out = {}
+        for on in (1, 0, 1):
+            eng.set_option("fuse_s2_pw", on)
+            dets = eng.detect(imgs)
+            layers = {l: eng.debug_layer(l, batch=B) for l in (4, 6, 9, 17, 3)}
+            if on in out:
+                continue
+            out[on] = (dets, layers)
+        for a, b in zip(out[1][0], out[0][0]):
+            np.testing.assert_array_equal(a, b)
+        for l in out[1][1]:
+            np.testing.assert_array_equal(out[1][1][l], out[0][1][l], err_msg=f"layer {l} at {B}x{H}x{W}")
+        assert np.abs(out[1][1][3]).max() > 0
+        eng.close()

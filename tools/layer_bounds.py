@@ -34,6 +34,8 @@ for (M, N, K, kh, kw, s, cfg, ms) in rows:
         fl = 2.0 * M * (64 * 64 + 576 * 64 + 128 * 128); inb = M * 128 * 2; outb = M * 128 * 2; silu = M * 256
     elif cfg == 106:    # reid_block_fused: two 3x3 on 64 channels
         fl = 2.0 * M * 2 * 576 * 64; inb = M * 64 * 2 * 2; outb = M * 64 * 2
+    elif cfg == 107:    # 3x3 / s2 (64 -> 128) + the pointwise conv that alone reads it (128 -> 128): one launch, the 3x3's output stays on chip
+        fl = 2.0 * M * 128 * (576 + 128); inb = M * 64 * 2 * 4; outb = M * 128 * 2; silu = M * 256
     elif cfg == 101:    # reid stem + pool: crops in, pooled out
         inb = M * 8 * 2; outb = (M // 4) * 64 * 2
     elif N == 8 or cfg == -1:

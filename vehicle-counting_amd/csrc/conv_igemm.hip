@@ -556,6 +556,7 @@ __device__ __forceinline__ void conv_epilogue_bf16_rows(const ConvP& p, f32x4 (&
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osrd2 = __builtin_amdgcn_make_buffer_rsrc(p.split > 0 ? p.out2 : p.out, 0, 0x7ffffff0, 0x00020000);
     float4 bias[CT];
 #pragma unroll
     for (int a = 0; a < CT; ++a) bias[a] = nbase + a * 16 < p.Cout ? *(const float4*)(p.bias + nbase + a * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -584,9 +585,99 @@ __device__ __forceinline__ void conv_epilogue_bf16_rows(const ConvP& p, f32x4 (&
             const u32x4 o4 = {sx.x, sy.x, sx.y, sy.y};
             const int nn = odd ? n - 4 : n;
             const bool ok = n < p.Cout && m < p.M;
-            __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, ok ? (m * p.out_cs + p.out_co + nn) * 2 : (int)0x80000000u, 0, 0);
+            if (p.split == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, ok ? (m * p.out_cs + p.out_co + nn) * 2 : (int)0x80000000u, 0, 0);
+            } else {                                                   // two destinations (C3.cv1 | cv2), as conv_epilogue_bf16
+                const bool second = nn >= p.split;
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd, (ok && !second) ? (m * p.out_cs + p.out_co + nn) * 2 : (int)0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o4, osrd2, (ok && second) ? (m * p.out2_cs + p.out2_co + nn - p.split) * 2 : (int)0x80000000u, 0, 0);
+            }
         }
     }
+}
+
+// ---- conv3x3s2_halo_kernel<..., F2>: the pointwise conv that is the ONLY reader of this conv's output, on the tile while it is on chip ----------
+// YOLOv5s layer 3 (Conv 64 -> 128, 3x3 / s2, 80^2) is read by C3.cv1 | cv2 of layer 4 (one 1x1 launch, 128 -> 64 | 64) and by nothing else: as two
+// launches its 210 MB (128 frames) are written and read straight back.  A wave of the 256 x 128 tile holds ALL 128 channels of its 64 pixels, so
+// after the 3x3's own epilogue (bias, SiLU, bf16 rounding: the values the stand-alone launch would have stored) the packed outputs are re-laid
+// into MFMA B operands across the wave's four 16-lane rows (ds_bpermute: the LDS crossbar, no LDS memory), the 1x1's 32 KB of weights wait as
+// ready-made fragments in the LDS the K loop has finished with, and the 1x1 runs its four K steps in the stand-alone kernel's order (ks = 0..3 from a
+// zero accumulator, one v_mfma_f32_16x16x32_bf16 per step and tile): bit-identical to the two launches (tests/test_gpu_round5.py).
+// O[t2][a] of a lane in 16-lane row r (conv_epilogue_bf16_rows' lane-pair exchange): pixel tile 2 t2 + (r & 1), channels 16 a + 8 (r >> 1) .. + 7.
+// B operand of K step ks for pixel tile t, row kg: channels 32 ks + 8 kg .. + 7 = O[t >> 1][2 ks + (kg >> 1)] of row 2 (kg & 1) + (t & 1).
+template <int PT, int CT>
+__device__ __forceinline__ void s2_pointwise_stage(const ConvP& p, const ConvP& q, f32x4 (&acc)[CT][PT], const int (&mrow)[PT], uint4* lds) {
+    static_assert(PT == 4 && CT == 8, "the 256 x 128 tile with four waves side by side in pixels");
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fch = lane >> 4;
+    // the 1x1's weights: fragment f = ks * 8 + a2 (channel tile a2, K step ks), this wave fetches f = 4 i + wave
+    uint4 wreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = i * 4 + wave, ks = f >> 3, a2 = f & 7;
+        wreg[i] = *(const uint4*)((const char*)q.w + ((size_t)(a2 * 16 + frow) * q.Kw + ks * 32 + fch * 8) * 2);
+    }
+    // the 3x3's epilogue, kept in registers
+    uint4 O[2][CT];
+    {
+        float4 bias[CT];
+#pragma unroll
+        for (int a = 0; a < CT; ++a) bias[a] = *(const float4*)(p.bias + a * 16 + fch * 4);
+#pragma unroll
+        for (int b = 0; b < PT; b += 2)
+#pragma unroll
+            for (int a = 0; a < CT; ++a) {
+                u32x2 P[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float v[4] = {acc[a][b + t][0] + bias[a].x, acc[a][b + t][1] + bias[a].y, acc[a][b + t][2] + bias[a].z, acc[a][b + t][3] + bias[a].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[j]));
+                    P[t] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+                const u32x2 sx = __builtin_amdgcn_permlane16_swap(P[0].x, P[1].x, false, false);
+                const u32x2 sy = __builtin_amdgcn_permlane16_swap(P[0].y, P[1].y, false, false);
+                O[b >> 1][a] = make_uint4(sx.x, sy.x, sx.y, sy.y);
+            }
+    }
+    __syncthreads();                                   // every wave's LDS-DMA writes (the ring's look-ahead past the last step) have landed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds[(i * 4 + wave) * 64 + lane] = wreg[i];
+    __syncthreads();
+    f32x4 acc2[CT][PT];
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool upper = (fch >> 1) != 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        Chunk xb[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int src = (frow + 16 * (2 * (fch & 1) + (t & 1))) * 4;
+            const uint4 lo = O[t >> 1][2 * ks], hi = O[t >> 1][2 * ks + 1];
+            const uint32_t l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
+            uint32_t d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)l4[j]);
+                const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)h4[j]);
+                d[j] = upper ? y : x;
+            }
+            xb[t].u = (u32x4v){d[0], d[1], d[2], d[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+            Chunk wf;
+            const uint4 wv = lds[(ks * 8 + a) * 64 + lane];
+            wf.u = (u32x4v){wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc2[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.h, xb[t].h, acc2[a][t], 0, 0, 0);
+        }
+    }
+    conv_epilogue_bf16_rows<PT, CT, ACT_SILU>(q, acc2, mrow, fch * 4);
 }
 
 struct S2Steps {          // the 18 steps of a 64-channel group: tap, 32-channel half, parity class, position within the class
@@ -606,8 +697,8 @@ constexpr S2Steps s2_steps() {
     return t;
 }
 
-template <int BP, int BC, int WP, int WC, int NS>
-__global__ __launch_bounds__(256, BP * BC <= 128 * 128 ? 3 : 2) void conv3x3s2_halo_kernel(const ConvP p) {
+template <int BP, int BC, int WP, int WC, int NS, bool F2 = false>     // F2: followed on the tile by the pointwise conv q that alone reads its output
+__global__ __launch_bounds__(256, BP * BC <= 128 * 128 ? 3 : 2) void conv3x3s2_halo_kernel(const ConvP p, const ConvP q) {
     constexpr int KC = 4, ES = 2;
     do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (0)] = wall_clock64(); } while (0);      // diagnostics (VC_CONV_DBG): phase timestamps like conv_igemm_kernel
     constexpr int XI = BP / 128 * 5;               // DMA instructions per class: 5 x 256 chunks = 160 pixels of 128 bytes per 128 outputs
@@ -811,9 +902,14 @@ __global__ __launch_bounds__(256, BP * BC <= 128 * 128 ? 3 : 2) void conv3x3s2_h
         const int r = (int)(((float)q + 0.5f) * inv_tw);
         mrow[i] = (flg >> (3 * i)) & 1u ? p.M : (g_top + r) * Wo + x0 + q - r * TW;
     }
-    if (p.act == ACT_SILU) conv_epilogue_bf16_rows<PT, CT, ACT_SILU>(p, acc, mrow, nbase);
-    else if (p.act == ACT_RELU) conv_epilogue_bf16_rows<PT, CT, ACT_RELU>(p, acc, mrow, nbase);
-    else conv_epilogue_bf16_rows<PT, CT, ACT_NONE>(p, acc, mrow, nbase);
+    if constexpr (F2) {
+        if (p.ablate == 8) conv_epilogue_bf16_rows<PT, CT, ACT_SILU>(p, acc, mrow, nbase);     // diagnostics: also store the 3x3's own output
+        s2_pointwise_stage<PT, CT>(p, q, acc, mrow, &lds[0]);
+    } else {
+        if (p.act == ACT_SILU) conv_epilogue_bf16_rows<PT, CT, ACT_SILU>(p, acc, mrow, nbase);
+        else if (p.act == ACT_RELU) conv_epilogue_bf16_rows<PT, CT, ACT_RELU>(p, acc, mrow, nbase);
+        else conv_epilogue_bf16_rows<PT, CT, ACT_NONE>(p, acc, mrow, nbase);
+    }
     if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (4)] = wall_clock64(); } while (0); }
 }
 
@@ -1167,7 +1263,31 @@ static int launch_s2halo(ConvP p, hipStream_t s) {
     const long tiles = (long)((p.Wo + p.s2_tw - 1) / p.s2_tw) * ((G + p.s2_th - 1) / p.s2_th) * ((p.Cout + BC - 1) / BC);
     p.Kw = p.Kp;
     p.ntiles = (int)tiles;
-    launch_timed(p, conv3x3s2_halo_kernel<BP, BC, WP, WC, NS>, dim3((unsigned)tiles), dim3(256), 0, s, p);
+    launch_timed(p, conv3x3s2_halo_kernel<BP, BC, WP, WC, NS>, dim3((unsigned)tiles), dim3(256), 0, s, p, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// p: a 3x3 / s2 conv with 128 output channels + SiLU; q: the 1x1 / s1 conv (128 -> 128 channels, SiLU, one or two destinations) that reads p's
+// output -- and is its ONLY reader (the caller's knowledge: p's output is not written).  s2_pointwise_stage above.
+bool s2halo_pw_applicable(const ConvP& p, const ConvP& q) {
+    int th, tw;
+    if (!s2halo_applicable(p) || p.Cout != 128 || p.act != ACT_SILU || !s2halo_geom(p, 256, &th, &tw)) return false;
+    if (q.prec != PREC_BF16 || q.kh != 1 || q.kw != 1 || q.sh != 1 || q.sw != 1 || q.ph != 0 || q.pw != 0 || q.Cin != 128 || q.K != 128 || q.Cout != 128) return false;
+    if (q.act != ACT_SILU || q.res_mode != RES_NONE || q.out_f32 || q.m_dev || q.in_up || q.Kp < 128) return false;
+    if (q.in != p.out || q.in_co != p.out_co || q.in_cs != p.out_cs || q.B != p.B || q.H != p.Ho || q.W != p.Wo || q.M != p.M) return false;
+    if (q.out_cs % 8 != 0 || q.out_co % 8 != 0 || (q.split != 0 && (q.split % 8 != 0 || q.out2_cs % 8 != 0 || q.out2_co % 8 != 0))) return false;
+    return true;
+}
+int launch_s2halo_pw(ConvP p, ConvP q, hipStream_t s) {
+    if (!s2halo_pw_applicable(p, q) || !s2halo_geom(p, 256, &p.s2_th, &p.s2_tw)) return VC_ERR_ARG;
+    const long G = (long)p.B * p.Ho;
+    const long tiles = (long)((p.Wo + p.s2_tw - 1) / p.s2_tw) * ((G + p.s2_th - 1) / p.s2_th);
+    p.Kw = p.Kp; q.Kw = q.Kp;
+    p.ntiles = (int)tiles;
+    static const bool also_store = getenv("VC_S2PW_STORE") && atoi(getenv("VC_S2PW_STORE")) != 0;   // diagnostics
+    if (also_store) p.ablate = 8;
+    launch_timed(p, conv3x3s2_halo_kernel<256, 128, 4, 1, 2, true>, dim3((unsigned)tiles), dim3(256), 0, s, p, q);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

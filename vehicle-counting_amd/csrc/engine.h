@@ -32,6 +32,7 @@ struct ConvParam {
 struct Op {
     enum Kind { CONV, SPPF, UPSAMPLE, MAXPOOL, TO_FP8, HEAD_COMPACT } kind;
     int level = 0;                   // HEAD_COMPACT: detection level
+    int sole_reader_next = 0;        // CONV: the next op is the only reader of this op's output (it may stay on chip)
     double flops_override = -1, bytes_override = -1;   // CONV: algorithmic work to report instead of the launch's own (fixed part)
     // CONV with a device-side row count (sparse Detect head): the EXECUTED work is flops_override + rows x flops_per_row (bytes alike),
     // rows = the count the compaction left on the device, read back after the pass; dense_* = what the dense head this launch replaces
@@ -125,7 +126,7 @@ struct vc_engine {
     bool finalized = false;
     // kernel-selection switches: read from the environment ONCE at engine creation (VC_C3_FUSED, VC_BNECK_FUSED, VC_FRONT_FUSED,
     // VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB), changed afterwards only through vc_engine_set_option -- nothing on the launch path calls getenv per launch
-    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1, head_side = 1, fuse_upsample = 1, sppf_sep = 1; } opt;
+    struct Options { int c3_fused = 1, bneck_fused = 1, bneck_cv3 = 1, front_fused = 1, crop_per_pixel = 0, sparse_head = 1, ff_ablate = 0, c3_ablate = 0, reid_block_fused = 1, head_side = 1, fuse_upsample = 1, sppf_sep = 1, fuse_s2_pw = 1; } opt;
     std::vector<void*> allocs;       // everything hipMalloc'ed, freed on destroy
     std::vector<void*> host_allocs;  // hipHostMalloc'ed
 
@@ -134,6 +135,7 @@ struct vc_engine {
     int ch[5] = {0, 0, 0, 0, 0}, rep[4] = {0, 0, 0, 0};
     std::map<std::string, vc::View> ybuf;        // named activation buffers (max shape)
     vc::View layer_view[24];
+    std::vector<vc::ConvP> s2pw_folded;                          // stride-2 convs whose output the last pass kept on chip (conv3x3s2_halo_kernel<..., F2>)
     std::vector<std::pair<vc::View, vc::View>> up_folded;        // UPSAMPLE ops (source, destination) the last detector pass folded into their consumers
     std::map<std::vector<int>, vc::YoloPlan> yolo_plans;          // key: B, nh, nw, sparse head?
     std::map<std::pair<int, int>, vc::ReidPlan> reid_plans;   // key: first crop, crop count

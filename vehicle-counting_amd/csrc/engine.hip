@@ -349,12 +349,15 @@ static int yolo_build_ops(vc_engine* e, int B, int Hn, int Wn, std::vector<Op>& 
     lv[1] = x = pb.conv("model.1.conv", x, full("l1", 4, c[1]), 3, 2, 1, ACT_SILU);
     lv[2] = x = yolo_c3(pb, e, 2, x, full("l2", 4, c[1]), c[1], e->rep[0], true);
     lv[3] = x = pb.conv("model.3.conv", x, full("l3", 8, c[2]), 3, 2, 1, ACT_SILU);
+    if (pb.status == VC_OK) ops.back().sole_reader_next = 1;      // "l3" is read by C3.cv1 | cv2 of layer 4 (the next op) and by nothing else
     View cat16 = full("cat16", 8, 2 * c[2]);
     lv[4] = x = yolo_c3(pb, e, 4, x, mkview(cat16, B, Hn / 8, Wn / 8, c[2], c[2]), c[2], e->rep[1], true);
     lv[5] = x = pb.conv("model.5.conv", x, full("l5", 16, c[3]), 3, 2, 1, ACT_SILU);
+    if (pb.status == VC_OK) ops.back().sole_reader_next = 1;
     View cat12 = full("cat12", 16, 2 * c[3]);
     lv[6] = x = yolo_c3(pb, e, 6, x, mkview(cat12, B, Hn / 16, Wn / 16, c[3], c[3]), c[3], e->rep[2], true);
     lv[7] = x = pb.conv("model.7.conv", x, full("l7", 32, c[4]), 3, 2, 1, ACT_SILU);
+    if (pb.status == VC_OK) ops.back().sole_reader_next = 1;
     lv[8] = x = yolo_c3(pb, e, 8, x, full("l8", 32, c[4]), c[4], e->rep[3], true);
     {   // SPPF (models/common.py::SPPF, k=5)
         View sc = full("sppcat", 32, 2 * c[4]);
@@ -664,6 +667,27 @@ static int run_ops_body(vc_engine* e, std::vector<Op>& ops, int aux_cat, hipStre
                     ++oi;                                                     // the 3x3 conv is done
                     break;
                 }
+                if (e->opt.fuse_s2_pw != 0 && op.sole_reader_next && nx && nx->kind == Op::CONV && s2halo_pw_applicable(cp, nx->conv)) {
+                    // a 3x3 / s2 conv and the pointwise conv that alone reads it in one launch (conv3x3s2_halo_kernel<..., F2>): YOLOv5s layer 3 + C3.cv1 | cv2 of layer 4
+                    const ConvP& o2 = nx->conv;
+                    const double flb = fl + 2.0 * o2.M * (double)o2.Cout * nx->C;
+                    const double byb = ((double)cp.B * cp.H * cp.W * cp.Cin + (double)cp.Cout * cp.K + (double)o2.Cout * o2.K) * es + (double)o2.M * o2.Cout * es;   // x in, both weights, cv1 | cv2 out
+                    cp.cfg = 107;
+                    if (cp.ev_start && e->prof_used > 0) { e->prof_pairs[e->prof_used - 1].flops = flb; e->prof_pairs[e->prof_used - 1].bytes = byb; }
+                    {
+                        ProfScope ps(e, VC_PROF_CONV, flb, byb, s);
+                        VC_TRY(launch_s2halo_pw(cp, o2, s));
+                    }
+                    if (e->profiling && e->op_log.size() < (1u << 20)) {
+                        char line[256];
+                        snprintf(line, sizeof(line), "conv M=%d N=%d K=%d k=3x3 s=2 cfg=107 ms=%.4f tflops=%.1f\n", cp.M, 128, cp.K + 128, e->last_ms, flb / (e->last_ms * 1e-3) / 1e12);
+                        e->op_log += line;
+                    }
+                    static const bool also_store = getenv("VC_S2PW_STORE") && atoi(getenv("VC_S2PW_STORE")) != 0;   // diagnostics: the fused kernel also stores the 3x3's output
+                    if (!also_store) e->s2pw_folded.push_back(op.conv);                        // its own output stays unwritten (vc_detect_debug_layer produces it on demand)
+                    ++oi;                                                     // the pointwise conv is done
+                    break;
+                }
                 if (fuse_front) {                                             // YOLO layers 0 + 1 in one kernel (front_fused.hip): layer 0 never reaches HBM
                     const Op& o1 = *nx;
                     const double fl1 = 2.0 * o1.conv.M * (double)o1.conv.Cout * o1.C;
@@ -786,6 +810,7 @@ static int yolo_forward(vc_engine* e, int B, int nh, int nw) {
     std::vector<Op>& ops = plan.ops;
     e->l0_stale = false;
     e->up_folded.clear();
+    e->s2pw_folded.clear();
     if (e->sparse_pass) {                                    // the compaction sets overflow flags and counts: clear them ahead of the ops
         e->hc_ring_cur = (int)(e->hc_ring_seq++ % vc_engine::HC_RING);
         VC_HIP(hipMemsetAsync(e->d_zero, 0, e->zero_bytes, ds));
@@ -1027,7 +1052,7 @@ int vc_engine_create(const vc_engine_config* cfg, vc_engine** out) {
         auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
         e->opt.c3_fused = env_int("VC_C3_FUSED", 1); e->opt.bneck_fused = env_int("VC_BNECK_FUSED", 1); e->opt.bneck_cv3 = env_int("VC_BNECK_CV3", 1);
         e->opt.front_fused = env_int("VC_FRONT_FUSED", 1); e->opt.crop_per_pixel = getenv("VC_CROP_PER_PIXEL") ? 1 : 0;
-        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1); e->opt.fuse_upsample = env_int("VC_FUSE_UPSAMPLE", 1); e->opt.sppf_sep = env_int("VC_SPPF_SEP", 1);
+        e->opt.sparse_head = env_int("VC_SPARSE_HEAD", 1); e->opt.reid_block_fused = env_int("VC_REID_BLOCK_FUSED", 1); e->opt.head_side = env_int("VC_HEAD_SIDE", 1); e->opt.fuse_upsample = env_int("VC_FUSE_UPSAMPLE", 1); e->opt.sppf_sep = env_int("VC_SPPF_SEP", 1); e->opt.fuse_s2_pw = env_int("VC_FUSE_S2PW", 1);
     }
     memcpy(e->anchors, kAnchors, sizeof(kAnchors));
     int st = VC_OK;
@@ -1218,6 +1243,7 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "head_side") e->opt.head_side = value;
     else if (n == "fuse_upsample") e->opt.fuse_upsample = value;
     else if (n == "sppf_sep") e->opt.sppf_sep = value;
+    else if (n == "fuse_s2_pw") e->opt.fuse_s2_pw = value;
     else if (n == "ff_ablate") e->opt.ff_ablate = value;            // diagnostics (wrong results): tools/ff_ablate.py
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
@@ -1355,6 +1381,11 @@ int vc_detect_debug_layer(vc_engine* e, int layer, float* out, size_t cap, int d
         for (const auto& ab : e->up_folded) VC_TRY(launch_upsample2x(ab.first, ab.second, e->prec, e->dstream));
         VC_HIP(hipStreamSynchronize(e->dstream));
         e->up_folded.clear();
+    }
+    if ((layer == 3 || layer == 5 || layer == 7) && !e->s2pw_folded.empty()) {   // the last pass kept a stride-2 conv's output on chip for its one reader
+        for (ConvP c : e->s2pw_folded) { c.cfg = 49; VC_TRY(launch_conv(c, e->dstream)); }   // the fused kernel's own tile and K order (conv3x3s2_halo_kernel<256, 128, 4, 1, 2>)
+        VC_HIP(hipStreamSynchronize(e->dstream));
+        e->s2pw_folded.clear();
     }
     VC_CHECK(!(layer == 0 && e->l0_stale), VC_ERR_STATE,
              "layer 0 was not written by the last pass (front_fused_kernel keeps it in LDS); vc_engine_set_option(e, \"front_fused\", 0) and run again");

@@ -187,6 +187,8 @@ static inline void launch_timed(const ConvP& p, K kernel, dim3 grid, dim3 block,
 int launch_conv(const ConvP& p, hipStream_t s);
 int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s);     // no argument checks: for the autotuner
 int launch_halo_v2_cfg(const ConvP& p, int cfg, hipStream_t s);  // conv_halo_v2.hip: tile configuration 55
+bool s2halo_pw_applicable(const ConvP& p, const ConvP& q);      // conv3x3s2_halo_kernel<..., F2>: a 3x3 / s2 conv and the pointwise conv that alone reads it, one launch
+int launch_s2halo_pw(ConvP p, ConvP q, hipStream_t s);
 int conv_num_cfgs();
 bool conv_stream_cfg(int cfg);                               // conv1x1_stream_kernel variants: offered to the autotuner only under VC_CONV_STREAM=1
 bool stem_direct_applicable(const ConvP& p);                    // stem_direct.hip: YOLO 6x6/s2 stem in bf16
