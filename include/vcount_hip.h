@@ -93,7 +93,7 @@ int vc_engine_set_anchors(vc_engine* e, const float* anchors18);
 int vc_engine_finalize(vc_engine* e); /* packs + uploads weights; detector/ReID calls are valid afterwards */
 /* Kernel-selection switches of a live engine (defaults come from the environment at vc_engine_create: VC_C3_FUSED, VC_BNECK_FUSED,
  * VC_FRONT_FUSED, VC_CROP_PER_PIXEL, VC_DOT_ARENA_MB).  Names: "c3_fused", "bneck_fused", "bneck_cv3" (0 / 1), "front_fused" (0 off, 1 stream path,
- * 2 always), "crop_per_pixel", "sparse_head", "reid_block_fused", "fuse_upsample", "sppf_sep", "head_side" (0 / 1; head_side: the P3 / P4 Detect-head ops on their own stream
+ * 2 always), "crop_per_pixel", "sparse_head", "reid_block_fused", "fuse_upsample", "sppf_sep", "fuse_s2_pw", "head_side" (0 / 1; head_side: the P3 / P4 Detect-head ops on their own stream
  * beside the neck layers that follow them), "dot_arena_mb" (largest appearance-table arena the tracker may allocate; 0 = compute the
  * appearance rows inside the walk).  The parity tests use it to compare a fused kernel with the launches it replaces. */
 int vc_engine_set_option(vc_engine* e, const char* name, int value);
