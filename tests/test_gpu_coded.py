@@ -1,0 +1,47 @@
+"""GPU: end-to-end CSV parity in the BENCHMARKED precisions on a well-conditioned detector (north_star: "outputs must
+match the reference CPU path's track_id/box/direction CSV within a stated float tolerance").
+
+vehicle_counting_amd/coded.py builds the detector (the seeded random YOLOv5 + a carrier path that reads a binary plate painted on every
+object: objectness +6 .. +9.75 on a plate, -6 elsewhere, class logits +6 / -9) -- no logit sits near conf_thres, so no rounding error
+decides a detection.  The fp32 CPU oracle's CSV of each clip is committed (tests/golden/coded_*.json, tests/golden/make_coded_golden.py;
+re-derived on the CPU by tests/test_oracle_coded.py).  Stated tolerance, all three cases: the CSV's rows in the same order with label,
+track id, frame, direction, first and last frame EXACT; boxes within 2 px and first / last points within 2 px of the oracle's (the CSV
+holds int()-truncated Kalman boxes: 1 px is the truncation, the rest the ~0.5 px a bf16 / fp8 box logit moves a box); per-(direction,
+class) counts exact.  The ill-conditioned seeded random head stays as the stress test (tests/test_gpu_bench_config.py)."""
+import types
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import coded_case as cc  # noqa: E402
+import vehicle_counting_amd.engine as E  # noqa: E402
+from vehicle_counting_amd.pipeline import CountingPipeline, FrameSource  # noqa: E402
+
+
+def run_product(name, precision, tmp_path, batch, asynchronous=True):
+    c = cc.CASES[name]
+    ysd, rsd, frames, _ = cc.build(name)
+    cfg = types.SimpleNamespace(model_name=c["variant"], min_conf=0.25, min_iou=0.45, max_det=300)
+    args = types.SimpleNamespace(weight=None, mapping=None, output_path=str(tmp_path))
+    eng = E.Engine(ysd, rsd, precision=precision, model_name=c["variant"], num_classes=cc.NC, img_size=c["size"], max_batch=batch,
+                   max_frame_hw=(c["H"], c["W"]), max_crops=batch * 64, max_tracks=4096, nn_budget_cap=60,
+                   max_candidates=8192 if c["size"] > 640 else 4096)
+    pipe = CountingPipeline(args, cfg, {"cam": {"cam_04": {"tracking_config": cc.TRACK_CFG}}}, engine=eng,
+                            class_names=[f"c{i}" for i in range(cc.NC)])
+    rows, counts = pipe.run_stream(FrameSource(frames), "cam_04", cc.zone_file(name, tmp_path), batch=batch, asynchronous=asynchronous)
+    eng.close()
+    return rows, counts
+
+
+@pytest.mark.parametrize("name,precision,batch", [("s640", "bf16", 16), ("s720p", "bf16", 16), ("s640", "f32", 16), ("l1280", "fp8", 8)])
+def test_csv_equals_the_fp32_oracle_in_the_benchmarked_precision(name, precision, batch, tmp_path):
+    """bf16: BASELINE.json configs[1] (640 x 640) and the reference's own frame geometry (1280 x 720 -> 384 x 640 tensor, resize folded
+    into the front kernel) through the batched asynchronous stream path; fp8: configs[4], YOLOv5l at 1280 x 1280 with e4m3 activations and
+    weights from layer 1 on, its OWN detections (no injection) through ReID + DeepSORT + counting; f32 as the control."""
+    g = cc.load_golden(name)
+    rows, counts = run_product(name, precision, tmp_path, batch)
+    assert len(g["rows"]) > 8 * cc.CASES[name]["T"], len(g["rows"])            # the clip tracks ~12 objects in every frame
+    db, dp = cc.compare_rows(rows, g["rows"], box_px=2, point_px=2.0)
+    print(f"{name} {precision}: {len(rows)} rows, max box difference {db} px, max first / last point difference {dp} px")
+    assert counts == g["counts"]

@@ -1363,7 +1363,12 @@ int conv_check(const ConvP& p);
 
 int launch_conv(const ConvP& p, hipStream_t s) {
     VC_TRY(conv_check(p));
-    return launch_conv_cfg(p, p.cfg, s);
+    const int rc = launch_conv_cfg(p, p.cfg, s);
+    // A tuned choice is keyed by the power-of-two bucket of M, but some families' applicability depends on the exact batch (v2_applicable:
+    // whole rows per tile; the upsample fold-in's tile subset): a launcher refuses before it launches anything, and the heuristic's
+    // implicit-GEMM tile takes every shape conv_check admits.
+    if (rc == VC_ERR_ARG && p.cfg >= 0 && p.cfg < conv_num_cfgs()) return launch_conv_cfg(p, -1, s);
+    return rc;
 }
 
 int conv_check(const ConvP& p) {

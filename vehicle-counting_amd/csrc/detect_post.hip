@@ -415,8 +415,13 @@ int launch_nms(int B, int max_cand, int max_det, float iou, const float* geom_de
     hipLaunchKernelGGL(rank_sort_kernel, dim3(max_cand / 256, B), dim3(256), 0, s, max_cand, pb);
     const int tiles = std::min(max_cand / 64, 8);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(tiles, tiles, B), dim3(64), 0, s, max_cand, iou, pb);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * (max_cand / 64 + VC_NMS_LDS_ROWS * (VC_NMS_LDS_ROWS / 64)) + sizeof(int) * max_det, s,
-                       max_cand, max_det, geom_dev, pb);
+    // kept_idx holds one entry per kept box: never more than min(max_det, max_cand) (upstream's max_nms is 30 000)
+    const size_t lds = sizeof(unsigned long long) * (max_cand / 64 + VC_NMS_LDS_ROWS * (VC_NMS_LDS_ROWS / 64)) + sizeof(int) * std::min(max_det, max_cand);
+    if (lds > 48 * 1024) {
+        static size_t raised = 0;
+        if (lds > raised) { VC_HIP(hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = lds; }
+    }
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(256), lds, s, max_cand, max_det, geom_dev, pb);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }

@@ -1248,6 +1248,10 @@ int vc_engine_set_option(vc_engine* e, const char* name, int value) {
     else if (n == "c3_ablate") e->opt.c3_ablate = value;
     else if (n == "dot_arena_mb") { VC_CHECK(value >= 0, VC_ERR_ARG, "dot_arena_mb must be >= 0"); e->dot_arena_max_floats = (size_t)value * 262144; }
     else { set_error("unknown option '%s'", name); return VC_ERR_NOTFOUND; }
+    // A cached op resolved its tile configuration for the kernel variant the options selected at its first launch (the upsample fold-in
+    // runs on a subset of the tiles and has its own tune key): every switch sends the ops back to tuned_cfg.
+    for (auto& kv : e->yolo_plans) for (Op& op : kv.second.ops) op.tuned = -2;
+    for (auto& kv : e->reid_plans) for (Op& op : kv.second.ops) op.tuned = -2;
     return VC_OK;
 }
 
