@@ -63,13 +63,18 @@ def injected(tracks):
 
 def oracle_rows_for_injected(frames, det, nc, embed):
     """VideoTrackerOracle on the injected rows, marshalled like networks/yolo.py:72-97 (10-decimal JSON round trip, xywh)."""
-    ovt = od.VideoTrackerOracle(nc, TRACK_CFG, embed)
-    out = []
-    for f in range(len(frames)):
-        m = oy.marshal_like_reference(det[f])
-        res = ovt.run(frames[f], m["bboxes"], m["classes"], m["scores"])
-        out.append(np.array([list(b) + [tr, lb] for b, tr, lb in zip(res["boxes"], res["tracks"], res["labels"])], dtype=np.int64).reshape(-1, 6))
-    return out
+    def compute():
+        ovt = od.VideoTrackerOracle(nc, TRACK_CFG, embed)
+        out = []
+        for f in range(len(frames)):
+            m = oy.marshal_like_reference(det[f])
+            res = ovt.run(frames[f], m["bboxes"], m["classes"], m["scores"])
+            out.append(np.array([list(b) + [tr, lb] for b, tr, lb in zip(res["boxes"], res["tracks"], res["labels"])], dtype=np.int64).reshape(-1, 6))
+        return out
+    # (tests/oracle_cache.py: 12 288 crops through the CPU ReID net took 79 s of every GPU-suite run; `embed` is always the oracle's
+    # embedder of synth_reid(1702) here, named in the key)
+    import oracle_cache
+    return oracle_cache.memo("rows_for_injected", [frames, det, nc, {k: TRACK_CFG[k] for k in sorted(TRACK_CFG)}, "make_embedder(synth_reid(1702))"], compute)
 
 
 def stream_rows(eng, tids, dev_frames, B, H, W, inject=None, cap_rows=512):
