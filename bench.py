@@ -44,6 +44,7 @@ NC = 80
 TRACK = dict(max_dist=0.2, min_confidence=0.25, nms_max_overlap=0.5, max_iou_distance=0.6, max_age=30, n_init=3, nn_budget=60)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp8": 5000.0, "f32": 157.3}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md; fp8 = MX-scaled K = 128 form; f32 = v_mfma_f32_16x16x4_f32, the vector rate)
 PEAK_HBM_GBS = 8000.0                              # HBM3E (MI355X_MICROARCH.md)
+ACHIEVABLE_HBM_GBS = 6300.0                        # what a read + write stream reaches (tools/ubench/stream_bw.hip)
 ZONE = os.path.join(ROOT, "tests", "golden", "cam_04_halfres.json")
 ZONE_720P = os.path.join(ROOT, "tests", "golden", "cam_04.json")           # the reference's own zone file (demo/sample/cam_04.json, 1280 x 720)
 
@@ -387,7 +388,38 @@ def measure(st, warmup, steps, world, peak_tflops, first=0, traffic=None, traffi
         "timed_launches_measured": int(conv_timed["launches"]),     # capped by the engine's pool of event pairs
         "traffic_note": ("HBM bytes per conv launch from %s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate passes of this command)" % traffic_src) if traffic_src else None,
     }
+    # the same algorithmic work over the AVERAGE LAUNCH DURATION (the contract's per-launch form; detector and ReID launches overlap, so
+    # this is below the wall-clock `frac`), and which HBM peak `peak` is
+    n_l = max(conv_timed["launches"], 1)
+    avg_s = conv_timed["ms"] * 1e-3 / n_l
+    if avg_s > 0:
+        roofline["per_launch_mfma_frac"] = conv_timed["flops"] / n_l / avg_s / 1e12 / peak_tflops
+        roofline["per_launch_hbm_frac"] = conv_timed["bytes"] / n_l / avg_s / 1e9 / PEAK_HBM_GBS
+        roofline["per_launch_frac"] = max(roofline["per_launch_mfma_frac"], roofline["per_launch_hbm_frac"])
+    roofline["hbm_peak_used"] = ("spec 8.0 TB/s (MI355X_MICROARCH.md); the copy rate tools/ubench/stream_bw reaches on this chip is %.1f TB/s, "
+                                 "the floor profiles/*_layer_bounds.md prices HBM-bound launches with" % (ACHIEVABLE_HBM_GBS / 1e3))
     return dt, post_ms, all_counts, roofline, {k: v["ms"] / 2 for k, v in cats.items()}
+
+
+def backbone_mfma_busy():
+    """north_star's own quantity -- SQ_VALU_MFMA_BUSY_CYCLES of the DETECTOR's conv kernels alone, duration-weighted -- cannot be counted inside
+    this process (PMC passes are separate rocprofv3 runs): the newest profiles/rNN_detector_only_mfma_util.md (tools/detector_only_mfma.sh) is quoted,
+    source named, like `traffic`."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_detector_only_mfma_util.md")), reverse=True):
+        with open(path) as f:
+            text = f.read()
+        m = re.search(r"duration-weighted: ([\d.]+) % MFMA busy", text)
+        if m:
+            out = {"backbone_mfma_busy": float(m.group(1)) / 100.0, "backbone_mfma_busy_src": "profiles/" + os.path.basename(path) +
+                   " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz), detector conv kernels only, 128 frames of 640 x 640)"}
+            m2 = re.search(r"at the measured shader clock of ([\d.]+) GHz: ([\d.]+) %", text)
+            if m2:
+                out["backbone_mfma_busy_at_measured_clock"] = float(m2.group(2)) / 100.0
+                out["measured_shader_clock_ghz"] = float(m2.group(1))
+            return out
+    return {"backbone_mfma_busy": None, "backbone_mfma_busy_src": None}
 
 
 def quick_point(wl, rank, local, dev, world, **kw):
@@ -534,13 +566,15 @@ def main():
     # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; tools/pmc_traffic.py stores the
     # per-launch figure of the same command under profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
     traffic, traffic_src = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if args.workload == "s640-bf16" and os.path.exists(tp):
             with open(tp) as f:
                 traffic, traffic_src = json.load(f)["conv_all"]["hbm_bytes_per_launch"], f"profiles/{rnd}_pmc_traffic.json"
             break
     dt, post_ms, all_counts, roofline, stage_ms = measure(st, args.warmup, args.steps, world, peak_tflops, traffic=traffic, traffic_src=traffic_src)
+    if args.workload == "s640-bf16":
+        roofline.update(backbone_mfma_busy())
 
     out = None
     if rank == 0:

@@ -16,6 +16,8 @@
 // bf16 path : v_mfma_f32_16x16x32_bf16, fp32 accumulate, one RNE rounding on store.
 // fp32 path : v_mfma_f32_16x16x4_f32 (exact fmaf chain) -- the tight-parity mode (SURVEY.md 8d ladder).
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <cstdlib>
 
 #include "vc_common.h"
@@ -36,7 +38,11 @@ namespace vc {
 // (nn.Upsample(None, 2, 'nearest') + Concat in front of C3.cv1 | cv2, YOLOv5 layers 11-13 and 15-17): the staged row of output pixel
 // (b, y, x) reads pixel (b, y / 2, x / 2) of p.in_up for K tiles below up_C and the concat buffer for the rest, so the upsampled map
 // is neither written nor read.  Same values in the same K order: bit-identical to upsample2x_kernel + this kernel.
-template <int BP, int BC, int WP, int WC, int KC, int NS, int PR, bool UP = false>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
+// SK (round 6, bf16): deterministic split-K for launches with too few output tiles to fill the chip (batch 1 .. 8: 16 workgroups walking
+// 72 K steps).  A work item is (output tile, K split s of p.ksplit): it multiplies K tiles [s nk / KS, (s + 1) nk / KS), stores its fp32
+// accumulators to p.sk_ws and takes a ticket of its tile; the workgroup that draws the LAST ticket adds the KS partial sums in split
+// order 0 .. KS - 1 (whichever workgroup arrives last: the same sum) and runs the epilogue.  No workgroup waits for another one.
+template <int BP, int BC, int WP, int WC, int KC, int NS, int PR, bool UP = false, bool SK = false>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
 __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p_arg) {
     ConvP p = p_arg;
     if (p_arg.m_dev) {                        // device-side problem size (uniform): fewer pixels, fewer tiles
@@ -78,6 +84,8 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     // workgroup share its XCD); each XCD gets a contiguous range of tiles so the channel tiles that share one pixel tile
     // hit the same private L2.
     const int ntiles = p.ntiles, G = gridDim.x;
+    const int KS = SK ? p.ksplit : 1;         // (uniform)
+    const int nitems = ntiles * KS;
     const int tiles_c = (p.Cout + BC - 1) / BC;
     const int tq = ntiles >> 3, tr = ntiles & 7;
 #define VC_TILE_OF(v) ((((v) & 7) < tr ? ((v) & 7) * (tq + 1) : tr * (tq + 1) + (((v) & 7) - tr) * tq) + ((v) >> 3))
@@ -98,7 +106,6 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
     const bool pointwise = p.kh == 1 && p.kw == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0;    // uniform
     const uint32_t tap_x = (uint32_t)(p.in_cs * ES), tap_y = (uint32_t)((p.W - p.kw + 1) * p.in_cs * ES);
-    const int nk = p.Kp / BK;
     // When Cin is a multiple of the K tile (every layer but the stems) a K tile lies inside ONE tap, the same for every
     // lane: the tap walk is then scalar state (SALU) instead of a divergent per-lane loop.
     const bool ut = (p.Cin % BK) == 0;
@@ -113,10 +120,15 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     unsigned long long xmask[XI];
     int kc_c = 0, kc_t = 0, kc_s = 0, u_tap = 0, u_s = 0, u_c = 0;
     uint32_t kc_off = 0, u_tapoff = 0;
-    int s_v = blockIdx.x, s_kt = 0, s_issued = 0;
+    int s_v = blockIdx.x, s_kt = 0, s_kt1 = 0, s_issued = 0;
+    const int nk = p.Kp / BK;
 #define VC_TILE_STATE(v)                                                                                                  \
-    if ((v) < ntiles) {                                                                                                   \
-        const int tile_ = VC_TILE_OF(v);                                                                                  \
+    if ((v) < nitems) {                                                                                                   \
+        const int tile_ = VC_TILE_OF(SK ? (v) / KS : (v));                                                                \
+        const int sp_ = SK ? (v) % KS : 0;                                                                                \
+        s_kt = SK ? sp_ * nk / KS : 0;                                                                                    \
+        s_kt1 = SK ? (sp_ + 1) * nk / KS : nk;                                                                            \
+        const int kst_ = s_kt * BK;           /* first K element of this item */                                           \
         const int sm0 = (tile_ / tiles_c) * BP, sn0 = (tile_ % tiles_c) * BC;                                              \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                                                  \
             const int m = sm0 + prow + PASS * i;                                                                          \
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
         }                                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) woff[i] = (uint32_t)(((sn0 + prow + PASS * i) * p.Kw + kc0 * CH) * ES); \
         {   /* (tap, c) of this thread's chunk and the tap's byte offset (r*W + s)*in_cs*ES, advanced by BK per K step */   \
-            const int k = kc0 * CH;                                                                                       \
+            const int k = kst_ + kc0 * CH;                                                                                \
             const int tap = k / p.Cin;                                                                                    \
             const int r = tap / p.kw;                                                                                     \
             kc_c = k - tap * p.Cin;                                                                                       \
@@ -169,7 +181,15 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             kc_off = (uint32_t)((r * p.W + kc_s) * p.in_cs * ES);                                                         \
         }                                                                                                                 \
         u_tap = 0; u_s = 0; u_c = 0; u_tapoff = 0;                                                                        \
+        if (SK && kst_ > 0) {                 /* (uniform) the scalar tap walk starts inside the K range */                \
+            const int tap = kst_ / p.Cin, r = tap / p.kw;                                                                 \
+            u_c = kst_ - tap * p.Cin;                                                                                     \
+            u_tap = min(tap, 63);                                                                                         \
+            u_s = tap - r * p.kw;                                                                                         \
+            u_tapoff = (uint32_t)((r * p.W + u_s) * p.in_cs * ES);                                                        \
+        }                                                                                                                 \
     } else {                                  /* no tile left: everything staged from here on is out of range (zeros) */   \
+        s_kt = 0; s_kt1 = nk;                                                                                             \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) { xmask[i] = 0ull; xoff[i] = 0; xoffl[i] = 0; }                    \
         _Pragma("unroll") for (int i = 0; i < WI; ++i) woff[i] = OOB;                                                     \
         kc_c = 0; kc_t = 0; kc_s = 0; kc_off = 0; u_tap = 0; u_s = 0; u_c = 0; u_tapoff = 0;                              \
@@ -215,8 +235,7 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
         kc_c = cc;                                                                                                       \
     }                                                                                                                    \
     ++s_issued;                                                                                                          \
-    if (++s_kt == nk) {                                                                                                  \
-        s_kt = 0;                                                                                                        \
+    if (++s_kt == s_kt1) {                                                                                               \
         s_v += G;                                                                                                        \
         VC_TILE_STATE(s_v);                                                                                              \
     }
@@ -251,15 +270,17 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
     VC_TS(2);
     int sbuf = NS - 1;
     uint32_t boff = lds_base;
-    for (int v = blockIdx.x; v < ntiles; v += G) {
-        const int tile = VC_TILE_OF(v);
+    for (int v = blockIdx.x; v < nitems; v += G) {
+        const int tile = VC_TILE_OF(SK ? v / KS : v);
+        const int split = SK ? v % KS : 0;
+        const int nk_item = SK ? (split + 1) * nk / KS - split * nk / KS : nk;
         const int m0 = (tile / tiles_c) * BP, n0 = (tile % tiles_c) * BC;
         f32x4 acc[CT][PT];
 #pragma unroll
         for (int a = 0; a < CT; ++a)
 #pragma unroll
             for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nk_item; ++kt) {
             VC_STAGE_NEXT(sbuf);                        // into the slot consumed last iteration (all waves passed its barrier)
             sbuf = sbuf + 1 == NS ? 0 : sbuf + 1;
             if constexpr (FP8) {
@@ -322,6 +343,36 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             boff = boff + STAGE_BYTES == lds_base + NS * STAGE_BYTES ? lds_base : boff + STAGE_BYTES;
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
             __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (SK) {
+            // partial sums out, ticket, and for the last arrival: all KS partial sums back in split order
+            constexpr int NT = NW * 64;
+            float* ws = p.sk_ws + (size_t)tile * KS * (CT * PT * NT * 4);
+            float* mine = ws + (size_t)split * (CT * PT * NT * 4);
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) *(f32x4*)(mine + ((a * PT + b) * NT + tid) * 4) = acc[a][b];
+            __threadfence();                              // release (agent scope): this thread's partial sums are visible before the ticket is drawn
+            __shared__ int sk_ticket;
+            __syncthreads();
+            if (tid == 0) sk_ticket = atomicAdd(p.sk_tickets + tile, 1);
+            __syncthreads();
+            const bool last = sk_ticket == KS - 1;        // (uniform)
+            if (!last) continue;
+            __threadfence();                              // acquire: the other workgroups' partial sums
+            if (tid == 0) atomicExch(p.sk_tickets + tile, 0);      // the tickets are zero again when the launch ends
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+#pragma unroll
+                for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < KS; ++sp) {
+                const float* part = ws + (size_t)sp * (CT * PT * NT * 4);
+#pragma unroll
+                for (int a = 0; a < CT; ++a)
+#pragma unroll
+                    for (int b = 0; b < PT; ++b) acc[a][b] += __builtin_nontemporal_load((const f32x4*)(part + ((a * PT + b) * NT + tid) * 4));
+            }
         }
         // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]; the next tile's first K tiles are already in flight
         if constexpr (FP8) conv_epilogue_fp8<PT, CT>(p, acc, m0 + wp * WTP, n0 + wc * WTC + fch * 4, frow);
@@ -1133,7 +1184,9 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 // weights-in-LDS streaming 1x1 (bf16): S(index, CT, KS, PT, NP): 128 -> 128, 256 -> 256, 256 -> 128, 128 -> 256 channels; NP passes over the
 // block's fragments, each for CT / NP channel tiles, keep accumulators + fragments + epilogue inside 256 registers at two waves per SIMD
 #define VC_STREAM_CFGS(S) S(50, 8, 4, 4, 2) S(51, 16, 8, 2, 2) S(52, 8, 8, 2, 1) S(53, 16, 4, 2, 2) S(54, 8, 4, 2, 1)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54) and conv3x3_halo_v2_kernel (55)
+// split-K instances of the implicit GEMM (bf16, round 6): K(index, BP, BC, WP, WC, KC, NS); offered when the tiles alone cannot fill the chip
+#define VC_SK_CFGS(K) K(56, 64, 64, 2, 2, 8, 3) K(57, 64, 64, 2, 2, 8, 4) K(58, 128, 64, 2, 2, 8, 3) K(59, 64, 128, 1, 4, 8, 3)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55) and the split-K tiles (56-59)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1202,6 +1255,50 @@ static int launch_one(ConvP p, hipStream_t s) {
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
         launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     }
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
+// Split-K workspace: fp32 partial sums + one ticket per output tile, one set per stream (launches of one stream are ordered; the detector's and
+// the ReID net's streams run side by side).  Tickets are zeroed once: the kernel leaves them at zero.
+struct SkWorkspace { float* ws = nullptr; int* tickets = nullptr; };
+static constexpr size_t SK_WS_BYTES = 32u << 20;
+static constexpr int SK_MAX_TILES = 16384;
+static int sk_workspace(hipStream_t s, SkWorkspace* out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SkWorkspace> table;
+    int dev = 0;
+    VC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    SkWorkspace& w = table[{dev, s}];
+    if (!w.ws) {
+        VC_HIP(hipMalloc((void**)&w.ws, SK_WS_BYTES));
+        VC_HIP(hipMalloc((void**)&w.tickets, sizeof(int) * SK_MAX_TILES));
+        VC_HIP(hipMemset(w.tickets, 0, sizeof(int) * SK_MAX_TILES));
+    }
+    *out = w;
+    return VC_OK;
+}
+
+template <int BP, int BC, int WP, int WC, int KC, int NS>
+static int launch_one_sk(ConvP p, hipStream_t s) {
+    if (p.prec != PREC_BF16 || p.in_up || p.m_dev) return VC_ERR_ARG;      // quietly: the autotuner skips it
+    const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
+    const int bk = KC * 8;
+    p.Kw = p.Kp;
+    p.Kp = (p.K + bk - 1) / bk * bk;
+    p.ntiles = tiles;
+    const int nk = p.Kp / bk;
+    static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, true>, WP * WC * 64);
+    // worth it only when the tiles leave most of the chip idle and every split still walks a few K tiles
+    constexpr size_t item_bytes = (size_t)BP * BC * 4;
+    int ks = std::min(std::min(slots_hw / std::max(tiles, 1), nk / 2), 16);
+    ks = std::min<long>(ks, (long)(SK_WS_BYTES / (item_bytes * (size_t)std::max(tiles, 1))));
+    if (ks < 2 || tiles > SK_MAX_TILES) return VC_ERR_ARG;
+    SkWorkspace w;
+    VC_TRY(sk_workspace(s, &w));
+    p.ksplit = ks; p.sk_ws = w.ws; p.sk_tickets = w.tickets;
+    launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, true>, dim3(tiles * ks), dim3(WP * WC * 64), 0, s, p);
     VC_HIP(hipGetLastError());
     return VC_OK;
 }
@@ -1355,6 +1452,9 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
         VC_CONV_CFGS(VC_X)
         VC_CONV_BIG_CFGS(VC_X)
 #undef VC_X
+#define VC_K(i, bp, bc, wp, wc, kc, ns) case i: return launch_one_sk<bp, bc, wp, wc, kc, ns>(p, s);
+        VC_SK_CFGS(VC_K)
+#undef VC_K
     }
     return VC_ERR_ARG;
 }

@@ -168,6 +168,10 @@ struct ConvP {
     // [B][H/2][W/2] tensor (channel stride up_cs, offset up_co) instead of channels [in_co, in_co + up_C) of `in` (Upsample + Concat folded in)
     const void* in_up;
     int up_C, up_cs, up_co;
+    // split-K (conv_igemm_kernel<..., SK>, set by its launcher): K splits per output tile, fp32 partial sums [tile][split][...], one ticket per tile
+    int ksplit;
+    float* sk_ws;
+    int* sk_tickets;
     long long* dbg;      // diagnostics only (VC_CONV_DBG): per-workgroup phase timestamps [tiles][8], 100 MHz clock; null in production
     int s2_th, s2_tw;    // set by the launcher of conv3x3s2_halo_kernel: its output tile rectangle (rows x columns)
     int slots;           // tests only: > 0 forces the persistent grid to this many workgroups (long tile walks); set by vc_conv2d_host from
