@@ -1282,7 +1282,8 @@ static int sk_workspace(hipStream_t s, SkWorkspace* out) {
 
 template <int BP, int BC, int WP, int WC, int KC, int NS>
 static int launch_one_sk(ConvP p, hipStream_t s) {
-    if (p.prec != PREC_BF16 || p.in_up || p.m_dev) return VC_ERR_ARG;      // quietly: the autotuner skips it
+    static const bool enabled = !(getenv("VC_CONV_SK") && atoi(getenv("VC_CONV_SK")) == 0);     // (A/B switch)
+    if (!enabled || p.prec != PREC_BF16 || p.in_up || p.m_dev) return VC_ERR_ARG;      // quietly: the autotuner skips it
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const int bk = KC * 8;
     p.Kw = p.Kp;
@@ -1467,7 +1468,7 @@ int launch_conv(const ConvP& p, hipStream_t s) {
     // A tuned choice is keyed by the power-of-two bucket of M, but some families' applicability depends on the exact batch (v2_applicable:
     // whole rows per tile; the upsample fold-in's tile subset): a launcher refuses before it launches anything, and the heuristic's
     // implicit-GEMM tile takes every shape conv_check admits.
-    if (rc == VC_ERR_ARG && p.cfg >= 0 && p.cfg < conv_num_cfgs()) return launch_conv_cfg(p, -1, s);
+    if (rc == VC_ERR_ARG && p.cfg >= 0 && p.cfg < conv_num_cfgs() && !getenv("VC_CONV_STRICT")) return launch_conv_cfg(p, -1, s);   // (VC_CONV_STRICT: the tile-configuration tests want the refusal)
     return rc;
 }
 
