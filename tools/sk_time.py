@@ -16,7 +16,7 @@ CASES = {
     "reid 3x3 128->128 13x13 x 18 crops (M 3042, K 1152)": (18, 13, 13, 128, 128, 3, 1, 1),
     "det 3x3 256->256 20x20 x 8 frames (M 3200)": (8, 20, 20, 256, 256, 3, 1, 1),
 }
-CFGS = [-1, 3, 6, 15, 16, 18, 36, 37, 30, 55, 56, 57, 58, 59]
+CFGS = [6, 15, 16, 36, 37, 56, 57, 58, 59, 60, 61, 62, 63]
 CHILD = """
 import sys, numpy as np
 sys.path.insert(0, %r)

@@ -345,23 +345,27 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             __builtin_amdgcn_s_barrier();
         }
         if constexpr (SK) {
-            // partial sums out, ticket, and for the last arrival: all KS partial sums back in split order
+            // Partial sums out, ticket, and for the last arrival: all KS partial sums back in split order.  The hand-over crosses XCDs (each
+            // has its own L2), but a release / acquire FENCE at agent scope writes back and invalidates a whole L2 (measured: the split
+            // launches ran 3 - 8 x slower than the unsplit ones).  Instead the partial sums themselves travel with agent-scope atomic
+            // stores / loads (sc1: write-through / cache-bypassing dword accesses), ordered against the ticket by the VM counter.
             constexpr int NT = NW * 64;
             float* ws = p.sk_ws + (size_t)tile * KS * (CT * PT * NT * 4);
             float* mine = ws + (size_t)split * (CT * PT * NT * 4);
 #pragma unroll
             for (int a = 0; a < CT; ++a)
 #pragma unroll
-                for (int b = 0; b < PT; ++b) *(f32x4*)(mine + ((a * PT + b) * NT + tid) * 4) = acc[a][b];
-            __threadfence();                              // release (agent scope): this thread's partial sums are visible before the ticket is drawn
+                for (int b = 0; b < PT; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __hip_atomic_store(mine + (((a * PT + b) * 4 + j) * NT + tid), acc[a][b][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's partial sums have reached memory
             __shared__ int sk_ticket;
-            __syncthreads();
-            if (tid == 0) sk_ticket = atomicAdd(p.sk_tickets + tile, 1);
+            __syncthreads();                                      // ... and every other thread's of the workgroup
+            if (tid == 0) sk_ticket = __hip_atomic_fetch_add(p.sk_tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const bool last = sk_ticket == KS - 1;        // (uniform)
             if (!last) continue;
-            __threadfence();                              // acquire: the other workgroups' partial sums
-            if (tid == 0) atomicExch(p.sk_tickets + tile, 0);      // the tickets are zero again when the launch ends
+            if (tid == 0) __hip_atomic_store(p.sk_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the tickets are zero again when the launch ends
 #pragma unroll
             for (int a = 0; a < CT; ++a)
 #pragma unroll
@@ -371,7 +375,9 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
 #pragma unroll
                 for (int a = 0; a < CT; ++a)
 #pragma unroll
-                    for (int b = 0; b < PT; ++b) acc[a][b] += __builtin_nontemporal_load((const f32x4*)(part + ((a * PT + b) * NT + tid) * 4));
+                    for (int b = 0; b < PT; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[a][b][j] += __hip_atomic_load(part + (((a * PT + b) * 4 + j) * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]; the next tile's first K tiles are already in flight
@@ -1184,9 +1190,12 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 // weights-in-LDS streaming 1x1 (bf16): S(index, CT, KS, PT, NP): 128 -> 128, 256 -> 256, 256 -> 128, 128 -> 256 channels; NP passes over the
 // block's fragments, each for CT / NP channel tiles, keep accumulators + fragments + epilogue inside 256 registers at two waves per SIMD
 #define VC_STREAM_CFGS(S) S(50, 8, 4, 4, 2) S(51, 16, 8, 2, 2) S(52, 8, 8, 2, 1) S(53, 16, 4, 2, 2) S(54, 8, 4, 2, 1)
+// deep rings on the small tiles (round 6): a launch of 28 workgroups walking 36 K steps is bound by the latency of its LDS-DMA loads (~1.2 us from
+// L2 / HBM on an otherwise idle chip) divided by the tiles in flight; six or eight stages instead of three
+#define VC_CONV_DEEP_CFGS(X) X(60, 64, 64, 2, 2, 8, 6) X(61, 64, 64, 2, 2, 8, 8) X(62, 128, 64, 2, 2, 8, 6) X(63, 64, 128, 1, 4, 8, 6)
 // split-K instances of the implicit GEMM (bf16, round 6): K(index, BP, BC, WP, WC, KC, NS); offered when the tiles alone cannot fill the chip
 #define VC_SK_CFGS(K) K(56, 64, 64, 2, 2, 8, 3) K(57, 64, 64, 2, 2, 8, 4) K(58, 128, 64, 2, 2, 8, 3) K(59, 64, 128, 1, 4, 8, 3)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55) and the split-K tiles (56-59)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59) and the deep rings (60-63)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1293,7 +1302,10 @@ static int launch_one_sk(ConvP p, hipStream_t s) {
     static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, true>, WP * WC * 64);
     // worth it only when the tiles leave most of the chip idle and every split still walks a few K tiles
     constexpr size_t item_bytes = (size_t)BP * BC * 4;
-    int ks = std::min(std::min(slots_hw / std::max(tiles, 1), nk / 2), 16);
+    // (measured, tools/sk_time.py: a K step of a 64 x 64 tile costs ~0.43 us -- LDS-DMA issue, not latency: rings of 6 / 8 stages, configurations
+    // 60 - 63, change nothing -- a launch ~6 us whatever its size, and the last arrival reads the KS partial sums one memory latency after the
+    // other: splits of at least four K steps, at most eight of them)
+    int ks = std::min(std::min(slots_hw / std::max(tiles, 1), nk / 4), 8);
     ks = std::min<long>(ks, (long)(SK_WS_BYTES / (item_bytes * (size_t)std::max(tiles, 1))));
     if (ks < 2 || tiles > SK_MAX_TILES) return VC_ERR_ARG;
     SkWorkspace w;
@@ -1452,6 +1464,7 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #define VC_X(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns>(p, s);
         VC_CONV_CFGS(VC_X)
         VC_CONV_BIG_CFGS(VC_X)
+        VC_CONV_DEEP_CFGS(VC_X)
 #undef VC_X
 #define VC_K(i, bp, bc, wp, wc, kc, ns) case i: return launch_one_sk<bp, bc, wp, wc, kc, ns>(p, s);
         VC_SK_CFGS(VC_K)
