@@ -67,11 +67,12 @@ def test_tune_import_reaches_plans_that_have_run():
     a.detect(imgs)                                                  # plans built, every op's choice resolved
     before = cfgs(a)
     text = a.tune_export()
-    # every 3 x 3 / s1 layer that chose a halo-staged kernel is sent to the implicit GEMM (configuration 2) instead
+    # every 3 x 3 / s1 layer that chose anything but the 128 x 128 implicit GEMM (configuration 2: a halo-staged kernel, a split-K tile at this
+    # small batch) is sent there instead
     lines, changed = [], 0
     for l in text.strip().splitlines():
         k, c = l.split()
-        if "_k3x3_s1_" in k and int(c) in (28, 29, 30, 31, 36, 37, 38, 39, 55):
+        if "_k3x3_s1_" in k and int(c) != 2:
             c, changed = "2", changed + 1
         lines.append(f"{k} {c}")
     assert changed > 0

@@ -19,7 +19,7 @@ SK_CASES = [
     (3, 4, 4, 512, 512, 3, 1, 1, 2, 0),         # ReID layer4: M = 48, K = 4608
     (1, 20, 20, 1024, 512, 1, 1, 0, 1, 0),      # SPPF.cv2: pointwise, K = 1024
     (1, 40, 40, 128, 256, 3, 2, 1, 1, 0),       # stride 2
-    (1, 9, 7, 24, 72, 3, 1, 1, 0, 0),           # Cin not a multiple of the K tile (per-lane tap walk), ragged pixel and channel tails, no activation
+    (1, 9, 7, 24, 72, 5, 1, 2, 0, 0),           # Cin not a multiple of the K tile (per-lane tap walk starting inside the K range), 5 x 5, ragged tails, no activation
     (1, 20, 20, 512, 255, 1, 1, 0, 0, 0),       # Detect head: Cout not a multiple of 4
 ]
 
@@ -43,3 +43,23 @@ def test_split_k_tiles(case, cfg, monkeypatch):
     np.testing.assert_array_equal(y[0], y[2])
     monkeypatch.setenv("VC_CONV_CFG", "15")                       # the same tile without the split: equal up to the order of the fp32 sums
     np.testing.assert_allclose(E.conv2d(x, w, b, stride=s, pad=p, act=act, res=res, res_mode=rm, precision="bf16"), y[0], rtol=2 ** -7, atol=2e-3)
+
+
+def test_split_k_workspace_reuse_is_clean(monkeypatch):
+    """The split-K workspace is one allocation per stream that every split-K launch reuses: the same two convolutions with different
+    data, alternating 150 times, must give their own bits every time (a partial sum read from a stale cache line of the other
+    launch would not)."""
+    B, H, W, Ci, Co, k = 2, 7, 7, 256, 256, 3
+    rng = np.random.default_rng(7)
+    data = []
+    for _ in range(2):
+        x = rng.standard_normal((B, H, W, Ci), dtype=np.float32)
+        w = (rng.standard_normal((Co, Ci, k, k), dtype=np.float32) / np.sqrt(Ci * k * k)).astype(np.float32)
+        data.append((x, w, rng.standard_normal(Co, dtype=np.float32) * 0.1))
+    monkeypatch.setenv("VC_CONV_CFG", "57")
+    monkeypatch.setenv("VC_CONV_STRICT", "1")
+    first = [E.conv2d(x, w, b, stride=1, pad=1, act=1, precision="bf16") for x, w, b in data]
+    assert not np.array_equal(first[0], first[1])
+    for it in range(150):
+        for i, (x, w, b) in enumerate(data):
+            np.testing.assert_array_equal(E.conv2d(x, w, b, stride=1, pad=1, act=1, precision="bf16"), first[i], err_msg=f"iteration {it}, case {i}")

@@ -1281,8 +1281,14 @@ static int sk_workspace(hipStream_t s, SkWorkspace* out) {
     std::lock_guard<std::mutex> lk(mu);
     SkWorkspace& w = table[{dev, s}];
     if (!w.ws) {
-        VC_HIP(hipMalloc((void**)&w.ws, SK_WS_BYTES));
-        VC_HIP(hipMalloc((void**)&w.tickets, sizeof(int) * SK_MAX_TILES));
+        static const bool uncached = !(getenv("VC_SK_UNCACHED") && atoi(getenv("VC_SK_UNCACHED")) == 0);      // (A/B switch)
+        if (uncached) {       // memory no XCD's L2 keeps a copy of: the hand-over between workgroups of different XCDs cannot meet a stale line
+            VC_HIP(hipExtMallocWithFlags((void**)&w.ws, SK_WS_BYTES, hipDeviceMallocUncached));
+            VC_HIP(hipExtMallocWithFlags((void**)&w.tickets, sizeof(int) * SK_MAX_TILES, hipDeviceMallocUncached));
+        } else {
+            VC_HIP(hipMalloc((void**)&w.ws, SK_WS_BYTES));
+            VC_HIP(hipMalloc((void**)&w.tickets, sizeof(int) * SK_MAX_TILES));
+        }
         VC_HIP(hipMemset(w.tickets, 0, sizeof(int) * SK_MAX_TILES));
     }
     *out = w;
