@@ -14,6 +14,8 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
 cd $R
 python tools/prof_summary.py $(find $OUT/trace -name "*.db" | head -1) "VC_B=128 VC_INJECT=0 VC_OBJ_SHIFT=-8 rocprofv3 --kernel-trace --stats -- python tools/conv_breakdown.py (detector only: the head finds nothing, the ReID net never runs)" > $OUT/kernel_stats.md
 python tools/pmc_summary.py $(find $OUT/mfma -name "*.db" | head -1) vc:: > $OUT/pmc_mfma.txt 2>&1
-python tools/mfma_util.py $OUT/pmc_mfma.txt $OUT/kernel_stats.md > $OUT/mfma_util.md 2>&1
+GHZ=""
+if [ -x tools/ubench/clock_probe ]; then tools/ubench/clock_probe 5000 > $OUT/clock_probe.txt 2>&1; GHZ=$(grep "MFMA + exp + rcp" $OUT/clock_probe.txt | sed -E 's/.*shader clock ([0-9.]+) GHz.*/\1/'); fi
+python tools/mfma_util.py $OUT/pmc_mfma.txt $OUT/kernel_stats.md $GHZ > $OUT/mfma_util.md 2>&1
 rm -rf $OUT/trace $OUT/mfma
 tail -25 $OUT/mfma_util.md

@@ -30,3 +30,6 @@ for k in sorted(busy, key=lambda k: -busy[k]):
     tb += busy[k] / 1024; td += n[k] * d[2] * 1e-6 * CLOCK_GHZ * 1e9
     print(f"| `{k}` | {n[k]} | {per:,.0f} | {d[2]:.1f} | {100 * util:.1f} % |")
 print(f"\nall conv launches, duration-weighted: {100 * tb / td:.1f} % MFMA busy")
+if len(sys.argv) > 3:      # tools/ubench/clock_probe: the shader clock the chip holds under an MFMA + transcendental load (2.4 GHz is the peak clock)
+    ghz = float(sys.argv[3])
+    print(f"at the measured shader clock of {ghz:.2f} GHz: {100 * tb / td * CLOCK_GHZ / ghz:.1f} % (the same busy cycles over the cycles that actually elapsed)")
