@@ -36,6 +36,7 @@ import vehicle_counting_amd.engine as E  # noqa: E402
 from vehicle_counting_amd import _lib as L  # noqa: E402
 from vehicle_counting_amd import parallel  # noqa: E402
 from vehicle_counting_amd.counting import NativeCounter, count_directions, csv_records  # noqa: E402
+from vehicle_counting_amd.coded import coded_frames, coded_yolo  # noqa: E402
 from vehicle_counting_amd.synth import synth_frames, synth_tracks  # noqa: E402
 from vehicle_counting_amd.track import VideoCounting  # noqa: E402
 from vehicle_counting_amd.weights import synth_reid, synth_yolo  # noqa: E402
@@ -149,7 +150,7 @@ def injected_detections(n_frames, hw, n_obj, seed):
 class Stream:
     """One camera stream on one engine: the three overlapped stages of the fused path."""
 
-    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1, frame_hw=None, zone=None, distinct_cams=False):
+    def __init__(self, wl, rank, local, dev, n_obj=None, inject=None, B=None, clip=None, precision=None, n_cam=1, frame_hw=None, zone=None, distinct_cams=False, coded=False):
         wl = dict(wl, precision=precision or wl["precision"])
         self.wl, self.dev = wl, dev
         self.B = B or wl["B"]
@@ -159,7 +160,9 @@ class Stream:
         inject = wl["inject"] if inject is None else inject
         clip = clip or wl["clip"]
         clip = max(self.B, clip // self.B * self.B)                  # whole batches, so a batch is one contiguous run of frames
-        self.ysd = synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
+        # coded: the well-conditioned detector of vehicle_counting_amd/coded.py on its plate-carrying clip -- the detector's OWN boxes (no
+        # injection) are exactly one per object, in every precision (tests/test_gpu_coded.py holds this configuration to the oracle's CSV)
+        self.ysd = coded_yolo(wl["model"], nc=NC) if coded else synth_yolo(wl["model"], nc=NC, seed=1702, det_scale=wl.get("det_scale", 4.0), obj_shift=wl["obj_shift"])
         self.rsd = synth_reid(1702)
         per_frame = max(160 if distinct_cams else 64, 2 * max(inject, n_obj))
         max_crops = max(512, self.B * per_frame)                     # (small batches: a single busy frame of the random head can carry > 64 boxes)
@@ -178,7 +181,8 @@ class Stream:
         self.trackers = [[self.eng.tracker_create(**TRACK) for _ in range(NC)] for _ in range(n_cam)]
         # every camera shows the rank's clip (same content, independent trackers): the point stays comparable with the single-camera
         # headline -- other seeds draw 4 x more boxes from the random head
-        one = synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True)
+        one = (coded_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank, size=wl["size"])[0] if coded else
+               synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank, bounce=True))
         per_cam = [one] * n_cam
         if distinct_cams:                                            # eight different scenes (other seeds: other objects, and more boxes from the random head)
             per_cam = [one] + [synth_frames(clip // n_cam, self.H, self.W, n_obj=n_obj, seed=1702 + rank + 101 * c, bounce=True) for c in range(1, n_cam)]
@@ -608,6 +612,10 @@ def main():
             # BASELINE.json configs[2] and configs[4], short runs of `--workload m1024-bf16` / `--workload l1280-fp8`
             "m1024_bf16": qp(WORKLOADS["m1024-bf16"], steps=4, warmup=2, full=True),
             "l1280_fp8": qp(WORKLOADS["l1280-fp8"], steps=6, warmup=2, full=True),
+            # the same two precisions on the well-conditioned detector, its own detections all the way (no injection): the configuration
+            # tests/test_gpu_coded.py holds to the oracle's CSV
+            "s640_bf16_coded": qp(coded=True, inject=0, clip=256, steps=12, warmup=3, full=True),
+            "l1280_fp8_coded": qp(WORKLOADS["l1280-fp8"], coded=True, inject=0, n_obj=12, steps=6, warmup=2, full=True),
             # BASELINE.json configs[3]'s 8 cameras on ONE GPU: 8 x 16 frames interleaved in every 128-frame batch (vc_stream_run_async_multi)
             "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True),
             "s640_8cam_distinct_clips": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True, distinct_cams=True),
