@@ -370,14 +370,27 @@ __global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP
             for (int a = 0; a < CT; ++a)
 #pragma unroll
                 for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int sp = 0; sp < KS; ++sp) {
-                const float* part = ws + (size_t)sp * (CT * PT * NT * 4);
+            // four splits' partial sums are requested together (64 - 128 loads in flight per lane: one memory latency per group instead of one per
+            // split -- the reads were the larger half of a split launch's time), then added in split order; a split past KS reads split
+            // KS - 1 again and is not added
+            for (int s0 = 0; s0 < KS; s0 += 4) {
+                float v[4][CT * PT * 4];
 #pragma unroll
-                for (int a = 0; a < CT; ++a)
+                for (int u = 0; u < 4; ++u) {
+                    const float* part = ws + (size_t)min(s0 + u, KS - 1) * (CT * PT * NT * 4);
 #pragma unroll
-                    for (int b = 0; b < PT; ++b)
+                    for (int i = 0; i < CT * PT * 4; ++i) v[u][i] = __hip_atomic_load(part + (i * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[a][b][j] += __hip_atomic_load(part + (((a * PT + b) * 4 + j) * NT + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = s0 + u < KS;              // (uniform)
+#pragma unroll
+                    for (int a = 0; a < CT; ++a)
+#pragma unroll
+                        for (int b = 0; b < PT; ++b)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[a][b][j] = on ? acc[a][b][j] + v[u][(a * PT + b) * 4 + j] : acc[a][b][j];
+                }
             }
         }
         // epilogue: D[channel = (lane>>4)*4 + reg][pixel = lane&15]; the next tile's first K tiles are already in flight
