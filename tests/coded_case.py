@@ -16,6 +16,8 @@ CASES = {
     "s640": dict(variant="yolov5s", size=640, H=640, W=640, T=64, n_obj=12, seed=1702, zone="cam_04_halfres.json"),
     # the reference's only real geometry: 1280 x 720 frames -> 384 x 640 tensor (Q8), the reference's own zone file's directions
     "s720p": dict(variant="yolov5s", size=640, H=720, W=1280, T=64, n_obj=12, seed=1702, zone="cam_04.json"),
+    # BASELINE.json configs[2]: YOLOv5m, 1024 x 1024 frames
+    "m1024": dict(variant="yolov5m", size=1024, H=1024, W=1024, T=24, n_obj=12, seed=1702, zone="cam_04.json"),
     # BASELINE.json configs[4]: YOLOv5l, 1280 x 1280 frames (the fp8 engine's case)
     "l1280": dict(variant="yolov5l", size=1280, H=1280, W=1280, T=24, n_obj=12, seed=1702, zone="cam_04.json"),
 }
