@@ -42,8 +42,11 @@ namespace vc {
 // 72 K steps).  A work item is (output tile, K split s of p.ksplit): it multiplies K tiles [s nk / KS, (s + 1) nk / KS), stores its fp32
 // accumulators to p.sk_ws and takes a ticket of its tile; the workgroup that draws the LAST ticket adds the KS partial sums in split
 // order 0 .. KS - 1 (whichever workgroup arrives last: the same sum) and runs the epilogue.  No workgroup waits for another one.
-template <int BP, int BC, int WP, int WC, int KC, int NS, int PR, bool UP = false, bool SK = false>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
-__global__ __launch_bounds__(WP * WC * 64, 1) void conv_igemm_kernel(const ConvP p_arg) {
+// OCC (round 6, configurations 64 - 66): workgroups per CU the register allocation is bounded for.  Two 8-wave workgroups on one CU share no
+// barrier: while one is in its epilogue (SiLU + stores, no loads issued, no MFMA) the other is in its K loop -- the phases a single 16-wave
+// workgroup runs one after the other overlap across the pair.  (HIP: the second launch-bound is WAVES per SIMD, hence OCC * waves / 4.)
+template <int BP, int BC, int WP, int WC, int KC, int NS, int PR, bool UP = false, bool SK = false, int OCC = 1>       // PR: PREC_BF16, PREC_F32 or PREC_FP8
+__global__ __launch_bounds__(WP * WC * 64, OCC == 1 ? 1 : OCC * WP * WC / 4) void conv_igemm_kernel(const ConvP p_arg) {
     ConvP p = p_arg;
     if (p_arg.m_dev) {                        // device-side problem size (uniform): fewer pixels, fewer tiles
         const int mm = min(p_arg.M, *p_arg.m_dev);
@@ -1208,7 +1211,9 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #define VC_CONV_DEEP_CFGS(X) X(60, 64, 64, 2, 2, 8, 6) X(61, 64, 64, 2, 2, 8, 8) X(62, 128, 64, 2, 2, 8, 6) X(63, 64, 128, 1, 4, 8, 6)
 // split-K instances of the implicit GEMM (bf16, round 6): K(index, BP, BC, WP, WC, KC, NS); offered when the tiles alone cannot fill the chip
 #define VC_SK_CFGS(K) K(56, 64, 64, 2, 2, 8, 3) K(57, 64, 64, 2, 2, 8, 4) K(58, 128, 64, 2, 2, 8, 3) K(59, 64, 128, 1, 4, 8, 3)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59) and the deep rings (60-63)
+// paired 8-wave workgroups, two per CU (round 6, conv_igemm_kernel<..., OCC = 2>): P(index, BP, BC, WP, WC, KC, NS)
+#define VC_PAIR_CFGS(P) P(64, 256, 128, 4, 2, 4, 3) P(65, 128, 256, 2, 4, 4, 3) P(66, 256, 128, 4, 2, 4, 2)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4 + 3; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59), the deep rings (60-63) and the paired 8-wave workgroups (64-66)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1230,8 +1235,9 @@ static int resident_workgroups(K kernel, int threads = 256) {
     return per_cu * cus;
 }
 
-template <int BP, int BC, int WP, int WC, int KC, int NS>
+template <int BP, int BC, int WP, int WC, int KC, int NS, int OCC = 1>
 static int launch_one(ConvP p, hipStream_t s) {
+    if (OCC != 1 && (p.prec != PREC_BF16 || p.in_up)) return VC_ERR_ARG;      // quietly: the paired-workgroup tiles exist for plain bf16 only
     const int tiles = ((p.M + BP - 1) / BP) * ((p.Cout + BC - 1) / BC);
     const int bk = KC * (p.prec == PREC_F32 ? 4 : p.prec == PREC_FP8 ? 16 : 8);
     p.Kw = p.Kp;                              // weight row stride as packed
@@ -1245,6 +1251,9 @@ static int launch_one(ConvP p, hipStream_t s) {
     // 0 / 32 / 64 / 96 / 128 free slots = 14.9 / 15.1 / 15.6 / 15.6 / 15.4 k frames/s; 256 free slots cost 9 % of conv time).
     static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
     if (p.in_up && p.prec != PREC_BF16) return VC_ERR_ARG;        // (conv_check refuses it with a message)
+    bool handled = false;
+    if constexpr (OCC == 1) {
+    handled = p.prec == PREC_F32 || p.prec == PREC_FP8 || p.in_up;
     if (p.prec == PREC_F32) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
@@ -1271,11 +1280,13 @@ static int launch_one(ConvP p, hipStream_t s) {
         } else {
             return VC_ERR_ARG;                                       // quietly: the autotuner skips it
         }
-    } else {
-        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, WP * WC * 64);
+    }
+    }
+    if (!handled) {
+        static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, false, OCC>, WP * WC * 64);
         const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
         const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
-        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
+        launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, false, OCC>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     }
     VC_HIP(hipGetLastError());
     return VC_OK;
@@ -1488,6 +1499,9 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #define VC_K(i, bp, bc, wp, wc, kc, ns) case i: return launch_one_sk<bp, bc, wp, wc, kc, ns>(p, s);
         VC_SK_CFGS(VC_K)
 #undef VC_K
+#define VC_P(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns, 2>(p, s);
+        VC_PAIR_CFGS(VC_P)
+#undef VC_P
     }
     return VC_ERR_ARG;
 }
