@@ -707,12 +707,35 @@ __device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, c
     if (prof && lane == 0) prof[1] = wall_clock64();
     auto app_at = [&](int t, int d) { return cost_app[(size_t)t * D + d]; };
     auto iou_at = [&](int t, int d) { return cost_iou[(size_t)t * D + d]; };
+    // Stale levels.  A confirmed track that missed its last frames usually has no detection of the step within the threshold (its object
+    // has left; the gate turned its whole row into VC_GATED).  If that holds for EVERY track of a level, the level's clamped matrix is
+    // constant, SciPy pairs row i with column i, every pair is rejected and min_cost_matching's lists come out with the first
+    // min(nl, n_left) columns moved behind the others (min_cost_matching above, the same shortcut on the gathered matrix): nothing is
+    // matched and `left` is rotated by nl when nl < n_left, unchanged otherwise.  Such a level costs a ballot here instead of a cost
+    // load, a wave reduction and the list exchange (~1.3 us each, 15 - 20 of them per step in a crowded tracker); rotations of successive
+    // stale levels add up and are applied once, in front of the next level that has to look at `left`.
+    bool adm = false;
+    if (conf && tsu >= 2)
+        for (int d = 0; d < D; ++d) adm = adm || !(cost_app[(size_t)lane * D + d] > h.max_dist);
+    int rot = 0;                                             // pending rotation: the list is left[(p + rot) % n_left]
+    auto settle = [&]() {
+        if (rot != 0) {
+            const int src = lane < n_left ? (lane + rot >= n_left ? lane + rot - n_left : lane + rot) : lane;
+            left = __shfl(left, src);
+            rot = 0;
+        }
+    };
     // matching_cascade (linear_assignment.py:80-145): level = time_since_update - 1, most recently seen tracks first
     for (int level = 0; level < n_levels && n_left > 0; ++level) {
         const unsigned long long rm = __ballot(conf && tsu == 1 + level);
         if (rm == 0) continue;
         const int nl = __popcll(rm), rank = __popcll(rm & lt);
         const bool in = (rm >> lane) & 1ull;
+        if (level >= 1 && __ballot(in && adm) == 0) {            // (adm is known for time_since_update >= 2, i.e. from level 1 on)
+            if (nl < n_left) { rot += nl; if (rot >= n_left) rot -= n_left; }
+            continue;
+        }
+        settle();
         if (nl == 1 || n_left == 1) {
             // One track in the level, or one detection left (most levels of a light scene): the assignment is the minimum of a
             // vector, smallest index among equal minima (SciPy's scan keeps the LAST unassigned minimum of a list that holds the
@@ -759,6 +782,7 @@ __device__ __forceinline__ void match_step_wave64(int lane, const StepWork& w, c
         if (in && mine) matched = true;
         left = un_cols; n_left = n_uc;
     }
+    settle();
     if (prof && lane == 0) prof[2] = wall_clock64();
     // IoU stage (tracker.py:118-127): unconfirmed tracks, then the confirmed tracks missed for exactly one frame
     const unsigned long long um = __ballot(lane < T && !conf), rcm = __ballot(conf && !matched && tsu == 1), unm = __ballot(conf && !matched && tsu != 1);

@@ -395,6 +395,17 @@ __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, co
         while ((1 << sh) < nd) ++sh;
         const int DL = 1 << sh, SL = 64 >> sh, dl = lane & (DL - 1), sg = lane >> sh;
         const bool ok = dl < nd;
+        // The Mahalanobis gate first (linear_assignment.py:148-192): a track whose object has left the scene -- most tracks of a crowded
+        // tracker between their last match and max_age -- gates every detection out, and its row is VC_GATED without the two dependent
+        // memory round trips (ring -> table rows) below.  The values written are the same either way.
+        const bool mine = ok && sg == 0;
+        const int g = jb.det_off + d0 + dl;
+        double g2 = 0.0;
+        if (mine) g2 = maha4(m, Lc, a.det_xyah + (size_t)g * 4);
+        if (!__any(mine && !(g2 > VC_CHI2_95_4))) {
+            if (mine) out[jb.out_off + d0 + dl] = VC_GATED;
+            continue;
+        }
         const int* grow = a.gal_row + (size_t)jb.slot * SC;
         const float* col = tab + det_local0 + d0 + min(dl, nd - 1);
         float best = -INFINITY;
@@ -412,10 +423,8 @@ __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, co
             for (int k = 0; k < 16; ++k) best = fmaxf(best, v[k]);      // entries past S repeat entry sg: the maximum is unchanged
         }
         for (int o = DL; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o));
-        if (ok && sg == 0) {
-            const int g = jb.det_off + d0 + dl;
+        if (mine) {
             const float cosv = best * (1.0f / sqrtf(a.det_ss[g]));
-            const double g2 = maha4(m, Lc, a.det_xyah + (size_t)g * 4);
             out[jb.out_off + d0 + dl] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
         }
     }
