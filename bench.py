@@ -484,7 +484,7 @@ class RefLoaderFrames:
         return iter(self.batches)
 
 
-def dropin_point_(wl, local, frame_hw, n_frames, zone, n_obj=12, seed=1702):
+def dropin_point_(wl, local, frame_hw, n_frames, zone, n_obj=12, seed=1702, pipelined=False):
     """Frames/s of the reference's OWN loop through the drop-in classes: CountingPipeline.run = /root/reference/modules/__init__.py:54-84,
     host frames, ImageDetect.run one image at a time (batch_size = 1, modules/datasets.py:93), VideoTracker.run per frame, VideoCounting
     at the end -- every call crosses the C ABI with host buffers and blocks (PCIe both ways inside the timed region)."""
@@ -503,14 +503,21 @@ def dropin_point_(wl, local, frame_hw, n_frames, zone, n_obj=12, seed=1702):
     eng.pretune(tuple(range(1, 65)))                                     # ReID conv autotune for every crop count a frame of this clip can bring (size buckets)
     warm = RefLoaderFrames(frames[:24])
     src = RefLoaderFrames(frames)
-    pipe.run(warm, "cam", zone)                                          # conv autotune, first-use allocations; its trackers are discarded
+    run = pipe.run_pipelined if pipelined else pipe.run
+    run(warm, "cam", zone)                                               # conv autotune, first-use allocations; its trackers are discarded
     eng.sync(); torch.cuda.synchronize()
     gc.collect(); gc.disable()
     t0 = time.perf_counter()
-    rows, counts = pipe.run(src, "cam", zone)                            # a new VideoTracker per video, like modules/__init__.py:32-36
+    rows, counts = run(src, "cam", zone)                                 # a new VideoTracker per video, like modules/__init__.py:32-36
     eng.sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    if pipelined:
+        eng.close()
+        torch.cuda.empty_cache()
+        return {"value": n_frames / dt, "unit": "frames/s", "frames": n_frames, "frame_hw": [H, W], "batch_size": 1, "ms_per_frame": dt / n_frames * 1e3,
+                "csv_rows": len(rows), "dtype": wl["precision"],
+                "path": "CountingPipeline.run_pipelined: the same loader and the same per-frame body, stage calls asynchronous (batch n+1's detector behind batch n's ReID + tracker), host frames"}
     # the same loop once more with the two stage calls timed separately
     tracker, _ = pipe._stages("cam", src.video_info, zone)
     t_det = t_trk = 0.0
@@ -606,28 +613,32 @@ def main():
         qp = lambda w=wl, **kw: (lambda: quick_point(w, rank, local, dev, world, **kw))
         points = {
             "K32_injected": qp(n_obj=32, inject=32, clip=256),
-            "K256_injected": qp(n_obj=256, inject=256, B=32, clip=128, steps=6, full=True),
+            "K256_injected": qp(n_obj=256, inject=256, B=32, clip=128, steps=24, warmup=3, full=True),
             # the engine mode whose CSV is identical to the oracle's (tests/test_gpu_bench_config.py): fp32 MFMA convs, same stream
-            "s640_fp32_exact_csv": qp(precision="f32", B=64, clip=128, steps=6, full=True),
+            "s640_fp32_exact_csv": qp(precision="f32", B=64, clip=128, steps=12, full=True),
             # BASELINE.json configs[2] and configs[4], short runs of `--workload m1024-bf16` / `--workload l1280-fp8`
-            "m1024_bf16": qp(WORKLOADS["m1024-bf16"], steps=4, warmup=2, full=True),
-            "l1280_fp8": qp(WORKLOADS["l1280-fp8"], steps=6, warmup=2, full=True),
+            "m1024_bf16": qp(WORKLOADS["m1024-bf16"], steps=16, warmup=2, full=True),
+            "l1280_fp8": qp(WORKLOADS["l1280-fp8"], steps=16, warmup=2, full=True),
             # the same two precisions on the well-conditioned detector, its own detections all the way (no injection): the configuration
             # tests/test_gpu_coded.py holds to the oracle's CSV
-            "s640_bf16_coded": qp(coded=True, inject=0, clip=256, steps=12, warmup=3, full=True),
-            "l1280_fp8_coded": qp(WORKLOADS["l1280-fp8"], coded=True, inject=0, n_obj=12, steps=6, warmup=2, full=True),
+            "s640_bf16_coded": qp(coded=True, inject=0, clip=256, steps=48, warmup=3, full=True),
+            "l1280_fp8_coded": qp(WORKLOADS["l1280-fp8"], coded=True, inject=0, n_obj=12, steps=16, warmup=2, full=True),
             # BASELINE.json configs[3]'s 8 cameras on ONE GPU: 8 x 16 frames interleaved in every 128-frame batch (vc_stream_run_async_multi)
-            "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True),
+            "s640_8cam_one_gpu": qp(n_cam=8, clip=512, steps=48, warmup=3, full=True),
             "s640_8cam_distinct_clips": qp(n_cam=8, clip=512, steps=12, warmup=3, full=True, distinct_cams=True),
             # the boundary the reference itself calls: batch_size = 1 through the drop-in classes, host frames
             "dropin_bs1": lambda: dropin_point(wl, local, (640, 640), 256, ZONE),
             "dropin_bs1_720p": lambda: dropin_point(WL_720P, local, (720, 1280), 256, ZONE_720P),
+            # the same loader and loop body with the stage calls asynchronous (CountingPipeline.run_pipelined): same rows, frame n+1's detector
+            # behind frame n's ReID + tracker
+            "dropin_bs1_pipelined": lambda: dropin_point(wl, local, (640, 640), 256, ZONE, pipelined=True),
+            "dropin_bs1_720p_pipelined": lambda: dropin_point(WL_720P, local, (720, 1280), 256, ZONE_720P, pipelined=True),
             # the reference's only real input geometry (Q8, networks/yolo.py:69-70; demo/sample/cam_04.json): 1280 x 720 frames -> 384 x 640 tensor
-            "s720p_bf16": qp(WL_720P, frame_hw=(720, 1280), zone=ZONE_720P, clip=256, steps=12, warmup=3, full=True),
+            "s720p_bf16": qp(WL_720P, frame_hw=(720, 1280), zone=ZONE_720P, clip=256, steps=48, warmup=3, full=True),
             # the same frames with the clip's 12 ground-truth rectangles injected after the detector has run in full (the random head needs
             # obj_shift 7.8 at this geometry: thousands of candidates per frame reach the NMS and persistent noise boxes load the tracker --
             # artefacts of the synthetic head, not of the geometry)
-            "s720p_bf16_K12_injected": qp(frame_hw=(720, 1280), zone=ZONE_720P, n_obj=12, inject=12, clip=256, steps=12, warmup=3, full=True),
+            "s720p_bf16_K12_injected": qp(frame_hw=(720, 1280), zone=ZONE_720P, n_obj=12, inject=12, clip=256, steps=48, warmup=3, full=True),
             # batch-size sweep of the headline stream (frames per vc_stream_* call) with the submit -> rows latency of a batch
             "batch_sweep": lambda: {f"B{b}": quick_point(wl, rank, local, dev, world, B=b, clip=256, steps=max(8, min(128, 512 // b)), warmup=max(3, min(16, 64 // b)))
                                     for b in (1, 8, 16, 32, 128)},

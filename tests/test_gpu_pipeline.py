@@ -33,13 +33,15 @@ def test_csv_parity(golden_dir, tmp_path):
     cfg = types.SimpleNamespace(model_name="yolov5s", min_conf=0.25, min_iou=0.45, max_det=300)
     args = types.SimpleNamespace(weight=None, mapping=None, output_path=str(tmp_path))
     cam_cfg = {"cam": {"cam_04": {"tracking_config": TRACK_CFG}}}
-    for mode in ("loop", "stream", "stream_async", "stream_async_host", "stream_host", "frame_sharded"):
+    for mode in ("loop", "pipelined", "stream", "stream_async", "stream_async_host", "stream_host", "frame_sharded"):
         eng = E.Engine(ysd, rsd, precision="f32", num_classes=NC, max_batch=8, max_frame_hw=(H, W), max_crops=512,
                        max_tracks=1024, nn_budget_cap=60)
         pipe = CountingPipeline(args, cfg, cam_cfg, engine=eng, class_names=[f"c{i}" for i in range(NC)])
         src = FrameSource(frames)
         if mode == "loop":
             rows, counts = pipe.run(src, "cam_04", zone)
+        elif mode == "pipelined":                        # the reference's loop over the same loader, stage calls asynchronous (round 6)
+            rows, counts = pipe.run_pipelined(src, "cam_04", zone)
         elif mode == "frame_sharded":                    # SURVEY.md 8f.1 driver on one rank: detect + embed + external-feature tracker
             rows, counts = pipe.run_frame_sharded(src, "cam_04", zone, chunk=4)
         else:                                           # "_host": frames stay in pinned host memory, staged two batches ahead (5 / 3 batches)

@@ -11,15 +11,24 @@ STATE = {od.TENTATIVE: 1, od.CONFIRMED: 2} if hasattr(od, "TENTATIVE") else None
 
 
 def scene(seed):
+    """seed >= 1000: "stale" scenes (round 6) -- 12 to 40 objects that are all seen for a while and then leave one by one while a few
+    stay and new ones arrive, long max_age: most cascade levels of a step hold only tracks whose objects are gone (the rotation
+    shortcut of match_step_wave64 / min_cost_matching), and the order of the remaining detections decides the ids of the new tracks."""
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(2, 70)); T = int(rng.integers(15, 50))
-    p = dict(max_dist=float(rng.uniform(0.05, 0.35)), max_iou_distance=float(rng.uniform(0.4, 0.95)), max_age=int(rng.integers(1, 40)),
+    stale = seed >= 1000
+    n = int(rng.integers(12, 40)) if stale else int(rng.integers(2, 70)); T = int(rng.integers(40, 60)) if stale else int(rng.integers(15, 50))
+    p = dict(max_dist=float(rng.uniform(0.05, 0.35)), max_iou_distance=float(rng.uniform(0.4, 0.95)), max_age=int(rng.integers(20, 40) if stale else rng.integers(1, 40)),
              n_init=int(rng.integers(1, 5)), budget=int(rng.choice([1, 2, 5, 30, 60])))
     protos = rng.standard_normal((n, 512)).astype(np.float32); protos /= np.linalg.norm(protos, axis=1, keepdims=True)
     twins = rng.random(n) < 0.2                                    # look-alikes: appearance ambiguous, motion decides
     for i in np.nonzero(twins)[0][1:]: protos[i] = protos[np.nonzero(twins)[0][0]]
     pos = rng.uniform([50, 50], [1200, 650], (n, 2)); vel = rng.uniform(-9, 9, (n, 2)); wh = rng.uniform([20, 20], [140, 170], (n, 2))
     born = rng.integers(0, T // 2 + 1, n); dies = born + rng.integers(3, T + 5, n); pvis = rng.uniform(0.6, 1.0)
+    if stale:
+        late = rng.random(n) < 0.25                                # a quarter arrives while the others are leaving
+        born = np.where(late, rng.integers(T // 3, T - 5, n), rng.integers(0, 4, n))
+        dies = np.where(late | (rng.random(n) < 0.15), T + 1, rng.integers(8, T - 5, n))
+        pvis = rng.uniform(0.9, 1.0)
     noise = float(rng.choice([0.005, 0.02, 0.06]))
     frames = []
     for t in range(T):

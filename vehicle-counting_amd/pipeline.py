@@ -6,6 +6,8 @@ Video decode/encode (cv2.VideoCapture / VideoWriter, modules/datasets.py) is out
 
 Drivers with identical results:
   run()                the reference's loop, one frame at a time through ImageDetect.run / VideoTracker.run (host frames);
+  run_pipelined()      the same loop over the same loader (any iterable of the reference's batch dicts, batch_size 1 included), but the
+                       stage calls are asynchronous: the detector of batch n+1 runs behind the ReID net and the tracker of batch n;
   run_stream()         frames resident in HBM, B frames per `vc_stream_run` call (detect batched, trackers stepped in order);
   run_frame_sharded()  ONE stream on several GPUs: detect + ReID shard by frame chunk over the ranks, the
                        per-detection payloads are gathered in frame order, rank 0 runs the sequential tracker.
@@ -100,6 +102,62 @@ class CountingPipeline:
                         obj["tracks"].append(res["tracks"][j])
                         obj["labels"].append(res["labels"][j])
                         obj["boxes"].append(res["boxes"][j])
+        return self._finish(counter, obj, cam_name)
+
+    def run_pipelined(self, source, cam_name, zone_path):
+        """modules/__init__.py:28-100 for one video with the per-frame body software-pipelined over the engine's streams.
+
+        Same input as run(): an iterable of the reference's loader batches ({'imgs', 'ori_imgs', 'frames'}, modules/datasets.py:47-76;
+        batch_size = 1 at :93), host frames.  Same results (rows in the same order, Q1 skip included): what changes is WHEN a batch's
+        stage work is issued -- batch n+2 is copied to the device and batch n+1's detector pass is enqueued before batch n's detections are
+        marshalled, embedded and tracked (`vc_stream_stage_host` / `vc_stream_submit` / `vc_stream_run_async` / `vc_stream_collect`), so
+        the ~60 dependent launches of a batch-1 detector pass overlap with the ReID net and the tracker walk of the frame before instead
+        of following them.  ImageDetect.run / VideoTracker.run stay blocking calls for callers that use the stage objects directly;
+        this driver is the drop-in for CountingPipeline.run itself."""
+        import collections
+        tracker, counter = self._stages(cam_name, source.video_info, zone_path)
+        obj = {"frames": [], "tracks": [], "labels": [], "boxes": []}
+        it = (b for b in source if b is not None)
+        staged = collections.deque()        # (frame ids, host array, device address, b, h, w): copied, detector not yet enqueued
+        submitted = collections.deque()     # detector enqueued, not yet handed to ReID + tracker
+        running = collections.deque()       # tracker enqueued, rows not yet collected
+
+        def stage():
+            batch = next(it, None)
+            if batch is None:
+                return
+            arr = np.ascontiguousarray(np.stack([np.asarray(f) for f in batch["ori_imgs"]]), dtype=np.uint8)   # (b, h, w, 3) BGR as the loader delivers it
+            b, h, w, _ = arr.shape
+            ptr = self.engine.stream_stage_host(arr.ctypes.data, b, h, w)
+            staged.append((np.asarray(batch["frames"], dtype=np.int64), arr, ptr, b, h, w))
+
+        def submit():
+            if staged:
+                ids, arr, ptr, b, h, w = staged.popleft()
+                self.engine.stream_submit(ptr, b, h, w)
+                submitted.append((ids, arr, ptr, b, h, w))
+
+        def collect():
+            ids, _arr = running.popleft()
+            rows, fidx = self.engine.stream_collect()[:2]
+            obj["frames"].extend(ids[fidx].tolist())
+            obj["tracks"].extend(rows[:, 4].tolist())
+            obj["labels"].extend(rows[:, 5].tolist())
+            obj["boxes"].extend(list(rows[:, :4].copy()))
+
+        with self._video(tracker):
+            stage(); stage()                                 # staging order = batch order (four host slots, round-robin)
+            submit()
+            while submitted:
+                stage()                                      # copy batch n+2 under the detector of batch n+1
+                submit()                                     # detect batch n+1 while batch n is embedded and tracked
+                ids, arr, ptr, b, h, w = submitted.popleft()
+                self.engine.stream_run_async(tracker.tracker_ids, ptr, b, h, w)
+                running.append((ids, arr))
+                if len(running) > 1:
+                    collect()
+            while running:
+                collect()
         return self._finish(counter, obj, cam_name)
 
     def run_stream(self, source, cam_name, zone_path, batch=16, asynchronous=False, host_frames=False):
