@@ -74,7 +74,7 @@ def test_conv2d(case, precision):
 
 
 @pytest.mark.parametrize("slots", [0, 8])
-@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 50)) + [55] + list(range(60, 67)))     # (56 - 59, split-K: tests/test_gpu_round6.py; 64 - 66: paired 8-wave workgroups)
+@pytest.mark.parametrize("cfg", list(range(32)) + list(range(36, 50)) + [55] + list(range(60, 69)))     # (56 - 59, split-K: tests/test_gpu_round6.py; 64 - 68: paired workgroups)
 def test_conv2d_every_tile_config(cfg, slots, monkeypatch):
     """Every entry of conv_igemm.hip's tile table (tile shape x K chunk x ring depth) on a padded 3x3 with a ragged
     pixel tail, a ragged channel tail and a K extent shorter than the deepest ring, and on a strided 1x1."""

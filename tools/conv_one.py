@@ -9,5 +9,5 @@ x = rng.standard_normal((B, H, W, Ci), dtype=np.float32)
 w = (rng.standard_normal((Co, Ci, k, k), dtype=np.float32) / np.sqrt(Ci * k * k)).astype(np.float32)
 b = np.zeros(Co, np.float32)
 for _ in range(int(os.environ.get("VC_REPS", 3))):
-    y = E.conv2d(x, w, b, stride=s, pad=p, act=1, precision="bf16")
+    y = E.conv2d(x, w, b, stride=s, pad=p, act=int(os.environ.get("VC_ACT", 1)), precision="bf16")
 print("ok", y.shape, float(np.abs(y).mean()))

@@ -1213,7 +1213,10 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 #define VC_SK_CFGS(K) K(56, 64, 64, 2, 2, 8, 3) K(57, 64, 64, 2, 2, 8, 4) K(58, 128, 64, 2, 2, 8, 3) K(59, 64, 128, 1, 4, 8, 3)
 // paired 8-wave workgroups, two per CU (round 6, conv_igemm_kernel<..., OCC = 2>): P(index, BP, BC, WP, WC, KC, NS)
 #define VC_PAIR_CFGS(P) P(64, 256, 128, 4, 2, 4, 3) P(65, 128, 256, 2, 4, 4, 3) P(66, 256, 128, 4, 2, 4, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4 + 3; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59), the deep rings (60-63) and the paired 8-wave workgroups (64-66)
+// 67 - 68: two 4-wave workgroups per CU with 128 x 64 wave tiles (12 fragment reads per 32 MFMAs: 96 B / clk of LDS reads where the 64 x 64 wave
+// tile asks for the LDS's whole 128 B / clk), 256 registers per wave
+#define VC_PAIR4_CFGS(P) P(67, 256, 128, 2, 2, 4, 3) P(68, 256, 128, 2, 2, 4, 2)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4 + 3 + 2; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59), the deep rings (60-63) and the paired workgroups (64-68)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1501,6 +1504,7 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
 #undef VC_K
 #define VC_P(i, bp, bc, wp, wc, kc, ns) case i: return launch_one<bp, bc, wp, wc, kc, ns, 2>(p, s);
         VC_PAIR_CFGS(VC_P)
+        VC_PAIR4_CFGS(VC_P)
 #undef VC_P
     }
     return VC_ERR_ARG;
