@@ -1238,6 +1238,25 @@ static int resident_workgroups(K kernel, int threads = 256) {
     return per_cu * cus;
 }
 
+// Grid of a persistent launch.  Workgroup b walks tiles b, b + G, ...: the launch lasts ceil(tiles / G) tile times, so a grid of "all slots but
+// the reserve" can cost a whole extra round -- 200 tiles of the 20 x 20 level on 192 slots: two rounds where 200 workgroups need one; 400 tiles:
+// three rounds instead of two; 800 tiles of a 40 x 40 layer: five instead of four.  Rounds first: the fewest rounds the chip allows (the
+// reserve of 64 slots for the other streams' kernels is given up only when that saves a round), then the smallest grid that still finishes in
+// that many rounds (tiles spread evenly, the slots that are not needed stay free for the ReID queue and the tracker), a multiple of 8 for
+// the XCD-aware tile order.  VC_CONV_BALANCED=0: the old rule (A/B switch).
+static int persistent_grid(int tiles, int slots_hw, int reserve, int slots_override) {
+    static const bool balanced = !(getenv("VC_CONV_BALANCED") && atoi(getenv("VC_CONV_BALANCED")) == 0);
+    if (slots_override > 0) return tiles > slots_override ? std::max(8, slots_override / 8 * 8) : tiles;
+    const int cap = std::max(8, std::max(256, slots_hw - reserve) / 8 * 8);
+    if (tiles <= cap) return tiles;
+    if (!balanced) return cap;
+    const int full = std::max(cap, slots_hw / 8 * 8);
+    const int r_cap = (tiles + cap - 1) / cap, r_full = (tiles + full - 1) / full;
+    const int rounds = std::min(r_cap, r_full);
+    const int g = ((tiles + rounds - 1) / rounds + 7) / 8 * 8;
+    return std::min(g, full);
+}
+
 template <int BP, int BC, int WP, int WC, int KC, int NS, int OCC = 1>
 static int launch_one(ConvP p, hipStream_t s) {
     if (OCC != 1 && (p.prec != PREC_BF16 || p.in_up)) return VC_ERR_ARG;      // quietly: the paired-workgroup tiles exist for plain bf16 only
@@ -1259,14 +1278,12 @@ static int launch_one(ConvP p, hipStream_t s) {
     handled = p.prec == PREC_F32 || p.prec == PREC_FP8 || p.in_up;
     if (p.prec == PREC_F32) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, WP * WC * 64);
-        const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
-        const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+        const int grid = (persist && !dyn_lds) ? persistent_grid(tiles, slots_hw, slots_reserve, slots_override) : tiles;
         launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, 2, PREC_F32>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     } else if (p.prec == PREC_FP8) {
         if constexpr (KC == 8 && (BP / WP / 16) % 2 == 0) {        // the fp8 epilogue pairs pixel tiles (PT even)
             static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_FP8>, WP * WC * 64);
-            const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
-            const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+            const int grid = (persist && !dyn_lds) ? persistent_grid(tiles, slots_hw, slots_reserve, slots_override) : tiles;
             launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_FP8>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
         } else {
             return VC_ERR_ARG;                                       // quietly: the autotuner skips it (fp8 runs on the 128-byte-row tiles only)
@@ -1277,8 +1294,7 @@ static int launch_one(ConvP p, hipStream_t s) {
                                (WP == 2 && WC == 2 && BC == 128 && (BP == 128 || BP == 256) && (KC == 8 || (KC == 4 && NS == 2 && BP == 128)));
         if constexpr (UP_OK) {
             static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, true>, WP * WC * 64);
-            const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
-            const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+            const int grid = (persist && !dyn_lds) ? persistent_grid(tiles, slots_hw, slots_reserve, slots_override) : tiles;
             launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, true>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
         } else {
             return VC_ERR_ARG;                                       // quietly: the autotuner skips it
@@ -1287,8 +1303,7 @@ static int launch_one(ConvP p, hipStream_t s) {
     }
     if (!handled) {
         static const int slots_hw = resident_workgroups(conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, false, OCC>, WP * WC * 64);
-        const int slots = slots_override > 0 ? slots_override : std::max(256, slots_hw - slots_reserve);
-        const int grid = (persist && !dyn_lds && tiles > slots) ? std::max(8, slots / 8 * 8) : tiles;
+        const int grid = (persist && !dyn_lds) ? persistent_grid(tiles, slots_hw, slots_reserve, slots_override) : tiles;
         launch_timed(p, conv_igemm_kernel<BP, BC, WP, WC, KC, NS, PREC_BF16, false, false, OCC>, dim3(grid), dim3(WP * WC * 64), dyn_lds, s, p);
     }
     VC_HIP(hipGetLastError());
