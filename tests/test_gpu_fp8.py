@@ -66,6 +66,33 @@ def test_conv2d_fp8_against_float64_on_the_quantised_operands(case):
     np.testing.assert_allclose(y, refq, rtol=0.126, atol=2 ** -9)   # never more than one e4m3 ulp away
 
 
+DIRECT8_CASES = [   # (tile configuration, case): conv1x1_direct_fp8_kernel -- CT x 16 channels per wave, KS steps of K = 128
+    (69, (1, 40, 40, 128, 128, 1, 1, 0, 1, 0)), (69, (1, 17, 13, 64, 72, 1, 1, 0, 0, 0)), (69, (2, 24, 24, 128, 64, 1, 1, 0, 1, 1)),
+    (70, (1, 40, 40, 256, 128, 1, 1, 0, 1, 0)), (70, (2, 20, 20, 256, 256, 1, 1, 0, 1, 2)),
+    (71, (1, 40, 40, 128, 256, 1, 1, 0, 1, 0)), (71, (3, 9, 11, 64, 64, 1, 1, 0, 2, 0)),
+    (72, (1, 40, 40, 128, 128, 1, 1, 0, 1, 0)), (72, (1, 17, 13, 64, 72, 1, 1, 0, 0, 0)), (72, (2, 16, 16, 128, 256, 1, 1, 0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("cfg,case", DIRECT8_CASES)
+def test_conv1x1_direct_fp8_configs(cfg, case, monkeypatch):
+    """The weights-in-registers pointwise kernel of the fp8 path (tile configurations 69 - 72) against the same float64 reference, and
+    bit for bit against the implicit GEMM it replaces (same products in the same MFMA steps)."""
+    monkeypatch.setenv("VC_CONV_STRICT", "1")                    # a refusal is an error here, not a quiet fall-back to the implicit GEMM
+    monkeypatch.setenv("VC_CONV_CFG", str(cfg))
+    test_conv2d_fp8_against_float64_on_the_quantised_operands(case)
+    B, H, W, Ci, Co, k, s, p, act, rm = case
+    rng = np.random.default_rng(cfg * 977 + Ci + Co)
+    x = q8(rng.standard_normal((B, H, W, Ci)))
+    w = (rng.standard_normal((Co, Ci, 1, 1)) / np.sqrt(Ci)).astype(np.float32)
+    b = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    res = q8(rng.standard_normal((B, H, W, Co))) if rm else None
+    y = E.conv2d(x, w, b, stride=1, pad=0, act=act, res=res, res_mode=rm, precision="fp8")
+    monkeypatch.setenv("VC_CONV_CFG", "4")
+    y0 = E.conv2d(x, w, b, stride=1, pad=0, act=act, res=res, res_mode=rm, precision="fp8")
+    np.testing.assert_array_equal(y, y0)
+
+
 def iou_one(b, others):
     x1, y1 = np.maximum(b[0], others[:, 0]), np.maximum(b[1], others[:, 1])
     x2, y2 = np.minimum(b[2], others[:, 2]), np.minimum(b[3], others[:, 3])

@@ -1052,6 +1052,78 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_direct_kernel(const ConvP p)
     }
 }
 
+// The same kernel for the fp8 path (round 6): pointwise layers with K <= 256 (Bottleneck.cv1, C3.cv1 | cv2, C3.cv3 of the 320^2 - 80^2 levels of
+// YOLOv5l at 1280^2, BASELINE.json configs[4]).  Through the implicit GEMM a K = 128 layer is ONE K step per tile: every 64-pixel tile pays
+// its tile bookkeeping, a barrier, a 16 KB weight tile re-streamed through LDS for 8 KB of pixels, and the fp8 layers ran no faster than the
+// bf16 ones on half the bytes (128 -> 128 at 160^2: 57 us for 105 MB).  Here the weights of a wave's CT x 16 channels sit in registers as MFMA
+// A operands (KS steps of K = 128: 8 registers per fragment), the pixels stream global -> registers, one fetch ahead.  K assignment inside a
+// step as in conv_igemm_kernel's fp8 branch (a lane's 32 K-bytes = chunks fch and 4 + fch of the 128-byte slice, both operands): the same
+// products in the same MFMA, bit-identical results.  Cin = 64: KS = 1, the upper half of the step is out-of-range offsets (zeros).
+template <int CT, int KS, int PT, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv1x1_direct_fp8_kernel(const ConvP p) {
+    constexpr uint32_t OOB = 0x80000000u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fch = lane >> 4;
+    const int NG = (p.Cout + CT * 16 - 1) / (CT * 16);
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;           // 4 % NG == 0: a workgroup holds whole sets of groups
+    const int g = gw % NG, stride = nw / NG;
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)((size_t)p.B * p.H * p.W * p.in_cs), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)((size_t)((p.Cout + 127) / 128 * 128) * p.Kw), 0x00020000);
+    u32x4 wlo[CT][KS], whi[CT][KS];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int row = (g * CT + ct) * 16 + frow;                   // rows past Cout are zero rows of the padded weight buffer
+            const int off = row * p.Kw + ks * 128 + fch * 16;
+            wlo[ct][ks] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0);
+            whi[ct][ks] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, off + 64, 0, 0);
+        }
+    u32x4 xl[PT][KS], xh[PT][KS], nl[PT][KS], nh[PT][KS];
+    const bool half = p.Cin <= 128 * KS - 64;                           // (uniform) Cin = 64: only the first chunk of the last step holds data
+    auto fetch = [&](int blk, u32x4 (&lo)[PT][KS], u32x4 (&hi)[PT][KS]) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = (blk * PT + pt) * 16 + frow;
+            const uint32_t base = (blk < nblk && m < p.M) ? (uint32_t)(m * p.in_cs + p.in_co + fch * 16) : OOB;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lo[pt][ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, (int)(base >= OOB ? OOB : base + ks * 128), 0, 0);
+                hi[pt][ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, (int)((base >= OOB || (half && ks == KS - 1)) ? OOB : base + ks * 128 + 64), 0, 0);
+            }
+        }
+    };
+    int blk = gw / NG;
+    fetch(blk, xl, xh);
+    for (; blk < nblk; blk += stride) {
+        fetch(blk + stride, nl, nh);
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+#pragma unroll
+            for (int b = 0; b < PT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int a = 0; a < CT; ++a) {
+                const i32x8 wa = {(int)wlo[a][ks].x, (int)wlo[a][ks].y, (int)wlo[a][ks].z, (int)wlo[a][ks].w, (int)whi[a][ks].x, (int)whi[a][ks].y, (int)whi[a][ks].z, (int)whi[a][ks].w};
+#pragma unroll
+                for (int b = 0; b < PT; ++b) {
+                    const i32x8 xa = {(int)xl[b][ks].x, (int)xl[b][ks].y, (int)xl[b][ks].z, (int)xl[b][ks].w, (int)xh[b][ks].x, (int)xh[b][ks].y, (int)xh[b][ks].z, (int)xh[b][ks].w};
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+            }
+        conv_epilogue_fp8<PT, CT>(p, acc, blk * PT * 16, g * CT * 16 + fch * 4, frow);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { xl[pt][ks] = nl[pt][ks]; xh[pt][ks] = nh[pt][ks]; }
+    }
+}
+
 // ---- 1x1 / stride 1, streaming form: weights in LDS, a wave owns ALL output channels of its pixels (bf16) -----------------------
 // The wide-map pointwise layers (K, N <= 256 at 80^2 / 40^2) move 2 - 7 times the bytes their MFMAs are worth in time, and both forms
 // above leave them at ~3.3 TB/s: the implicit GEMM pays a DMA issue, a counted wait and a workgroup barrier per K tile around a dozen
@@ -1216,7 +1288,9 @@ static const ConvCfg kCfg[] = {VC_CONV_CFGS(VC_X)};
 // 67 - 68: two 4-wave workgroups per CU with 128 x 64 wave tiles (12 fragment reads per 32 MFMAs: 96 B / clk of LDS reads where the 64 x 64 wave
 // tile asks for the LDS's whole 128 B / clk), 256 registers per wave
 #define VC_PAIR4_CFGS(P) P(67, 256, 128, 2, 2, 4, 3) P(68, 256, 128, 2, 2, 4, 2)
-int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4 + 3 + 2; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59), the deep rings (60-63) and the paired workgroups (64-68)
+// weights-in-registers 1x1 of the fp8 path (conv1x1_direct_fp8_kernel): F(index, CT, KS, PT, OCC); K <= 128 KS
+#define VC_DIRECT8_CFGS(F) F(69, 4, 1, 2, 2) F(70, 4, 2, 2, 2) F(71, 4, 1, 4, 2) F(72, 8, 1, 2, 2)
+int conv_num_cfgs() { return (int)(sizeof(kCfg) / sizeof(kCfg[0])) + 4 + 4 + 4 + 4 + 6 + 5 + 1 + 4 + 4 + 3 + 2 + 4; }   // + the halo-staged 3x3 (28-31, 36-39), the direct 1x1 (32-35), the 16-wave 256 x 256 tiles (40-43), the halo-staged 3x3/s2 (44-49), the streaming 1x1 (50-54), conv3x3_halo_v2_kernel (55), the split-K tiles (56-59), the deep rings (60-63) the paired workgroups (64-68) and the fp8 direct 1x1 (69-72)
 
 // resident workgroups of one kernel instantiation on the whole device (occupancy x CUs), queried once
 static int device_cus() {
@@ -1480,6 +1554,31 @@ static int launch_direct1x1(ConvP p, hipStream_t s) {
 }
 
 
+static bool direct8_applicable(const ConvP& p, int ct, int ks) {
+    if (p.prec != PREC_FP8 || p.kh != 1 || p.kw != 1 || p.sh != 1 || p.sw != 1 || p.ph != 0 || p.pw != 0) return false;
+    if (p.K != p.Cin || p.Cin > ks * 128 || p.Cin <= (ks - 1) * 128 || p.Cin % 64 != 0 || (p.Cin % 128 != 0 && p.Cin != 64)) return false;
+    if (p.Ho != p.H || p.Wo != p.W || p.in_cs % 16 != 0 || p.in_co % 16 != 0 || p.in_up || p.m_dev || !p.scale || p.Kw < ks * 128) return false;
+    const int ng = (p.Cout + ct * 16 - 1) / (ct * 16);
+    return ng == 1 || ng == 2 || ng == 4;                         // (the channel tail of a group is masked by the epilogue; its weight rows are zero padding)
+}
+
+template <int CT, int KS, int PT, int OCC>
+static int launch_direct8(ConvP p, hipStream_t s) {
+    static const bool enabled = !(getenv("VC_CONV_DIRECT8") && atoi(getenv("VC_CONV_DIRECT8")) == 0);   // A/B switch
+    p.Kw = p.Kp;
+    if (!enabled || !direct8_applicable(p, CT, KS)) return VC_ERR_ARG;             // quietly, like launch_halo
+    const int ng = (p.Cout + CT * 16 - 1) / (CT * 16);
+    const int nblk = (p.M + PT * 16 - 1) / (PT * 16);
+    const int need = (nblk * ng + 3) / 4;
+    static const int slots_hw = resident_workgroups(conv1x1_direct_fp8_kernel<CT, KS, PT, OCC>);
+    static const int slots_reserve = getenv("VC_CONV_RESERVE") ? atoi(getenv("VC_CONV_RESERVE")) : 64;
+    const int slots = p.slots > 0 ? p.slots : std::max(256, slots_hw - slots_reserve);
+    p.ntiles = nblk * ng;
+    launch_timed(p, conv1x1_direct_fp8_kernel<CT, KS, PT, OCC>, dim3(std::min(need, slots)), dim3(256), 0, s, p);
+    VC_HIP(hipGetLastError());
+    return VC_OK;
+}
+
 template <int CT, int KS, int PT, int NP>
 static int launch_stream1x1(ConvP p, hipStream_t s) {
     if (!direct1x1_applicable(p, CT, KS) || p.Cout != CT * 16) return VC_ERR_ARG;                     // quietly, like launch_halo
@@ -1521,6 +1620,9 @@ int launch_conv_cfg(const ConvP& p, int cfg, hipStream_t s) {
         VC_PAIR_CFGS(VC_P)
         VC_PAIR4_CFGS(VC_P)
 #undef VC_P
+#define VC_F(i, ct, ks, pt, occ) case i: return launch_direct8<ct, ks, pt, occ>(p, s);
+        VC_DIRECT8_CFGS(VC_F)
+#undef VC_F
     }
     return VC_ERR_ARG;
 }
