@@ -127,12 +127,14 @@ def test_bench_config_bf16_track_level_tolerance(bench_case, tmp_path):
     assert cd <= 3, (counts, ref_counts)
 
 
-def test_timed_configuration_b128_autotuned_bf16_directly():
+@pytest.mark.parametrize("T128", [128, 256])
+def test_timed_configuration_b128_autotuned_bf16_directly(T128):
     """"the exact configuration timed (B = 128, autotune on, bf16) is compared with nothing directly".  Here it is: bench.py's
-    weights and its first 128-frame batch through vc_stream_submit on a bf16 engine with max_batch = 128 and the autotuner ON (this
-    process's default: the tile configurations the timed run picks for the 128-frame size buckets, fused kernels included), compared
-    with the fp32 oracle on frames 0, 63 and 127 of the batch under the bf16 ladder of tests/test_gpu_nets.py: per-layer max-norm <= 6e-2 and
-    rms <= 4e-2 of the oracle's tensor; every oracle box with conf >= 0.30 has a same-class partner with IoU >= 0.45 and >= 85 % are the
+    weights and its first batch (128 frames, and the 256 frames per call the headline uses since round 6) through vc_stream_submit on a
+    bf16 engine with max_batch = the batch and the autotuner ON (this
+    process's default: the tile configurations the timed run picks for the batch's size buckets, fused kernels included), compared
+    with the fp32 oracle on frames 0, 63 and the last one of the batch under the bf16 ladder of tests/test_gpu_nets.py: per-layer max-norm <= 6e-2 and
+    rms <= 4e-2 of the oracle's tensor; every oracle box with conf >= 0.35 (conf_thres + the confidence tolerance) has a same-class partner with IoU >= 0.45 and >= 85 % are the
     same box (IoU >= 0.9, |dconf| <= 1e-1: the bench head multiplies logit noise by det_scale = 4 over 80 classes).  (A row-level comparison of this clip against the fp32 engine was tried first: found 0.57 /
     id-consistent 0.56 on the 128-frame bouncing clip -- lower than the 64-frame clip's 0.75 because every flipped marginal detection
     renumbers the tracks after it; a clip-dependent hit rate is not a tolerance, the numeric ladder is.)"""
@@ -140,14 +142,13 @@ def test_timed_configuration_b128_autotuned_bf16_directly():
 
     from oracle import yolov5 as oy
     assert os.environ.get("VC_AUTOTUNE", "1") != "0", "this test is about the autotuned configuration"
-    T128 = 128
     ysd, rsd = synth_yolo("yolov5s", nc=NC, seed=1702, det_scale=4.0, obj_shift=1.0), synth_reid(1702)
     frames = synth_frames(T128, H, W, n_obj=12, seed=1702, bounce=True)
     dev = torch.from_numpy(frames).cuda()
     eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=T128, max_frame_hw=(H, W), max_crops=T128 * 64, max_tracks=8192, nn_budget_cap=60)
     eng.stream_submit(dev.data_ptr(), T128, H, W)
     rows7, _ = eng.stream_embed(dev.data_ptr(), T128, H, W)        # detector + ReID of the whole batch; rows7 = frame, x1, y1, x2, y2, conf, label
-    pick = [0, 63, 127]
+    pick = [0, 63, T128 - 1]
     imgs = [frames[f][:, :, ::-1] for f in pick]
     x, s0, s1 = oy.preprocess(imgs, 640)
     pred, ys, _ = oy.forward(ysd, x, "yolov5s", NC, return_layers=True)
@@ -161,7 +162,7 @@ def test_timed_configuration_b128_autotuned_bf16_directly():
     n_ref = n_same = 0
     for f, r in zip(pick, ref_dets):
         d = rows7[rows7[:, 0] == f][:, 1:]
-        for rb in r[r[:, 4] >= 0.30]:
+        for rb in r[r[:, 4] >= 0.35]:                          # conf_thres 0.25 + the confidence tolerance below: a box nearer the threshold may be lost to it
             same = d[d[:, 5] == rb[5]]
             assert len(same) > 0, (f, rb)
             iou = np.array([_iou(rb[:4], q[:4]) for q in same])

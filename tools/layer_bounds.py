@@ -48,4 +48,5 @@ for (M, N, K, kh, kw, s, cfg, ms) in rows:
     for i, v in enumerate((ms, t_m, t_b, t_s, mx, sm)):
         tot[i] += v
     print(f"| {'ReID ' if reid else ''}{M} x {N} x {K}, {kh}x{kw}, s{s}, cfg {cfg} | {ms:.4f} | {t_m:.4f} | {t_b:.4f} | {t_s:.4f} | {mx:.4f} | {sm:.4f} | {ms / mx:.2f} |")
-print(f"| **all {len(rows)} launches of a 128-frame step** | **{tot[0]:.3f}** | {tot[1]:.3f} | {tot[2]:.3f} | {tot[3]:.3f} | {tot[4]:.3f} | {tot[5]:.3f} | {tot[0] / tot[4]:.2f} |")
+nfr = max((r[0] for r in rows if r[3] == 6), default=0) // (320 * 320)      # the stem's output pixels give the batch (640 x 640 frames)
+print(f"| **all {len(rows)} launches of a {nfr if nfr else 'one'}-frame step** | **{tot[0]:.3f}** | {tot[1]:.3f} | {tot[2]:.3f} | {tot[3]:.3f} | {tot[4]:.3f} | {tot[5]:.3f} | {tot[0] / tot[4]:.2f} |")

@@ -36,7 +36,7 @@ unset VC_TUNE_CACHE
 cp $OUT/pmc_traffic.json profiles/${R}_pmc_traffic.json      # the bench line quotes the traffic of THESE passes
 timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench.log
 python tools/mfma_util.py $OUT/pmc_mfma.txt $OUT/kernel_stats.md > $OUT/mfma_util.md 2>&1
-(echo "# tools/conv_breakdown.py: every conv launch of one step, one kernel on the GPU at a time (blocking events); cfg = tile configuration the autotuner picked (100 stem_direct, 101 reid stem + pool, 102 front_fused, 103 c3_fused, 104 bneck_fused)"; VC_B=128 timeout 300 python tools/conv_breakdown.py 2>/dev/null | grep -v amdgpu.ids) > $OUT/conv_layers_s640.txt
+(echo "# tools/conv_breakdown.py: every conv launch of one step, one kernel on the GPU at a time (blocking events); cfg = tile configuration the autotuner picked (100 stem_direct, 101 reid stem + pool, 102 front_fused, 103 c3_fused, 104 bneck_fused)"; VC_B=256 timeout 300 python tools/conv_breakdown.py 2>/dev/null | grep -v amdgpu.ids) > $OUT/conv_layers_s640.txt
 python tools/layer_bounds.py $OUT/conv_layers_s640.txt > $OUT/layer_bounds.md
 for f in kernel_stats.md mfma_util.md gpu_busy.txt conv_layers_s640.txt conv_tune.txt layer_bounds.md; do cp $OUT/$f profiles/${R}_$f; done
 cp $OUT/bench_n1.json profiles/${R}_bench_n1.json
