@@ -133,7 +133,7 @@ def test_timed_configuration_b128_autotuned_bf16_directly(T128):
     weights and its first batch (128 frames, and the 256 frames per call the headline uses since round 6) through vc_stream_submit on a
     bf16 engine with max_batch = the batch and the autotuner ON (this
     process's default: the tile configurations the timed run picks for the batch's size buckets, fused kernels included), compared
-    with the fp32 oracle on frames 0, 63 and the last one of the batch under the bf16 ladder of tests/test_gpu_nets.py: per-layer max-norm <= 6e-2 and
+    with the fp32 oracle on frames 0, 31, 63 and the last one of the batch under the bf16 ladder of tests/test_gpu_nets.py: per-layer max-norm <= 6e-2 and
     rms <= 4e-2 of the oracle's tensor; every oracle box with conf >= 0.35 (conf_thres + the confidence tolerance) has a same-class partner with IoU >= 0.45 and >= 85 % are the
     same box (IoU >= 0.9, |dconf| <= 1e-1: the bench head multiplies logit noise by det_scale = 4 over 80 classes).  (A row-level comparison of this clip against the fp32 engine was tried first: found 0.57 /
     id-consistent 0.56 on the 128-frame bouncing clip -- lower than the 64-frame clip's 0.75 because every flipped marginal detection
@@ -148,7 +148,7 @@ def test_timed_configuration_b128_autotuned_bf16_directly(T128):
     eng = E.Engine(ysd, rsd, precision="bf16", num_classes=NC, max_batch=T128, max_frame_hw=(H, W), max_crops=T128 * 64, max_tracks=8192, nn_budget_cap=60)
     eng.stream_submit(dev.data_ptr(), T128, H, W)
     rows7, _ = eng.stream_embed(dev.data_ptr(), T128, H, W)        # detector + ReID of the whole batch; rows7 = frame, x1, y1, x2, y2, conf, label
-    pick = [0, 63, T128 - 1]
+    pick = [0, 31, 63, T128 - 1]
     imgs = [frames[f][:, :, ::-1] for f in pick]
     x, s0, s1 = oy.preprocess(imgs, 640)
     pred, ys, _ = oy.forward(ysd, x, "yolov5s", NC, return_layers=True)
@@ -172,7 +172,7 @@ def test_timed_configuration_b128_autotuned_bf16_directly(T128):
             if iou[j] >= 0.9:
                 n_same += 1
                 assert abs(same[j, 4] - rb[4]) <= 1e-1         # measured 7.8e-2 on the bench head (det_scale 4 over 80 classes; the 8-class ladder holds 6e-2)
-    assert n_ref > 10 and n_same >= 0.85 * n_ref, (n_ref, n_same)
+    assert n_ref >= 8 and n_same >= 0.85 * n_ref, (n_ref, n_same)
     eng.close()
 
 
