@@ -3,8 +3,9 @@
     python tools/layer_bounds.py profiles/r05_conv_layers_s640.txt > profiles/r05_layer_bounds.md
 
 MFMA floor = FLOPs / 2.5 PFLOP/s (dense bf16 peak); HBM floor = (input + weights + output bytes of the launch as it runs: fused kernels count only
-what leaves the CU) / 6.3 TB/s (the achievable rate of MI355X_MICROARCH.md); SiLU floor = activation evaluations x 52 SIMD cycles per 64 values
-(two quarter-rate transcendentals + five full-rate operations) / 1024 SIMDs / 2.3 GHz.  ReLU / linear epilogues have no
+what leaves the CU) / 6.3 TB/s (the achievable rate of MI355X_MICROARCH.md); SiLU floor = activation evaluations x 27 SIMD cycles per 64 values
+(measured: tools/ubench/silu_rate.hip, x * rcp(1 + exp2(-x log2 e)) at four waves per SIMD -- v_exp_f32 / v_rcp_f32 7.7 cycles each, a plain f32
+operation 2.6; rounds 1 - 5 priced it at 52 from two quarter-rate transcendentals) / 1024 SIMDs / 2.3 GHz.  ReLU / linear epilogues have no
 transcendental floor.  The three resources can overlap, so max(...) is the floor of a perfectly overlapped kernel and sum(...) that of one
 whose phases run one after the other."""
 import re, sys
@@ -43,7 +44,7 @@ for (M, N, K, kh, kw, s, cfg, ms) in rows:
     wb = N * K * 2
     t_m = fl / 2.5e15 * 1e3
     t_b = (inb + wb + outb) / 6.3e12 * 1e3
-    t_s = silu * 52.0 / 64.0 / 1024 / 2.3e9 * 1e3
+    t_s = silu * 27.0 / 64.0 / 1024 / 2.3e9 * 1e3
     mx, sm = max(t_m, t_b, t_s), t_m + t_b + t_s
     for i, v in enumerate((ms, t_m, t_b, t_s, mx, sm)):
         tot[i] += v
