@@ -74,7 +74,7 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
         const int slot = h.list[t];
         TrackRecD& r = h.recs[slot];
         r.age += 1; r.tsu += 1;
-        w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = r.tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head; w.hits[t] = r.hits; w.id[t] = r.id;
+        w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = r.tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head; w.hits[t] = r.hits; w.id[t] = r.id; w.adm[t] = 1;
         double* m = &h.mean[(size_t)slot * 8];
         double* P = &h.cov[(size_t)slot * 64];
         kalman_predict_dev(m, P);
@@ -97,6 +97,9 @@ int tch_step(void* hp, const double* tlwh, const float* feat, int k, int W, int 
                 const double g2 = maha4(m, Lc, &xyah[(size_t)d * 4]);
                 h.cost_app[(size_t)t * D + d] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
             }
+            bool any = false;                                         // StepWork::adm, as appearance_row_table writes it on the device
+            for (int d = 0; d < D; ++d) any = any || !(h.cost_app[(size_t)t * D + d] > h.hdr.max_dist);
+            w.adm[t] = any ? 1 : 0;
         }
         if (D > 0 && !(r.state == CONFIRMED && r.tsu != 1)) {
             double b[4];

@@ -384,6 +384,8 @@ struct StepWork {
     long long* id;
     int *confirmed, *unconfirmed, *left, *rows, *un_rows, *un_cols, *un_tracks, *match_t, *match_d, *ri, *ci, *newslot;
     unsigned char *row_used, *col_used, *matched;
+    unsigned char* adm;             // per live track: 0 = no detection of the step is within the appearance threshold of this (confirmed) track
+                                    // (written with the track's cost row; 1 = unknown / some detection is: always a safe value)
     LapWork lap;
     double *small_c, *small_t;      // gathered sub-matrix / its transpose when it has at most small_n entries (LDS on the device:
     int small_n;                    // the assignment's scans then never leave the CU); 0 = always use the caller's buffers
@@ -392,7 +394,7 @@ struct StepWork {
 };
 
 // bytes of one StepWork with capacity cap (all arrays 8-byte aligned: cap is a multiple of 8)
-VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (6 + 12 + 4) + 8 * 4 + 5); }
+VC_HD size_t step_work_bytes(int cap) { return (size_t)cap * (4 * (6 + 12 + 4) + 8 * 4 + 6); }
 
 VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     char* p = (char*)base;
@@ -407,7 +409,7 @@ VC_HD void step_work_carve(StepWork& w, void* base, int cap) {
     I(w.slot); I(w.state); I(w.tsu); I(w.galc); I(w.galh); I(w.hits);
     I(w.confirmed); I(w.unconfirmed); I(w.left); I(w.rows); I(w.un_rows); I(w.un_cols); I(w.un_tracks); I(w.match_t); I(w.match_d);
     I(w.ri); I(w.ci); I(w.newslot);
-    B(w.lap.SR); B(w.lap.SC); B(w.row_used); B(w.col_used); B(w.matched);
+    B(w.lap.SR); B(w.lap.SC); B(w.row_used); B(w.col_used); B(w.matched); B(w.adm);
 }
 
 // The transposed solve (nr > nc): t holds the matrix as [nc][nr]; pairs come back sorted by ORIGINAL row like SciPy's.
@@ -869,6 +871,22 @@ VC_HD void match_step(Lanes L, const StepWork& w, const TrackerHdr& h, int T, in
         const int nl = compact(L, n_conf, [&](int q) { return w.tsu[w.confirmed[q]] == 1 + level; }, [&](int pos, int q) { w.rows[pos] = w.confirmed[q]; });
         if (nl == 0) continue;
         wave_sync();
+        {
+            // A level whose tracks are all stale (w.adm: no detection of the step within the threshold, known since the cost rows were written)
+            // is the constant-matrix case of min_cost_matching without gathering its sub-matrix: nothing matched, the first nl unmatched
+            // detections move behind the others when nl < n_left (match_step_wave64 has the same shortcut in registers).  In a dense scene
+            // (90 tracks, 50 detections) two thirds of the cascade's time went into gathering such levels from global memory.
+            unsigned long long any = 0;
+            for (int q = L.lane; q < nl; q += L.n) any |= w.adm[w.rows[q]] ? 1ull : 0ull;
+            if (wave_or(L, any) == 0) {
+                if (nl < n_left) {
+                    for (int e = L.lane; e < n_left; e += L.n) other[e] = left[e + nl < n_left ? e + nl : e + nl - n_left];
+                    int* sw = left; left = other; other = sw;
+                    wave_sync();
+                }
+                continue;
+            }
+        }
         if (nl == 1 || n_left == 1) {
             // One track in the level, or one detection left: the assignment is the minimum of a vector (smallest index among equal
             // minima, lap_solve), and min_cost_matching's list handling reduces to removing the column when the pair is accepted

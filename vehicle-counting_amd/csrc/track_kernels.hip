@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) void track_dots_kernel(const TrackBatchArgs a,
 
 // One wave per track: the gated appearance row from the precomputed table.  Lane = detection (coalesced reads of a table row),
 // loop over the track's ring entries; cost = 1 - max_s <g_s, f_d> / |f_d|.
+// adm_out (StepWork::adm of the track): 1 when some detection of the step is within max_dist of the track, else 0
 __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, const TrackDotPlan& dp, const CostJob& jb, int det_local0,
-                                                     double* out, int lane, const double* m, const double* Pm) {
+                                                     double* out, int lane, const double* m, const double* Pm, double max_dist, unsigned char* adm_out) {
     const TrackPool& tp = a.pool;
     const int S = jb.gal_count, D = jb.det_n, SC = tp.budget_cap;
     const float* tab = a.dot_arena + dp.table_off;
@@ -389,6 +390,7 @@ __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, co
     // lanes = (sample group, detection): with D detections the wave splits into 64 / pow2(D) sample groups, each lane walks every
     // SL-th ring entry (independent loads, all in flight together) and the groups are merged with a few lane exchanges -- a step of
     // a light scene (D ~ 6, S ~ 60) is 8 table reads per lane behind one memory latency instead of 60 behind fifteen
+    bool adm = false;                                    // (uniform)
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int nd = min(64, D - d0);
         int sh = 0;
@@ -423,11 +425,15 @@ __device__ __forceinline__ void appearance_row_table(const TrackBatchArgs& a, co
             for (int k = 0; k < 16; ++k) best = fmaxf(best, v[k]);      // entries past S repeat entry sg: the maximum is unchanged
         }
         for (int o = DL; o < 64; o <<= 1) best = fmaxf(best, __shfl_xor(best, o));
+        double val = VC_GATED;
         if (mine) {
             const float cosv = best * (1.0f / sqrtf(a.det_ss[g]));
-            out[jb.out_off + d0 + dl] = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+            val = g2 > VC_CHI2_95_4 ? VC_GATED : (double)(1.0f - cosv);
+            out[jb.out_off + d0 + dl] = val;
         }
+        adm = adm || __any(mine && !(val > max_dist));
     }
+    if (lane == 0) *adm_out = adm ? 1 : 0;
 }
 
 // ---- slot pool: during a kernel slots are only TAKEN from the free stack (filled before the launch) and freed slots are only
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 const int age = r.age + 1, tsu = r.tsu + 1;
                 r.age = age; r.tsu = tsu;
                 w.slot[t] = slot; w.state[t] = r.state; w.tsu[t] = tsu; w.galc[t] = r.gal_count; w.galh[t] = r.gal_head;
-                w.hits[t] = r.hits; w.id[t] = r.id;
+                w.hits[t] = r.hits; w.id[t] = r.id; w.adm[t] = 1;
             }
             kalman_predict_wave(tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, lane, use_st ? sh.st_mean[t] : nullptr, use_st ? sh.st_cov[t] : nullptr);
             if (use_st && D > 0) {
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 const int st = w.state[t], tsu = w.tsu[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, sh.st_mean[t], sh.st_cov[t]);
+                    appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, sh.st_mean[t], sh.st_cov[t], hdr->max_dist, &w.adm[t]);
                 }
                 if (!(st == CONFIRMED && tsu != 1)) {
                     double b[4];
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(NW * 64) void track_batch_kernel(const TrackBatchAr
                 const int st = w.state[t], tsu = w.tsu[t], slot = w.slot[t];
                 if (st == CONFIRMED) {
                     const CostJob cj{slot, w.galc[t], tk.det_off, D, t * D, tsu};
-                    if (TABLE || dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64);
+                    if (TABLE || dp.use_table) appearance_row_table(a, dp, cj, tk.det_off - plan.det_begin, cost_app, lane, tp.mean + (size_t)slot * 8, tp.cov + (size_t)slot * 64, hdr->max_dist, &w.adm[t]);
                     else if constexpr (!TABLE) appearance_row_wave(tp, cj, a.feat, a.det_featrow, a.det_xyah, cost_app, lane);
                 }
                 if (!(st == CONFIRMED && tsu != 1)) {
