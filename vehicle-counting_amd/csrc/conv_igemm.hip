@@ -1312,12 +1312,13 @@ static int resident_workgroups(K kernel, int threads = 256) {
     return per_cu * cus;
 }
 
-// Grid of a persistent launch.  Workgroup b walks tiles b, b + G, ...: the launch lasts ceil(tiles / G) tile times, so a grid of "all slots but
-// the reserve" can cost a whole extra round -- 200 tiles of the 20 x 20 level on 192 slots: two rounds where 200 workgroups need one; 400 tiles:
-// three rounds instead of two; 800 tiles of a 40 x 40 layer: five instead of four.  Rounds first: the fewest rounds the chip allows (the
-// reserve of 64 slots for the other streams' kernels is given up only when that saves a round), then the smallest grid that still finishes in
-// that many rounds (tiles spread evenly, the slots that are not needed stay free for the ReID queue and the tracker), a multiple of 8 for
-// the XCD-aware tile order.  VC_CONV_BALANCED=0: the old rule (A/B switch).
+// Grid of a persistent launch.  Workgroup b walks tiles b, b + G, ...: the launch lasts ceil(tiles / G) tile times.  The old rule -- every slot
+// but a reserve of 64 for the other streams' kernels (never fewer than 256 slots) -- can cost a whole extra round on the configurations with
+// several workgroups per CU (3200 tiles on 448 of 512 slots: eight rounds where seven do) and always occupies every slot it may, whatever the
+// tile count.  Rounds first: the fewest rounds the chip allows (the reserve is given up only when that saves a round), then the smallest
+// grid that still finishes in that many rounds (800 tiles in four rounds: 200 workgroups, not 256 -- the slots that are not needed stay free
+// for the ReID queue and the tracker), a multiple of 8 for the XCD-aware tile order.  Measured + 0.5 % end to end, two alternations.
+// VC_CONV_BALANCED=0: the old rule (A/B switch).
 static int persistent_grid(int tiles, int slots_hw, int reserve, int slots_override) {
     static const bool balanced = !(getenv("VC_CONV_BALANCED") && atoi(getenv("VC_CONV_BALANCED")) == 0);
     if (slots_override > 0) return tiles > slots_override ? std::max(8, slots_override / 8 * 8) : tiles;
